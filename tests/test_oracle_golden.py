@@ -1,0 +1,162 @@
+"""CPU: the oracle (oracle/) against the golden vectors captured from the reference's own
+Python (ref_*.npz) and from the installed transformers Llama/CLIP (hf_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dpo_ref as D
+from oracle import llava_ref as LR
+from oracle import optim_ref as O
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_logprobs_and_entropy(golden_dir):
+    g = load(golden_dir, "ref_logprobs.npz")
+    lp = D.compute_logprobs(t(g["logits"]), t(g["labels"]), 0)
+    np.testing.assert_allclose(lp.numpy(), g["logprobs"], rtol=1e-6, atol=1e-6)
+    # Quirk Q4: pad cells are exactly (negative) zero
+    assert (lp.numpy()[g["labels"] == 0] == 0).all()
+    assert (torch.signbit(lp).numpy().astype(np.uint8) == g["signbit"]).all()
+    ent = D.entropy_from_logits(t(g["logits"]))
+    np.testing.assert_allclose(ent.numpy(), g["entropies"], rtol=1e-5, atol=1e-6)
+
+
+def test_dpo_loss_variants(golden_dir):
+    g = load(golden_dir, "ref_dpo_loss.npz")
+    pc, pr, rc, rr, sc, sr = (t(g[k]) for k in ("pc", "pr", "rc", "rr", "sc", "sr"))
+    for i, meta in enumerate(g["meta"]):
+        fdiv, ls, rf, scores = str(meta).split("|")
+        cfg = D.DPOConfig(f_divergence_type=fdiv, label_smoothing=float(ls), reference_free=bool(int(rf)))
+        out = D.dpo_loss(cfg, pc, pr, rc, rr, sc if int(scores) else None, sr if int(scores) else None)
+        for got, key in zip(out, ("losses", "c", "r")):
+            np.testing.assert_allclose(got.numpy(), g[f"case{i}_{key}"], rtol=1e-6, atol=1e-7, err_msg=str(meta))
+
+
+def test_compute_policy_loss_and_stats(golden_dir):
+    g = load(golden_dir, "ref_policy_loss.npz")
+    for ci, meta in enumerate(g["meta"]):
+        CoPO, AncPO, mdpo, detailed = (bool(int(x)) for x in str(meta).split("|"))
+        pre = f"c{ci}_"
+        rollouts = {k[len(pre) + 3:]: t(v) for k, v in g.items() if k.startswith(pre + "in_")}
+        pol = {k[len(pre) + 4:]: t(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith(pre + "pol_")}
+        clean = {k: v for k, v in pol.items() if not k.startswith("mask_")}
+        masked = {k: v for k, v in pol.items() if k.startswith("mask_")}
+        cfg = D.DPOConfig(CoPO=CoPO, AncPO=AncPO, mDPO_anchor=mdpo, detailed_report=detailed)
+        loss, stats = D.compute_policy_loss(cfg, rollouts, clean, masked if CoPO else None)
+        np.testing.assert_allclose(loss.item(), g[pre + "loss"], rtol=1e-6, err_msg=str(meta))
+        loss.backward()
+        for k, v in pol.items():
+            want = g[pre + "grad_" + k]
+            got = v.grad.numpy() if v.grad is not None else np.zeros_like(want)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-8, err_msg=f"{meta} {k}")
+        ref_stats = {k[len(pre) + 5:].replace("__", "/"): v for k, v in g.items() if k.startswith(pre + "stat_")}
+        assert set(ref_stats) == set(stats), (set(ref_stats) ^ set(stats))
+        assert len(stats) == 32
+        for k, v in ref_stats.items():
+            np.testing.assert_allclose(stats[k].numpy(), v, rtol=1e-5, atol=1e-7, err_msg=f"{meta} {k}")
+
+
+def test_policy_forward_slicing(golden_dir):
+    """AutoregressivePolicy.forward (rl_models.py:75-144): shift, slice, temperature, masks."""
+    g = load(golden_dir, "ref_policy_forward.npz")
+    queries, qmask = t(g["queries"]), t(g["qmask"]).bool()
+    resp = {k[5:]: t(v) for k, v in g.items() if k.startswith("resp_")}
+    ids, mask = D.stack_policy_inputs(queries, qmask, resp)
+    B, Q = queries.shape
+    T = next(iter(resp.values())).shape[1]
+    lp, ent = D.policy_head(t(g["full_logits"]), ids, Q, T, temperature=0.7)
+    for i, k in enumerate(D.response_keys(resp)):
+        np.testing.assert_allclose(lp[i * B:(i + 1) * B].numpy(), g[f"out_{k}_logprobs"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ent[i * B:(i + 1) * B].numpy(), g[f"out_{k}_entropies"], rtol=1e-5, atol=1e-6)
+
+
+def test_mask_image(golden_dir):
+    g = load(golden_dir, "ref_mask_image.npz")
+    img = t(g["img"])
+    torch.manual_seed(99)
+    np.testing.assert_array_equal(D.mask_single_image(img, 0.3, "random").numpy(), g["random"])
+    torch.manual_seed(99)
+    np.testing.assert_array_equal(D.mask_single_image(img, 0.3, "blockwise").numpy(), g["blockwise"])
+    torch.manual_seed(99)
+    rm = D.mask_percentage_per_row(torch.ones(3, 16, dtype=torch.bool), 0.3)
+    np.testing.assert_array_equal(rm.numpy().astype(np.uint8), g["rowmask"])
+
+
+def test_truncate(golden_dir):
+    g = load(golden_dir, "ref_truncate.npz")
+    comp = t(g["completions"])
+    np.testing.assert_array_equal(D.truncate_after_eos_with_padding(comp, 2, 0).numpy(), g["plain"])
+    np.testing.assert_array_equal(
+        D.truncate_after_eos_with_padding(comp, 2, 0, [1577, 29973]).numpy(), g["with_stops"])
+
+
+def _tiny_dims():
+    return LR.LlavaDims.tiny(hidden=64, n_layers=2, n_heads=2, head_dim=32, ffn=96, vocab=80,
+                             v_hidden=32, v_layers=3, v_heads=2, v_ffn=64, image_size=28, lora_r=8, lora_alpha=16.0)
+
+
+def test_llama_against_hf(golden_dir):
+    g = load(golden_dir, "hf_llama.npz")
+    d = _tiny_dims()
+    W = LR.init_weights(d, seed=int(g["seed"]), std=float(g["std"]))
+    ids, mask = t(g["ids"]), t(g["mask"]).bool()
+    x = W["model.embed_tokens.weight"][ids]
+    h = LR.llama_decoder(x, mask, W, None, d)
+    logits = LR.lm_logits(h, W, d).numpy()
+    valid = g["mask"].astype(bool)
+    np.testing.assert_allclose(logits[valid], g["logits"][valid], rtol=2e-4, atol=2e-4)
+
+
+def test_clip_against_hf(golden_dir):
+    g = load(golden_dir, "hf_clip.npz")
+    d = _tiny_dims()
+    W = LR.init_weights(d, seed=int(g["seed"]), std=float(g["std"]))
+    feats = LR.vision_tower(t(g["pixels"]), W, None, d).numpy()
+    np.testing.assert_allclose(feats, g["feats"], rtol=2e-4, atol=2e-4)
+
+
+def test_accum_arith_and_schedule():
+    # opadpo_train.py:383-433 with the shipped script values at WORLD_SIZE=4
+    assert D.grad_accum_arith(64, 32, 2, 2, 4) == (8, 4)
+    # HF cosine-with-warmup lambda
+    sched = torch.optim.lr_scheduler.LambdaLR
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-6)
+    from transformers.optimization import get_scheduler
+    s = get_scheduler("cosine", optimizer=opt, num_warmup_steps=5, num_training_steps=300)
+    for step in range(0, 40):
+        assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(step, 1e-6, 5, 300)) < 1e-15
+        opt.step()
+        s.step()
+
+
+def test_adamw_against_torch():
+    torch.manual_seed(0)
+    p = torch.randn(257)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        g = torch.randn(257)
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        O.adamw_step(p, g, m, v, step, 1e-3, grad_scale=O.clip_coef(float((g * g).sum()), 1.0))
+        np.testing.assert_allclose(p.numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_last_checkpoint_contract(golden_dir, tmp_path):
+    g = load(golden_dir, "ref_last_checkpoint.npz")
+    assert list(g["first"]) == ["None", "False"]
+    assert list(g["found"]) == ["checkpoint-150", "False"]
+    assert list(g["done"]) == ["None", "True"]
