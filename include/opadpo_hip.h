@@ -1,0 +1,130 @@
+/* libopadpo_hip.so — C ABI of the MI355X (gfx950) OPA-DPO hot path.
+ *
+ * The reference (zhyang2226/OPA-DPO) has no FFI: its hot path is the Python call
+ * `self.base_model(**inputs)` inside AutoregressivePolicy.forward
+ * (opadpo/dpo_models/rl_models.py:114-120) plus loss.backward()/optimizer.step()
+ * (opadpo/dpo_models/rl_trainer.py:155-175), all of which lands in third-party CUDA wheels
+ * (torch/cuBLAS, flash-attn, peft, bitsandbytes).  This header is the seam a maintainer binds
+ * instead (ctypes stub: INTEGRATION.md).  Every entry point:
+ *   - is plain `extern "C"`: raw device pointers + sizes, no torch / C++ types;
+ *   - is asynchronous on the `hipStream_t` passed as `void* stream` (torch's current stream);
+ *   - borrows all memory (the caller — torch-ROCm — owns and keeps it alive);
+ *   - returns 0 on success, a non-zero hipError_t otherwise (`opadpo_last_error()` = text);
+ *     it never aborts and never falls back to a CPU path.
+ * bf16 tensors are `uint16_t` bit patterns (torch.bfloat16).  "ld*" = leading dimension in
+ * elements.  Token ids are int32, pad id 0, image token -200 (utils/constants.py:28).
+ */
+#ifndef OPADPO_HIP_H
+#define OPADPO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPADPO_ABI_VERSION 1
+#define OPADPO_ACT_NONE 0
+#define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
+#define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
+
+int opadpo_abi_version(void);
+const char* opadpo_last_error(void);
+/* kernel-variant switches (diagnostics): use_glds = global_load_lds staging in gemm_nt,
+ * use_tr = ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn. */
+void opadpo_set_flags(int use_glds, int use_tr);
+
+/* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
+ * C[M,N] = act(alpha * (A1[M,K1].B1[N,K1]^T + A2[M,K2].B2[N,K2]^T) + bias) + R
+ * replaces nn.Linear + peft.tuners.lora.Linear.forward (y = xW^T + (alpha/r)(xA^T)B^T) reached
+ * from rl_models.py:120, and their dgrad in backward (rl_trainer.py:162).
+ * A2's column offset for output column n0 is (n0 / a2_group_n) * a2_group_stride (fused q|k|v and
+ * gate|up projections); pass a2_group_n = 0 for a single group.  N % 128 == 0, K1 % 64 == 0,
+ * K2 % 64 == 0; M arbitrary.  out_f32: C is float32 instead of bf16. */
+int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                   const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
+                   int a2_group_n, int a2_group_stride,
+                   void* C, int ldc, int out_f32, const uint16_t* R, int ldr, const uint16_t* bias,
+                   int M, int N, float alpha, int act, void* stream);
+
+/* LoRA weight gradients: C[N1,N2] (fp32) += alpha * sum_m P[m,N1] * Q[m,N2]   (dB = dY^T t,
+ * dA = dT^T x; autograd of peft lora_A / lora_B, rl_trainer.py:162).  Q column offset for output
+ * row n1 is (n1 / q_group_n1) * q_group_stride.  N1 % 128 == 0, N2 % 128 == 0. splits<=0: auto. */
+int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float* C, int ldc,
+                   int M, int N1, int N2, int q_group_n1, int q_group_stride, float alpha, int splits,
+                   void* stream);
+
+/* ---- attention (flash-attn 2.5.3 LlamaFlashAttention2 / CLIP eager attention) -------------------
+ * q,k,v: element (s,pos,head,d) at ptr[(s*L+pos)*ld + head*hd + d]; o/dout with ldo.
+ * key_mask [S,L] bytes (NULL = all keys valid); causal: key pos <= query pos.  hd in {64,128}.
+ * lse [S,nh,L] fp32 (may be NULL in forward when no backward follows). */
+int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
+                    float* lse, const uint8_t* key_mask, int S, int L, int nh, int hd, int causal, float scale,
+                    void* stream);
+/* dq_acc: fp32 [S*L, nh*hd], zeroed by the caller; dk/dv bf16 with the k/v addressing;
+ * delta: fp32 scratch [S,nh,L]. */
+int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
+                    const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
+                    float* dq_acc, uint16_t* dk, uint16_t* dv, float* delta,
+                    int S, int L, int nh, int hd, int causal, float scale, void* stream);
+
+/* ---- norms / rotary / SwiGLU (transformers modeling_llama.py / modeling_clip.py) -------------- */
+int opadpo_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream);
+int opadpo_rmsnorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const float* rstd,
+                       const uint16_t* dres, uint16_t* dx, int rows, int H, void* stream);
+int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
+/* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position r % L);
+ * cos/sin: fp32 [L, hd/2]; inverse=1 applies the transposed rotation (gradient). */
+int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
+                int inverse, void* stream);
+int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream);   /* gu = [gate | up] */
+int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu, int rows, int F, void* stream);
+
+/* ---- embedding gather + multimodal splice (LLaVA prepare_inputs_labels_for_multimodal) ------------
+ * ids/text_mask [S,n_txt]; each row holds exactly one image_token, replaced by the P rows
+ * feats[feat_row[s]] -> x [S, n_txt+P-1, H], key_mask [S, n_txt+P-1].  image_mask [S,P] or NULL. */
+int opadpo_embed_splice(const int32_t* ids, const uint8_t* text_mask, const uint16_t* embed, const uint16_t* feats,
+                        const int32_t* feat_row, const uint8_t* image_mask, uint16_t* x, uint8_t* key_mask,
+                        int S, int n_txt, int P, int H, int image_token, void* stream);
+
+/* ---- CLIP patch embedding (Conv2d k=s=patch as im2col + gemm_nt) ---------------------------------- */
+int opadpo_im2col(const uint16_t* pixels, uint16_t* out, int B, int image_size, int patch, int kpad, void* stream);
+int opadpo_vision_embed(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* x, int B, int P, int h, void* stream);
+
+/* ---- data movement helpers ---------------------------------------------------------------------- */
+int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx, uint16_t* dst, int n, int H, void* stream);
+int opadpo_scatter_rows(const uint16_t* src, const int32_t* rows_idx, uint16_t* dst, int ld_dst, int n, int H, void* stream);
+int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream);
+int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream);
+int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream);
+
+/* ---- head: compute_logprobs (utils/common_utils.py:112-118) + entropy (rl_models.py:128,132) -------
+ * logits fp32 [rows,V] (ldl), labels int32 (0 = pad -> logp = -0.0, ent = 0), z = logits*inv_temp. */
+int opadpo_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,
+                    float* lse, int rows, int V, void* stream);
+/* dz = dlogp * (onehot(label) - softmax(z)) * inv_temp as bf16 [rows,V] (ldz). */
+int opadpo_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
+                    float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream);
+
+/* ---- clip_grad_norm_ + AdamW (rl_trainer.py:164-175; utils/trainer_utils.py:35) ------------------- */
+int opadpo_sumsq(const float* g, size_t n, float* out, void* stream);  /* out[0] += sum g^2 */
+/* p,m,v fp32 [n]; g fp32; p_bf16 (nullable) refreshed; step is 1-based; sumsq (nullable) device
+ * scalar holding ||g||^2; effective gradient = g * grad_div * min(1, max_norm/(||g||*grad_div+1e-6)). */
+int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, size_t n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, const float* sumsq, double max_norm,
+                 double grad_div, void* stream);
+
+/* ---- on-policy rollout (opadpo/generator_models/online_generator.py:292-309) ----------------------
+ * single-token attention over a KV cache: q [B, nh*hd] (ldq), cache [B, max_ctx, nh*hd] bf16,
+ * keys 0..ctx-1 valid where key_mask[b*max_ctx + j] != 0. */
+int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
+                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, int max_ctx, float scale, void* stream);
+/* temperature -> top-k -> top-p -> multinomial (HF logits processors order); one draw per row from
+ * a counter-based generator keyed on (seed, step, row).  finished rows emit pad_id. */
+int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
+                  uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPADPO_HIP_H */

@@ -1,0 +1,371 @@
+// Flash attention forward / backward for gfx950 (bf16 in, fp32 softmax + accumulation).
+//
+// Forward ("swapped" formulation, everything keyed on q = lane & 15):
+//   S^T[key][q] = K . Q^T         (MFMA A = K fragment from LDS, B = Q fragment in registers)
+//   online softmax over keys: in-lane over 16 values + 2 cross-lane-group shuffles
+//   O^T[d][q]  += V^T . P^T       (A = V fragment through ds_read_b64_tr_b16, B = P straight
+//                                  from the S accumulators — no LDS round trip for P)
+// Block = 4 waves x 16 q rows = 64 q rows of one (sequence, head); KV tiles of 64 keys.
+// Masking: causal and/or an arbitrary per-key byte mask [S,L] (left-padded queries,
+// right-padded responses, CoPO 'attention' image-key dropping).
+//
+// Backward (FlashAttention-2 style): block = one KV tile (64 keys) of one (sequence, head),
+// wave w owns keys w*16..+15 (dK/dV in registers), loops over q tiles; dQ goes to an fp32
+// accumulation buffer with atomics.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// lane gets tile[r0 + j][c0 + c] (j = 0..3) and tile[r1 + j][c0 + c] (slots 4..7), c = lane & 15.
+// r0 / r1 already include the lane-group term.
+template <bool TR>
+__device__ __forceinline__ bf16x8_t lds_frag_rows2(const char* tile, int ld_bytes, int r0, int r1, int c0, int lane) {
+  union { bf16x8_t v; s16x4_t h[2]; uint16_t s[8]; } u;
+  const int c = lane & 15;
+  if constexpr (TR) {
+    const int colb = (c0 + (c & 3) * 4) * 2;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile + (size_t)(r0 + (c >> 2)) * ld_bytes + colb));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile + (size_t)(r1 + (c >> 2)) * ld_bytes + colb));
+  } else {
+    const char* p0 = tile + (size_t)r0 * ld_bytes + (c0 + c) * 2;
+    const char* p1 = tile + (size_t)r1 * ld_bytes + (c0 + c) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u.s[j] = *(const uint16_t*)(p0 + j * ld_bytes);
+      u.s[4 + j] = *(const uint16_t*)(p1 + j * ld_bytes);
+    }
+  }
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& a, const f32x4_t& b) {
+  union { bf16x8_t v; uint32_t w[4]; } u;
+  u.w[0] = pack_bf2(a[0], a[1]); u.w[1] = pack_bf2(a[2], a[3]);
+  u.w[2] = pack_bf2(b[0], b[1]); u.w[3] = pack_bf2(b[2], b[3]);
+  return u.v;
+}
+
+// stage a [64][HD] tile (rows = positions pos0.. of sequence s) into LDS row-major, zero past L
+template <int HD>
+__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int ld, int s, int L, int pos0, int head, int tid) {
+  constexpr int CPR = HD / 8;  // 16-byte chunks per row
+#pragma unroll
+  for (int i = 0; i < (64 * CPR) / 256; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / CPR, c16 = idx % CPR;
+    const int pos = pos0 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (pos < L) v = *(const uint4*)(src + ((size_t)s * L + pos) * ld + head * HD + c16 * 8);
+    *(uint4*)(dst + row * (HD * 2) + c16 * 16) = v;
+  }
+}
+
+template <int HD, bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 64];
+  char* Ks = smem;
+  char* Vs = smem + 64 * HD * 2;
+  uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
+  constexpr int KK = HD / 32, DF = HD / 16, LD = HD * 2;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int s = blockIdx.z, h = blockIdx.y;
+  // heavier (later) causal tiles first
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int q0 = qt * 64;
+  const int L = p.L;
+  const int qpos = q0 + w * 16 + c;
+  const int qrow = min(qpos, L - 1);
+
+  bf16x8_t qf[KK];
+  {
+    const bf16_t* qp = p.q + ((size_t)s * L + qrow) * p.ld + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      uint4 v = *(const uint4*)(qp + kk * 32 + g * 8);
+      qf[kk] = *(bf16x8_t*)&v;
+    }
+  }
+  f32x4_t o[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) o[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kt * 64;
+    stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
+    stage_tile<HD>(Vs, p.v, p.ld, s, L, k0, h, tid);
+    if (tid < 64) {
+      const int kp = k0 + tid;
+      Ms[tid] = (kp < L) ? (p.key_mask ? p.key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+    }
+    __syncthreads();
+
+    f32x4_t sc[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      sc[kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const bf16x8_t kfr = *(const bf16x8_t*)(Ks + (kf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
+        sc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], sc[kf], 0, 0, 0);
+      }
+    }
+    // sc[kf][r] = S^T[key = kf*16 + g*4 + r][q = c]
+    float mx = NEG_BIG;
+    bool ok[4][4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kl = kf * 16 + g * 4 + r;
+        const int kp = k0 + kl;
+        ok[kf][r] = Ms[kl] && (!p.causal || kp <= qpos);
+        sc[kf][r] = ok[kf][r] ? sc[kf][r] * p.scale : NEG_BIG;
+        mx = fmaxf(mx, sc[kf][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = ok[kf][r] ? __expf(sc[kf][r] - m_new) : 0.f;
+        sc[kf][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t pf = pack_frag(sc[2 * ks], sc[2 * ks + 1]);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const bf16x8_t vf = lds_frag_rows2<TR>(Vs, LD, (2 * ks) * 16 + g * 4, (2 * ks + 1) * 16 + g * 4, d * 16, lane);
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qpos < L) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* op = p.o + ((size_t)s * L + qpos) * p.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      uint2 v;
+      v.x = pack_bf2(o[d][0] * inv, o[d][1] * inv);
+      v.y = pack_bf2(o[d][2] * inv, o[d][3] * inv);
+      *(uint2*)(op + d * 16 + g * 4) = v;
+    }
+    if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = l_run > 0.f ? m_run + __logf(l_run) : NEG_BIG;
+  }
+}
+
+// delta[s,h,pos] = sum_d dO * O
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (row, head)
+  const int lane = threadIdx.x & 63;
+  const int total = p.S * p.L * p.nh;
+  if (idx >= total) return;
+  const int row = idx / p.nh, h = idx % p.nh;
+  float acc = 0.f;
+  if (lane < HD / 2) {
+    const uint32_t a = *(const uint32_t*)(p.dout + (size_t)row * p.ldo + h * HD + lane * 2);
+    const uint32_t b = *(const uint32_t*)(p.o + (size_t)row * p.ldo + h * HD + lane * 2);
+    acc = __uint_as_float(a << 16) * __uint_as_float(b << 16) +
+          __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const int s = row / p.L, pos = row % p.L;
+    p.delta[((size_t)s * p.nh + h) * p.L + pos] = acc;
+  }
+}
+
+template <int HD, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+  constexpr int KK = HD / 32, DF = HD / 16, LD = HD * 2;
+  constexpr int TILE = 64 * HD * 2;
+  __shared__ __attribute__((aligned(16))) char smem[3 * TILE + 64 * 64 * 2 + 64 * 4 * 2 + 64];
+  char* Qs = smem;
+  char* dOs = smem + TILE;
+  char* Ks = smem + 2 * TILE;
+  char* dSs = smem + 3 * TILE;                       // [64 q][64 keys] bf16
+  float* lse_s = (float*)(dSs + 64 * 64 * 2);
+  float* dlt_s = lse_s + 64;
+  uint8_t* Ms = (uint8_t*)(dlt_s + 64);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int s = blockIdx.z, h = blockIdx.y, kt = blockIdx.x;
+  const int L = p.L;
+  const int k0 = kt * 64;
+  const int kpos = k0 + w * 16 + c;          // this lane's key (as fragment row / output row)
+  const int krow = min(kpos, L - 1);
+
+  stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
+  if (tid < 64) {
+    const int kp = k0 + tid;
+    Ms[tid] = (kp < L) ? (p.key_mask ? p.key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+  }
+  bf16x8_t kf[KK], vf[KK];
+  {
+    const bf16_t* kp_ = p.k + ((size_t)s * L + krow) * p.ld + h * HD;
+    const bf16_t* vp_ = p.v + ((size_t)s * L + krow) * p.ld + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      uint4 a = *(const uint4*)(kp_ + kk * 32 + g * 8);
+      uint4 b = *(const uint4*)(vp_ + kk * 32 + g * 8);
+      kf[kk] = *(bf16x8_t*)&a;
+      vf[kk] = *(bf16x8_t*)&b;
+    }
+  }
+  f32x4_t dk[DF], dv[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) { dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+  const bool key_ok = Ms[w * 16 + c] != 0;
+
+  const int n_qt = (L + 63) / 64;
+  const int qt_begin = p.causal ? kt : 0;
+  for (int qt = qt_begin; qt < n_qt; ++qt) {
+    const int q0 = qt * 64;
+    stage_tile<HD>(Qs, p.q, p.ld, s, L, q0, h, tid);
+    stage_tile<HD>(dOs, p.dout, p.ldo, s, L, q0, h, tid);
+    if (tid < 64) {
+      const int qp = q0 + tid;
+      const size_t li = ((size_t)s * p.nh + h) * L + min(qp, L - 1);
+      lse_s[tid] = p.lse[li];
+      dlt_s[tid] = p.delta[li];
+    }
+    __syncthreads();
+
+    f32x4_t sc[4], dp[4];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf) {
+      sc[qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const bf16x8_t qfr = *(const bf16x8_t*)(Qs + (qf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
+        const bf16x8_t dofr = *(const bf16x8_t*)(dOs + (qf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
+        // D[i = q][j = key]: lane holds key = c, q = qf*16 + g*4 + r
+        sc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], sc[qf], 0, 0, 0);
+        dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dp[qf], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qf * 16 + g * 4 + r;
+        const int qp = q0 + ql;
+        const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp);
+        const float pv = ok ? __expf(sc[qf][r] * p.scale - lse_s[ql]) : 0.f;
+        const float ds = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
+        sc[qf][r] = pv;
+        dp[qf][r] = ds;
+        *(bf16_t*)(dSs + ql * 128 + (w * 16 + c) * 2) = f2bf(ds);
+      }
+    // dV^T[d][key] += dO^T . P ; dK^T[d][key] += Q^T . dS   (contraction over the 64 q rows)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t pf = pack_frag(sc[2 * ks], sc[2 * ks + 1]);
+      const bf16x8_t dsf = pack_frag(dp[2 * ks], dp[2 * ks + 1]);
+      const int r0 = (2 * ks) * 16 + g * 4, r1 = (2 * ks + 1) * 16 + g * 4;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const bf16x8_t dof = lds_frag_rows2<TR>(dOs, LD, r0, r1, d * 16, lane);
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[d], 0, 0, 0);
+        const bf16x8_t qf2 = lds_frag_rows2<TR>(Qs, LD, r0, r1, d * 16, lane);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2, dsf, dk[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // dS tile complete
+    // dQ[q = w*16 + c][d] = sum over the 64 keys of dS[q][key] * K[key][d]
+    {
+      f32x4_t dq[DF];
+#pragma unroll
+      for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t dsf = *(const bf16x8_t*)(dSs + (w * 16 + c) * 128 + (ks * 32 + g * 8) * 2);
+#pragma unroll
+        for (int d = 0; d < DF; ++d) {
+          const bf16x8_t kfr = lds_frag_rows2<TR>(Ks, LD, ks * 32 + g * 8, ks * 32 + g * 8 + 4, d * 16, lane);
+          dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf, dq[d], 0, 0, 0);
+        }
+      }
+      const int qp = q0 + w * 16 + c;
+      if (qp < L) {
+        float* dst = p.dq_acc + ((size_t)s * L + qp) * (p.nh * HD) + h * HD;
+#pragma unroll
+        for (int d = 0; d < DF; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(dst + d * 16 + g * 4 + r, dq[d][r]);
+      }
+    }
+    __syncthreads();
+  }
+  if (kpos < L) {
+    bf16_t* dkp = p.dk + ((size_t)s * L + kpos) * p.ld + h * HD;
+    bf16_t* dvp = p.dv + ((size_t)s * L + kpos) * p.ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      uint2 a, b;
+      a.x = pack_bf2(dk[d][0], dk[d][1]); a.y = pack_bf2(dk[d][2], dk[d][3]);
+      b.x = pack_bf2(dv[d][0], dv[d][1]); b.y = pack_bf2(dv[d][2], dv[d][3]);
+      *(uint2*)(dkp + d * 16 + g * 4) = a;
+      *(uint2*)(dvp + d * 16 + g * 4) = b;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  if (a.S <= 0 || a.L <= 0) return hipSuccess;
+  const dim3 grid((a.L + 63) / 64, a.nh, a.S);
+  const bool tr = opadpo_flag_tr();
+  if (a.hd == 128) {
+    if (tr) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, st, a);
+  } else if (a.hd == 64) {
+    if (tr) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, st, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
+  if (a.S <= 0 || a.L <= 0) return hipSuccess;
+  if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
+  const int total = a.S * a.L * a.nh;
+  const dim3 grid((a.L + 63) / 64, a.nh, a.S);
+  const bool tr = opadpo_flag_tr();
+  if (a.hd == 128) {
+    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((total + 3) / 4), dim3(256), 0, st, a);
+    if (tr) hipLaunchKernelGGL((attn_bwd_kernel<128, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<128, false>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((total + 3) / 4), dim3(256), 0, st, a);
+    if (tr) hipLaunchKernelGGL((attn_bwd_kernel<64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<64, false>), grid, dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,176 @@
+// extern "C" boundary of libopadpo_hip.so (declared in include/opadpo_hip.h).
+// Host-side validation only; every kernel launch is asynchronous on the caller's stream.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "kernels.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+int bad(const char* where, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+  return (int)hipErrorInvalidValue;
+}
+inline int done(hipError_t e, const char* where) { return e == hipSuccess ? 0 : fail(e, where); }
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+}  // namespace
+
+extern "C" {
+
+int opadpo_abi_version(void) { return OPADPO_ABI_VERSION; }
+const char* opadpo_last_error(void) { return g_err; }
+void opadpo_set_flags(int use_glds, int use_tr) { opadpo_set_flags_impl(use_glds, use_tr); }
+
+int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                   const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
+                   int a2_group_n, int a2_group_stride,
+                   void* C, int ldc, int out_f32, const uint16_t* R, int ldr, const uint16_t* bias,
+                   int M, int N, float alpha, int act, void* stream) {
+  if (M < 0 || N <= 0 || N % 128) return bad("opadpo_gemm_nt", "N must be a positive multiple of 128");
+  if (K1 < 0 || K2 < 0 || K1 % 64 || K2 % 64 || K1 + K2 == 0) return bad("opadpo_gemm_nt", "K1/K2 must be multiples of 64");
+  if ((K1 && (!A1 || !B1)) || (K2 && (!A2 || !B2)) || !C) return bad("opadpo_gemm_nt", "null operand");
+  if (lda1 % 8 || ldb1 % 8 || (K2 && (lda2 % 8 || ldb2 % 8)) || ldc % 4 || (R && ldr % 4))
+    return bad("opadpo_gemm_nt", "leading dimensions must keep 16-byte operand / 8-byte output alignment");
+  if (a2_group_n && a2_group_n % 128) return bad("opadpo_gemm_nt", "a2_group_n must be a multiple of the 128-column tile");
+  GemmNTArgs a;
+  a.A1 = A1; a.B1 = B1; a.A2 = A2; a.B2 = B2; a.C = C; a.R = R; a.bias = bias;
+  a.M = M; a.N = N; a.K1 = K1; a.K2 = K2;
+  a.lda1 = lda1; a.ldb1 = ldb1; a.lda2 = lda2; a.ldb2 = ldb2; a.ldc = ldc; a.ldr = ldr;
+  a.a2_group_n = a2_group_n; a.a2_group_stride = a2_group_stride;
+  a.alpha = alpha; a.act = act; a.out_f32 = out_f32;
+  return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt");
+}
+
+int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float* C, int ldc,
+                   int M, int N1, int N2, int q_group_n1, int q_group_stride, float alpha, int splits,
+                   void* stream) {
+  if (N1 <= 0 || N2 <= 0 || N1 % 128 || N2 % 128) return bad("opadpo_gemm_tn", "N1/N2 must be positive multiples of 128");
+  if (!P || !Q || !C || ldp % 8 || ldq % 8) return bad("opadpo_gemm_tn", "null operand or misaligned leading dimension");
+  if (q_group_n1 && q_group_n1 % 128) return bad("opadpo_gemm_tn", "q_group_n1 must be a multiple of 128");
+  GemmTNArgs a;
+  a.P = P; a.Q = Q; a.C = C; a.M = M; a.N1 = N1; a.N2 = N2; a.ldp = ldp; a.ldq = ldq; a.ldc = ldc;
+  a.q_group_n1 = q_group_n1; a.q_group_stride = q_group_stride; a.alpha = alpha; a.splits = splits;
+  return done(launch_gemm_tn(a, S(stream)), "opadpo_gemm_tn");
+}
+
+int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
+                    float* lse, const uint8_t* key_mask, int S_, int L, int nh, int hd, int causal, float scale,
+                    void* stream) {
+  if (hd != 64 && hd != 128) return bad("opadpo_attn_fwd", "head_dim must be 64 or 128");
+  if (!q || !k || !v || !o || ld % 8 || ldo % 4) return bad("opadpo_attn_fwd", "null operand or misaligned leading dimension");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.key_mask = key_mask;
+  a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
+  return done(launch_attn_fwd(a, S(stream)), "opadpo_attn_fwd");
+}
+
+int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
+                    const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
+                    float* dq_acc, uint16_t* dk, uint16_t* dv, float* delta,
+                    int S_, int L, int nh, int hd, int causal, float scale, void* stream) {
+  if (hd != 64 && hd != 128) return bad("opadpo_attn_bwd", "head_dim must be 64 or 128");
+  if (!q || !k || !v || !o || !dout || !lse || !dq_acc || !dk || !dv || !delta || ld % 8 || ldo % 8)
+    return bad("opadpo_attn_bwd", "null operand or misaligned leading dimension");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q; a.k = k; a.v = v; a.o = (uint16_t*)o; a.lse = (float*)lse; a.key_mask = key_mask;
+  a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
+  a.dout = dout; a.dq_acc = dq_acc; a.dk = dk; a.dv = dv; a.delta = delta;
+  return done(launch_attn_bwd(a, S(stream)), "opadpo_attn_bwd");
+}
+
+int opadpo_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream) {
+  return done(launch_rmsnorm_fwd(x, w, y, rstd, rows, H, eps, S(stream)), "opadpo_rmsnorm_fwd");
+}
+int opadpo_rmsnorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const float* rstd,
+                       const uint16_t* dres, uint16_t* dx, int rows, int H, void* stream) {
+  return done(launch_rmsnorm_bwd(dy, x, w, rstd, dres, dx, rows, H, S(stream)), "opadpo_rmsnorm_bwd");
+}
+int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream) {
+  return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
+}
+int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
+                int inverse, void* stream) {
+  if (ld % 8) return bad("opadpo_rope", "misaligned leading dimension");
+  return done(launch_rope(qk, ld, cos_tab, sin_tab, rows, L, n_heads, hd, inverse, S(stream)), "opadpo_rope");
+}
+int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream) {
+  return done(launch_silu_mul_fwd(gu, act, rows, F, S(stream)), "opadpo_silu_mul_fwd");
+}
+int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu, int rows, int F, void* stream) {
+  return done(launch_silu_mul_bwd(dact, gu, dgu, rows, F, S(stream)), "opadpo_silu_mul_bwd");
+}
+int opadpo_embed_splice(const int32_t* ids, const uint8_t* text_mask, const uint16_t* embed, const uint16_t* feats,
+                        const int32_t* feat_row, const uint8_t* image_mask, uint16_t* x, uint8_t* key_mask,
+                        int S_, int n_txt, int P, int H, int image_token, void* stream) {
+  if (!ids || !text_mask || !embed || !feats || !feat_row || !x || !key_mask) return bad("opadpo_embed_splice", "null operand");
+  return done(launch_embed_splice(ids, text_mask, embed, feats, feat_row, image_mask, x, key_mask, S_, n_txt, P, H,
+                                  image_token, S(stream)), "opadpo_embed_splice");
+}
+int opadpo_im2col(const uint16_t* pixels, uint16_t* out, int B, int image_size, int patch, int kpad, void* stream) {
+  if (image_size % patch || kpad < 3 * patch * patch) return bad("opadpo_im2col", "bad geometry");
+  return done(launch_im2col(pixels, out, B, image_size, patch, kpad, S(stream)), "opadpo_im2col");
+}
+int opadpo_vision_embed(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* x, int B, int P, int h, void* stream) {
+  return done(launch_vision_embed(patches, cls, pos, x, B, P, h, S(stream)), "opadpo_vision_embed");
+}
+int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx, uint16_t* dst, int n, int H, void* stream) {
+  if (ld_src % 8) return bad("opadpo_gather_rows", "misaligned leading dimension");
+  return done(launch_gather_rows(src, ld_src, rows_idx, dst, n, H, S(stream)), "opadpo_gather_rows");
+}
+int opadpo_scatter_rows(const uint16_t* src, const int32_t* rows_idx, uint16_t* dst, int ld_dst, int n, int H, void* stream) {
+  if (ld_dst % 8) return bad("opadpo_scatter_rows", "misaligned leading dimension");
+  return done(launch_scatter_rows(src, rows_idx, dst, ld_dst, n, H, S(stream)), "opadpo_scatter_rows");
+}
+int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream) {
+  return done(launch_transpose(in, out, R, C, S(stream)), "opadpo_transpose");
+}
+int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream) {
+  return done(launch_f32_to_bf16(in, out, n, S(stream)), "opadpo_f32_to_bf16");
+}
+int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream) {
+  if (ld % 4) return bad("opadpo_f32_to_bf16_strided", "misaligned leading dimension");
+  return done(launch_f32_to_bf16_strided(in, out, rows, C, ld, S(stream)), "opadpo_f32_to_bf16_strided");
+}
+int opadpo_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,
+                    float* lse, int rows, int V, void* stream) {
+  if (!logits || !labels || !logp || !ent || !lse) return bad("opadpo_head_fwd", "null operand");
+  return done(launch_head_fwd(logits, ldl, labels, inv_temp, logp, ent, lse, rows, V, S(stream)), "opadpo_head_fwd");
+}
+int opadpo_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
+                    float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream) {
+  if (!logits || !labels || !lse || !dlogp || !dz) return bad("opadpo_head_bwd", "null operand");
+  return done(launch_head_bwd(logits, ldl, labels, lse, dlogp, inv_temp, dz, ldz, rows, V, S(stream)), "opadpo_head_bwd");
+}
+int opadpo_sumsq(const float* g, size_t n, float* out, void* stream) {
+  return done(launch_sumsq(g, n, out, S(stream)), "opadpo_sumsq");
+}
+int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, size_t n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, const float* sumsq, double max_norm,
+                 double grad_div, void* stream) {
+  if (step < 1) return bad("opadpo_adamw", "step is 1-based");
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  return done(launch_adamw(p, g, m, v, p_bf16, n, (float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay,
+                           (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)grad_div, S(stream)), "opadpo_adamw");
+}
+int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
+                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, int max_ctx, float scale, void* stream) {
+  if (ctx > max_ctx) return bad("opadpo_attn_decode", "ctx > max_ctx");
+  return done(launch_attn_decode(q, k_cache, v_cache, o, key_mask, B, nh, hd, ctx, max_ctx, ldq, scale, S(stream)),
+              "opadpo_attn_decode");
+}
+int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
+                  uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, void* stream) {
+  if (temperature <= 0.f) return bad("opadpo_sample", "temperature must be > 0");
+  return done(launch_sample(logits, ldl, rows, V, temperature, top_k, top_p, seed, step, finished, pad_id, out, S(stream)),
+              "opadpo_sample");
+}
+
+}  // extern "C"

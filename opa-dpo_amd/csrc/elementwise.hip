@@ -1,0 +1,398 @@
+// HBM-bound row / elementwise kernels (bf16 storage, fp32 math, 16-byte vector accesses).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- RMSNorm ------------------------------------------------------------------------------
+// one block (256 threads) per row; H % 8 == 0.  y = x * rsqrt(mean(x^2) + eps) * w
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd,
+                                                           int H, float eps) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  const bf16_t* xr = x + row * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + i), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+  }
+  ss = block_sum_256(ss, red);
+  const float r = rsqrtf(ss / H + eps);
+  if (rstd && threadIdx.x == 0) rstd[row] = r;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8], g[8];
+    unpack8(*(const uint4*)(xr + i), f);
+    unpack8(*(const uint4*)(w + i), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] * r * g[j];
+    *(uint4*)(y + row * H + i) = pack8(f);
+  }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) (+ dres),  g = dy * w, xhat = x * rstd
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* w,
+                                                           const float* rstd, const bf16_t* dres, bf16_t* dx, int H) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  const float r = rstd[row];
+  float dot = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float a[8], b[8], c[8];
+    unpack8(*(const uint4*)(dy + row * H + i), a);
+    unpack8(*(const uint4*)(x + row * H + i), b);
+    unpack8(*(const uint4*)(w + i), c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += a[j] * c[j] * b[j] * r;
+  }
+  dot = block_sum_256(dot, red) / H;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float a[8], b[8], c[8], o[8];
+    unpack8(*(const uint4*)(dy + row * H + i), a);
+    unpack8(*(const uint4*)(x + row * H + i), b);
+    unpack8(*(const uint4*)(w + i), c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = r * (a[j] * c[j] - b[j] * r * dot);
+    if (dres) {
+      float d[8];
+      unpack8(*(const uint4*)(dres + row * H + i), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += d[j];
+    }
+    *(uint4*)(dx + row * H + i) = pack8(o);
+  }
+}
+
+// ---- LayerNorm (CLIP) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b,
+                                                             bf16_t* y, int H, float eps) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  const bf16_t* xr = x + row * H;
+  float s = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + i), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j];
+  }
+  const float mean = block_sum_256(s, red) / H;
+  float v = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + i), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; v += d * d; }
+  }
+  const float r = rsqrtf(block_sum_256(v, red) / H + eps);
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8], g[8], c[8];
+    unpack8(*(const uint4*)(xr + i), f);
+    unpack8(*(const uint4*)(w + i), g);
+    unpack8(*(const uint4*)(b + i), c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * r * g[j] + c[j];
+    *(uint4*)(y + row * H + i) = pack8(f);
+  }
+}
+
+// ---- RoPE (half-split rotate, HF Llama) ------------------------------------------------------
+// buffer qk: row r (= s*L + pos), head-major columns; rotates n_heads heads starting at column 0
+// (call once for the q section and once for the k section, or with 2*n_heads when contiguous).
+// forward: x' = x*cos + rot(x)*sin ; inverse (gradient): g' = g*cos - rot(g)*sin  with rot(x) = [-x2, x1]
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const float* cosb, const float* sinb,
+                                                    size_t total, int L, int n_heads, int hd, int inverse) {
+  const int half = hd / 2;
+  const int per_row = n_heads * (half / 8);     // 8 (x1,x2) pairs per thread
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / per_row;
+    const int rem = (int)(idx % per_row);
+    const int head = rem / (half / 8), i0 = (rem % (half / 8)) * 8;
+    const int pos = (int)(row % L);
+    bf16_t* base = qk + row * ld + head * hd;
+    float x1[8], x2[8];
+    unpack8(*(const uint4*)(base + i0), x1);
+    unpack8(*(const uint4*)(base + half + i0), x2);
+    const float* cp = cosb + (size_t)pos * half + i0;
+    const float* sp = sinb + (size_t)pos * half + i0;
+    float o1[8], o2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float c = cp[j], s = inverse ? -sp[j] : sp[j];
+      o1[j] = x1[j] * c - x2[j] * s;
+      o2[j] = x2[j] * c + x1[j] * s;
+    }
+    *(uint4*)(base + i0) = pack8(o1);
+    *(uint4*)(base + half + i0) = pack8(o2);
+  }
+}
+
+// ---- SwiGLU ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* gu, bf16_t* act, size_t rows, int F) {
+  const int per_row = F / 8;
+  const size_t total = rows * per_row;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / per_row;
+    const int i = (int)(idx % per_row) * 8;
+    float g[8], u[8], o[8];
+    unpack8(*(const uint4*)(gu + row * 2 * F + i), g);
+    unpack8(*(const uint4*)(gu + row * 2 * F + F + i), u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.0f + __expf(-g[j])) * u[j];
+    *(uint4*)(act + row * F + i) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu,
+                                                            size_t rows, int F) {
+  const int per_row = F / 8;
+  const size_t total = rows * per_row;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / per_row;
+    const int i = (int)(idx % per_row) * 8;
+    float g[8], u[8], d[8], dg[8], du[8];
+    unpack8(*(const uint4*)(gu + row * 2 * F + i), g);
+    unpack8(*(const uint4*)(gu + row * 2 * F + F + i), u);
+    unpack8(*(const uint4*)(dact + row * F + i), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-g[j]));
+      const float silu = g[j] * sg;
+      du[j] = d[j] * silu;
+      dg[j] = d[j] * u[j] * sg * (1.0f + g[j] * (1.0f - sg));
+    }
+    *(uint4*)(dgu + row * 2 * F + i) = pack8(dg);
+    *(uint4*)(dgu + row * 2 * F + F + i) = pack8(du);
+  }
+}
+
+// ---- embedding gather + multimodal splice --------------------------------------------------
+// Row s: ids[s, 0..n_txt) with exactly one image_token at position p -> output row layout
+// [text before | P image features | text after], L = n_txt + P - 1.  One block per output
+// position.  Also emits the key mask [S,L].
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed,
+                                                            const bf16_t* feats, const int32_t* feat_row,
+                                                            const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                                                            int n_txt, int P, int H, int image_token) {
+  __shared__ int img_pos;
+  const int s = blockIdx.y, pos = blockIdx.x;
+  const int L = n_txt + P - 1;
+  if (threadIdx.x == 0) img_pos = n_txt;   // "no image token" -> plain text row (never for valid input)
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_txt; i += 256)
+    if (ids[(size_t)s * n_txt + i] == image_token) img_pos = i;
+  __syncthreads();
+  const int ip = img_pos;
+  const bf16_t* src;
+  uint8_t m;
+  if (pos < ip) {
+    const int t = pos;
+    const int id = ids[(size_t)s * n_txt + t];
+    src = embed + (size_t)max(id, 0) * H;
+    m = text_mask[(size_t)s * n_txt + t];
+  } else if (pos < ip + P && ip < n_txt) {
+    const int j = pos - ip;
+    src = feats + ((size_t)feat_row[s] * P + j) * H;
+    m = image_mask ? image_mask[(size_t)s * P + j] : (uint8_t)1;
+  } else {
+    const int t = pos - (ip < n_txt ? P - 1 : 0);
+    const int id = ids[(size_t)s * n_txt + min(t, n_txt - 1)];
+    src = embed + (size_t)max(id, 0) * H;
+    m = text_mask[(size_t)s * n_txt + min(t, n_txt - 1)];
+  }
+  bf16_t* dst = x + ((size_t)s * L + pos) * H;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) *(uint4*)(dst + i) = *(const uint4*)(src + i);
+  if (threadIdx.x == 0) key_mask[(size_t)s * L + pos] = m;
+}
+
+// ---- CLIP patch embedding helpers -------------------------------------------------------------
+// im2col for the stride==kernel conv: out[(b*P + py*G + px), k = c*patch*patch + dy*patch + dx], zero padded to kpad
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* pixels, bf16_t* out, int image_size, int patch, int kpad) {
+  const int G = image_size / patch;
+  const int P = G * G;
+  const size_t prow = blockIdx.x;           // b*P + p
+  const int b = (int)(prow / P), pp = (int)(prow % P);
+  const int py = pp / G, px = pp % G;
+  const int K = 3 * patch * patch;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    bf16_t v = 0;
+    if (k < K) {
+      const int ch = k / (patch * patch), r = k % (patch * patch);
+      const int dy = r / patch, dx = r % patch;
+      v = pixels[(((size_t)b * 3 + ch) * image_size + (py * patch + dy)) * image_size + px * patch + dx];
+    }
+    out[prow * kpad + k] = v;
+  }
+}
+
+// x[b, 0] = cls + pos[0] ; x[b, 1+p] = patches[b*P+p] + pos[1+p]
+__global__ __launch_bounds__(256) void vision_embed_kernel(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos,
+                                                            bf16_t* x, int P, int h) {
+  const int b = blockIdx.y, t = blockIdx.x;   // t in [0, P]
+  const bf16_t* src = (t == 0) ? cls : patches + ((size_t)b * P + t - 1) * h;
+  for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
+    float a[8], c[8];
+    unpack8(*(const uint4*)(src + i), a);
+    unpack8(*(const uint4*)(pos + (size_t)t * h + i), c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += c[j];
+    *(uint4*)(x + ((size_t)b * (P + 1) + t) * h + i) = pack8(a);
+  }
+}
+
+// ---- row gather / scatter ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* src, int ld_src, const int32_t* rows_idx,
+                                                           bf16_t* dst, int H) {
+  const size_t r = blockIdx.x;
+  const bf16_t* s = src + (size_t)rows_idx[r] * ld_src;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) *(uint4*)(dst + r * H + i) = *(const uint4*)(s + i);
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst,
+                                                            int ld_dst, int H) {
+  const size_t r = blockIdx.x;
+  bf16_t* d = dst + (size_t)rows_idx[r] * ld_dst;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) *(uint4*)(d + i) = *(const uint4*)(src + r * H + i);
+}
+
+// ---- bf16 transpose [R,C] -> [C,R] through a 64x64 LDS tile -----------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, bf16_t* out, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? in[(size_t)(r0 + r) * C + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < C) out[(size_t)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(in + i);
+      uint2 o;
+      o.x = pack_bf2(v.x, v.y);
+      o.y = pack_bf2(v.z, v.w);
+      *(uint2*)(out + i) = o;
+    } else {
+      for (size_t j = i; j < n; ++j) out[j] = f2bf(in[j]);
+    }
+  }
+}
+
+// fp32 [rows, C] contiguous -> bf16 columns [0, C) of a wider buffer with leading dimension ld
+__global__ __launch_bounds__(256) void f32_to_bf16_strided_kernel(const float* in, bf16_t* out, size_t rows, int C, int ld) {
+  const int per_row = C / 4;
+  const size_t total = rows * per_row;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / per_row;
+    const int i = (int)(idx % per_row) * 4;
+    const float4 v = *(const float4*)(in + row * C + i);
+    uint2 o;
+    o.x = pack_bf2(v.x, v.y);
+    o.y = pack_bf2(v.z, v.w);
+    *(uint2*)(out + row * ld + i) = o;
+  }
+}
+
+inline int ew_grid(size_t total_threads) {
+  size_t b = (total_threads + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+hipError_t launch_rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
+                              bf16_t* dx, int rows, int H, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, rstd, dres, dx, H);
+  return hipGetLastError();
+}
+hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
+                       int inverse, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (hd % 16) return hipErrorInvalidValue;
+  const size_t total = (size_t)rows * n_heads * (hd / 16);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse);
+  return hipGetLastError();
+}
+hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (F % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, gu, act, (size_t)rows, F);
+  return hipGetLastError();
+}
+hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (F % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, dact, gu, dgu, (size_t)rows, F);
+  return hipGetLastError();
+}
+hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
+                               const int32_t* feat_row, const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                               int S, int n_txt, int P, int H, int image_token, hipStream_t st) {
+  if (S <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_splice_kernel, dim3(n_txt + P - 1, S), dim3(256), 0, st, ids, text_mask, embed, feats, feat_row,
+                     image_mask, x, key_mask, n_txt, P, H, image_token);
+  return hipGetLastError();
+}
+hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int G = image_size / patch;
+  hipLaunchKernelGGL(im2col_kernel, dim3(B * G * G), dim3(256), 0, st, pixels, out, image_size, patch, kpad);
+  return hipGetLastError();
+}
+hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  if (h % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vision_embed_kernel, dim3(P + 1, B), dim3(256), 0, st, patches, cls, pos, x, P, h);
+  return hipGetLastError();
+}
+hipError_t launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* rows_idx, bf16_t* dst, int n, int H, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, st, src, ld_src, rows_idx, dst, H);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst, int ld_dst, int n, int H, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, st, src, rows_idx, dst, ld_dst, H);
+  return hipGetLastError();
+}
+hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st) {
+  if (R <= 0 || C <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, out, R, C);
+  return hipGetLastError();
+}
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_f32_to_bf16_strided(const float* in, bf16_t* out, size_t rows, int C, int ld, hipStream_t st) {
+  if (rows == 0) return hipSuccess;
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(f32_to_bf16_strided_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, st, in, out, rows, C, ld);
+  return hipGetLastError();
+}

@@ -1,0 +1,295 @@
+// bf16 MFMA GEMMs for gfx950.
+//
+//  gemm_nt : C[M,N] = epi( alpha * ( A1[M,K1] . B1[N,K1]^T  +  A2[M,K2 @ group] . B2[N,K2]^T ) )
+//            Both operands K-contiguous ("NT").  The second (A2,B2) pair is the LoRA tail:
+//            y = [x | t] . [W | B]^T with t = s*(x A^T) — LoRA fused into the base GEMM by
+//            K-concatenation, one fp32 MFMA accumulator, no second pass over C.  For fused
+//            projections (q|k|v, gate|up) the tail's A-operand columns depend on the output
+//            column group: A2 column offset = (n0 / a2_group_n) * a2_group_stride.
+//            128x128 tile, BK=64, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16,
+//            global_load_lds_dwordx4 staging (LDS image lane-linear, XOR swizzle applied on
+//            the per-lane SOURCE address and on the ds_read_b128 address), double-buffered,
+//            one barrier per K-step, XCD-aware grouped tile order.
+//  gemm_tn : C[N1,N2] (fp32) += alpha * sum_m P[m,N1] . Q[m,N2 @ group]   (LoRA wgrad:
+//            dB = dY^T t, dA = dT^T x).  Contraction runs along the rows of both operands, so
+//            fragments come from LDS through ds_read_b64_tr_b16; split over M with fp32
+//            atomics (gradients accumulate across micro-batches anyway).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;       // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
+constexpr int GROUP_M = 8;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == OPADPO_ACT_QUICK_GELU) return v / (1.0f + __expf(-1.702f * v));
+  if (act == OPADPO_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  return v;
+}
+
+template <bool GLDS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+
+  // staging coordinates of this lane inside a 1-KiB (8 rows x 128 B) chunk
+  const int srow = lane >> 3, spos = lane & 7;
+
+  uint4 regs[8];  // register-staging fallback only
+
+  auto stage_issue = [&](int buf, int t) {
+    const bf16_t *Ab, *Bb;
+    int lda, ldb, k0;
+    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * BK; }
+    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * BK; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = wave * 4 + i;
+      const int r = chunk * 8 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const int gr = min(m0 + r, p.M - 1);
+      const bf16_t* srcA = Ab + (size_t)gr * lda + k0 + c * 8;
+      const bf16_t* srcB = Bb + (size_t)(n0 + r) * ldb + k0 + c * 8;
+      char* dA = smem + buf * STAGE_BYTES + chunk * 1024;
+      char* dB = dA + TILE_BYTES;
+      if constexpr (GLDS) {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(srcA), LDS_PTR(void, dA), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(srcB), LDS_PTR(void, dB), 16, 0, 0);
+      } else {
+        regs[i] = *(const uint4*)srcA;
+        regs[4 + i] = *(const uint4*)srcB;
+      }
+    }
+  };
+  auto stage_commit = [&](int buf) {
+    if constexpr (!GLDS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int chunk = wave * 4 + i;
+        char* dA = smem + buf * STAGE_BYTES + chunk * 1024 + lane * 16;
+        *(uint4*)dA = regs[i];
+        *(uint4*)(dA + TILE_BYTES) = regs[4 + i];
+      }
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage_issue(0, 0);
+  stage_commit(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 15, fchk = lane >> 4;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t af[4], bfr[4];
+      const int c = kk * 4 + fchk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + frow;
+        bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // operands swapped (B-tile rows as the MFMA "A" side): the lane ends up holding 4
+          // consecutive output columns of one output row -> 8/16-byte stores.
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) stage_commit(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: lane holds C[m][n..n+3], m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fchk * 4;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * p.alpha;
+      if (p.bias) {
+        const uint2 b = *(const uint2*)(p.bias + n);
+        v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
+        v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
+      }
+      if (p.act) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], p.act);
+      }
+      if (p.R) {
+        const uint2 r = *(const uint2*)(p.R + (size_t)m * p.ldr + n);
+        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+      }
+      if (p.out_f32) {
+        *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN (wgrad) GEMM
+// ------------------------------------------------------------------------------------------
+constexpr int TK = 64;  // rows (m) per LDS stage
+
+template <bool TR>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TK * 128 * 2];  // P tile, Q tile: [TK][128] bf16
+  char* Ps = smem;
+  char* Qs = smem + TK * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n2 = p.N2 / 128;
+  const int t1 = blockIdx.x / tiles_n2, t2 = blockIdx.x % tiles_n2;
+  const int n1_0 = t1 * 128, n2_0 = t2 * 128;
+  const int chunk = (((p.M + gridDim.y - 1) / gridDim.y) + TK - 1) / TK * TK;
+  const int m_begin = blockIdx.y * chunk;
+  const int m_end = min(p.M, m_begin + chunk);
+  if (m_begin >= m_end) return;
+
+  const bf16_t* Q = p.Q;
+  if (p.q_group_n1 > 0) Q += (size_t)(n1_0 / p.q_group_n1) * p.q_group_stride;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int mb = m_begin; mb < m_end; mb += TK) {
+    // stage [TK][128] of P and Q through registers (zero rows past m_end)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;          // 1024 x 16 B per tile
+      const int row = idx >> 4, c16 = idx & 15;
+      const int m = mb + row;
+      uint4 pv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
+      if (m < m_end) {
+        pv = *(const uint4*)(p.P + (size_t)m * p.ldp + n1_0 + c16 * 8);
+        qv = *(const uint4*)(Q + (size_t)m * p.ldq + n2_0 + c16 * 8);
+      }
+      *(uint4*)(Ps + row * 256 + c16 * 16) = pv;
+      *(uint4*)(Qs + row * 256 + c16 * 16) = qv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK / 32; ++kk) {
+      bf16x8_t pf[4], qf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf[i] = lds_frag_rows<TR>(Ps, 256, kk * 32, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qf[j] = lds_frag_rows<TR>(Qs, 256, kk * 32, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = n1][j = n2]: lane holds col n2 = lane&15, rows n1 = (lane>>4)*4 + reg
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n1 = n1_0 + wm * 64 + i * 16 + g * 4 + q;
+        const int n2 = n2_0 + wn * 64 + j * 16 + c;
+        atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[i][j][q] * p.alpha);
+      }
+}
+
+}  // namespace
+
+static bool g_use_glds = true;
+static bool g_use_tr = true;
+void opadpo_set_flags_impl(int use_glds, int use_tr) {
+  g_use_glds = use_glds != 0;
+  g_use_tr = use_tr != 0;
+}
+bool opadpo_flag_tr() { return g_use_tr; }
+
+hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    attr_set = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+  if (g_use_glds)
+    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.N1 % 128 || a.N2 % 128) return hipErrorInvalidValue;
+  const int tiles = (a.N1 / 128) * (a.N2 / 128);
+  int splits = a.splits;
+  if (splits <= 0) {
+    splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (a.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  if (g_use_tr)
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles, splits), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles, splits), dim3(256), 0, st, a);
+  return hipGetLastError();
+}

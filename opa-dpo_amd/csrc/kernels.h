@@ -1,0 +1,90 @@
+// Internal C++ launcher declarations shared by the kernel translation units and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/opadpo_hip.h"
+
+typedef uint16_t bf16_t;
+
+struct GemmNTArgs {
+  const bf16_t* A1; const bf16_t* B1;   // [M,K1] lda1 ; [N,K1] ldb1
+  const bf16_t* A2; const bf16_t* B2;   // LoRA tail: [M,*] lda2 ; [N,K2] ldb2 (may be null, K2 = 0)
+  void* C;                              // [M,N] ldc, bf16 or fp32
+  const bf16_t* R;                      // residual [M,N] ldr (nullable)
+  const bf16_t* bias;                   // [N] (nullable)
+  int M, N, K1, K2;
+  int lda1, ldb1, lda2, ldb2, ldc, ldr;
+  int a2_group_n, a2_group_stride;
+  float alpha;
+  int act;
+  int out_f32;
+};
+
+struct GemmTNArgs {
+  const bf16_t* P; const bf16_t* Q;     // [M,N1] ldp ; [M,*] ldq
+  float* C;                             // [N1,N2] ldc fp32, accumulated with atomics
+  int M, N1, N2;
+  int ldp, ldq, ldc;
+  int q_group_n1, q_group_stride;       // Q column offset = (n1_0 / q_group_n1) * q_group_stride
+  float alpha;
+  int splits;                           // <=0: auto
+};
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;   // element (s, pos, head, d) at ptr[(s*L+pos)*ld + head*hd + d]
+  bf16_t* o;                                            // same addressing with ldo
+  float* lse;                                           // [S, nh, L]
+  const uint8_t* key_mask;                              // [S, L] (nullable = all valid)
+  int S, L, nh, hd;
+  int ld, ldo;
+  int causal;
+  float scale;
+  // backward only
+  const bf16_t* dout;                                   // ldo addressing
+  float* dq_acc;                                        // fp32 [S*L, nh*hd] accumulation buffer (zeroed by caller)
+  bf16_t* dk; bf16_t* dv;                               // ld addressing (same as k / v)
+  float* delta;                                         // [S, nh, L] scratch
+};
+
+void opadpo_set_flags_impl(int use_glds, int use_tr);
+bool opadpo_flag_tr();
+
+hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
+hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
+
+hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st);
+hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st);
+
+hipError_t launch_rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st);
+hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
+                              bf16_t* dx, int rows, int H, hipStream_t st);
+hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
+hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
+                       int inverse, hipStream_t st);
+hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
+hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
+hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
+                               const int32_t* feat_row, const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                               int S, int n_txt, int P, int H, int image_token, hipStream_t st);
+hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st);
+hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st);
+hipError_t launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* rows_idx, bf16_t* dst, int n, int H, hipStream_t st);
+hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst, int ld_dst, int n, int H, hipStream_t st);
+hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);
+hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);
+hipError_t launch_f32_to_bf16_strided(const float* in, bf16_t* out, size_t rows, int C, int ld, hipStream_t st);
+
+hipError_t launch_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,
+                           float* lse, int rows, int V, hipStream_t st);
+hipError_t launch_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
+                           float inv_temp, bf16_t* dz, int ldz, int rows, int V, hipStream_t st);
+
+hipError_t launch_sumsq(const float* g, size_t n, float* out, hipStream_t st);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, const float* sumsq,
+                        float max_norm, float grad_div, hipStream_t st);
+
+hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
+                         uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, hipStream_t st);
+hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* o, const uint8_t* key_mask,
+                              int B, int nh, int hd, int ctx, int max_ctx, int ldq, float scale, hipStream_t st);

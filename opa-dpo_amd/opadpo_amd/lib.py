@@ -1,0 +1,152 @@
+"""ctypes binding of libopadpo_hip.so (C ABI: include/opadpo_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopadpo_hip.so")
+
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_sz = C.c_size_t
+_u64 = C.c_uint64
+
+# name -> argtypes (restype is int unless noted).  Must list EVERY symbol of include/opadpo_hip.h.
+SIGNATURES = {
+    "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _f, _i, _p],
+    "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "opadpo_rmsnorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_rmsnorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "opadpo_silu_mul_fwd": [_p, _p, _i, _i, _p],
+    "opadpo_silu_mul_bwd": [_p, _p, _p, _i, _i, _p],
+    "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "opadpo_im2col": [_p, _p, _i, _i, _i, _i, _p],
+    "opadpo_vision_embed": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "opadpo_gather_rows": [_p, _i, _p, _p, _i, _i, _p],
+    "opadpo_scatter_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "opadpo_transpose": [_p, _p, _i, _i, _p],
+    "opadpo_f32_to_bf16": [_p, _p, _sz, _p],
+    "opadpo_f32_to_bf16_strided": [_p, _p, _sz, _i, _i, _p],
+    "opadpo_head_fwd": [_p, _i, _p, _f, _p, _p, _p, _i, _i, _p],
+    "opadpo_head_bwd": [_p, _i, _p, _p, _p, _f, _p, _i, _i, _i, _p],
+    "opadpo_sumsq": [_p, _sz, _p, _p],
+    "opadpo_adamw": [_p, _p, _p, _p, _p, _sz, _d, _d, _d, _d, _d, _i, _p, _d, _d, _p],
+    "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _i, _p, _p],
+}
+OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags"]
+
+_lib: Optional[C.CDLL] = None
+
+
+class OpadpoError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (build it first with opa-dpo_amd/build.py / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OpadpoError(
+            f"{LIB_PATH} not found: build it with `python opa-dpo_amd/build.py` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.opadpo_abi_version.restype = _i
+    lib.opadpo_last_error.restype = C.c_char_p
+    lib.opadpo_set_flags.argtypes = [_i, _i]
+    lib.opadpo_set_flags.restype = None
+    if lib.opadpo_abi_version() != 1:
+        raise OpadpoError("ABI version mismatch")
+    _lib = lib
+    g = os.environ.get("OPADPO_USE_GLDS")
+    t = os.environ.get("OPADPO_USE_TR")
+    if g is not None or t is not None:
+        lib.opadpo_set_flags(int(g or 1), int(t or 1))
+    return lib
+
+
+def set_flags(use_glds: bool = True, use_tr: bool = True) -> None:
+    load().opadpo_set_flags(int(use_glds), int(use_tr))
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise OpadpoError(f"{name} failed: {lib.opadpo_last_error().decode()}")
+
+
+# ---------------------------------------------------------------------------------------------
+# thin typed wrappers over torch tensors (device memory + stream plumbing only)
+# ---------------------------------------------------------------------------------------------
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda:
+        raise OpadpoError(f"{name}: expected cuda {dtype}, got {t.device} {t.dtype}")
+    if t.dim() >= 2 and t.stride(-1) != 1:
+        raise OpadpoError(f"{name}: innermost dimension must be contiguous")
+
+
+def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
+            b2: Optional[torch.Tensor] = None, a2_group_n: int = 0, a2_group_stride: int = 0,
+            residual: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+            act: int = ACT_NONE) -> torch.Tensor:
+    """out[M,N] = act(alpha*(a1 @ b1^T + a2[:, group] @ b2^T) + bias) + residual.  2-D row-major views
+    with arbitrary row stride (leading dimension)."""
+    _chk(a1, torch.bfloat16, "a1"); _chk(b1, torch.bfloat16, "b1")
+    M, K1 = a1.shape
+    N = b1.shape[0]
+    assert b1.shape[1] == K1 and out.shape[0] == M and out.shape[1] == N
+    K2 = 0
+    if a2 is not None:
+        _chk(a2, torch.bfloat16, "a2"); _chk(b2, torch.bfloat16, "b2")
+        K2 = b2.shape[1]
+        assert b2.shape[0] == N and a2.shape[0] == M
+    out_f32 = out.dtype == torch.float32
+    assert out_f32 or out.dtype == torch.bfloat16
+    call("opadpo_gemm_nt", ptr(a1), a1.stride(0), ptr(b1), b1.stride(0), K1,
+         ptr(a2), a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+         a2_group_n, a2_group_stride, ptr(out), out.stride(0), int(out_f32),
+         ptr(residual), residual.stride(0) if residual is not None else 0, ptr(bias), M, N, float(alpha), act, stream())
+    return out
+
+
+def gemm_tn(p: torch.Tensor, q: torch.Tensor, c: torch.Tensor, *, n2: Optional[int] = None, q_group_n1: int = 0,
+            q_group_stride: int = 0, alpha: float = 1.0, splits: int = 0) -> torch.Tensor:
+    """c[N1,N2] (fp32) += alpha * p[M,N1]^T @ q[M,N2]."""
+    _chk(p, torch.bfloat16, "p"); _chk(q, torch.bfloat16, "q"); _chk(c, torch.float32, "c")
+    M, N1 = p.shape
+    N2 = c.shape[1] if n2 is None else n2
+    assert c.shape[0] == N1 and q.shape[0] == M
+    call("opadpo_gemm_tn", ptr(p), p.stride(0), ptr(q), q.stride(0), ptr(c), c.stride(0), M, N1, N2,
+         q_group_n1, q_group_stride, float(alpha), splits, stream())
+    return c

@@ -1,0 +1,110 @@
+"""AutoregressivePolicy-compatible wrapper over the HIP engine.
+
+Same call contract as opadpo/dpo_models/rl_models.py:75-144:
+
+    policy(images=, queries=, queries_attn_masks=, temperature=, **{<name>_response: ids [B,T]})
+        -> {<name>_response_logprobs: [B,T], <name>_response_entropies: [B,T]}
+
+with the same kwarg filter ("response" in key, no "_mask"/"scores"/"image_relations"), the same
+stacking order of the response keys on the batch dimension and the same masking.  Outputs are
+fp32 (the reference returns the model dtype, bf16 at run time).  The log-probs carry a grad_fn
+when the adapter is trainable and torch grad mode is on; backward runs the HIP LoRA backward and
+ACCUMULATES into adapter.grad (the flat fp32 gradient buffer), like autograd's .grad +=.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .dims import PAD_ID
+from .model import LlavaEngine, LoraAdapter, SeqBatch
+
+
+def response_keys(kwargs) -> List[str]:
+    return [k for k in kwargs
+            if "response" in k and "_mask" not in k and "scores" not in k and "image_relations" not in k]
+
+
+class _SeqLogprobs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, policy, batch, feats, temperature):
+        logp, ent, saved = policy.engine.seq_logprobs_fwd(policy.adapter, batch, feats, temperature, train=True)
+        ctx.policy, ctx.saved = policy, saved
+        ctx.mark_non_differentiable(ent)
+        return logp, ent
+
+    @staticmethod
+    def backward(ctx, dlogp, _dent):
+        ctx.policy.engine.seq_logprobs_bwd(ctx.policy.adapter, ctx.saved, dlogp)
+        ctx.saved = None
+        return None, None, None, None, None
+
+
+class AutoregressivePolicy(torch.nn.Module):
+    def __init__(self, engine: LlavaEngine, adapter: LoraAdapter, response_len: int, temperature: float = 1.0,
+                 adapter_name: Optional[str] = None):
+        super().__init__()
+        self.engine = engine
+        self.adapter = adapter
+        self.adapter_name = adapter_name
+        self.response_len = response_len
+        self.temperature = temperature
+        # autograd anchor: a leaf that requires grad so that the HIP forward gets a grad_fn
+        self._anchor = torch.zeros(1, device=engine.dev, requires_grad=True) if adapter.trainable else None
+
+    def build_batch(self, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
+        dev = self.engine.dev
+        d = self.engine.d
+        keys = response_keys(responses)
+        if not keys:
+            raise ValueError("no *response* tensors passed to the policy")
+        B, Q = queries.shape
+        queries = queries.to(dev)
+        qm = queries_attn_masks.to(dev).bool()
+        ids, masks = [], []
+        image_mask = None
+        for k in keys:
+            r = responses[k].to(dev)
+            i = torch.cat([queries, r], dim=1)
+            if qm.size(1) == Q:                               # rl_models.py:100-102
+                m = i != PAD_ID
+                m[:, :Q] = qm
+            else:                                             # CoPO 'attention' (:103-105): [image mask | query mask]
+                P = d.n_patches
+                assert qm.size(1) == P + Q
+                m = torch.cat([qm[:, P:], r != PAD_ID], dim=1)
+                image_mask = qm[:, :P]
+            ids.append(i)
+            masks.append(m)
+        K = len(keys)
+        T = responses[keys[0]].shape[1]
+        assert T == self.response_len, "policy slices with args.response_len (rl_models.py:121-123, Quirk Q7)"
+        batch = SeqBatch(
+            ids=torch.cat(ids, 0).to(torch.int32).contiguous(),
+            text_mask=torch.cat(masks, 0).to(torch.uint8).contiguous(),
+            feat_row=torch.arange(B, device=dev, dtype=torch.int32).repeat(K).contiguous(),
+            image_mask=None if image_mask is None else image_mask.to(torch.uint8).repeat(K, 1).contiguous(),
+            T=T)
+        return keys, batch
+
+    def forward(self, images: Optional[torch.Tensor] = None, queries: torch.Tensor = None,
+                queries_attn_masks: torch.Tensor = None, temperature: Optional[float] = None,
+                image_feats: Optional[torch.Tensor] = None, mode: Optional[str] = None, **kwargs) -> Dict[str, torch.Tensor]:
+        if temperature is None:
+            temperature = self.temperature
+        keys, batch = self.build_batch(queries, queries_attn_masks, kwargs)
+        B = queries.shape[0]
+        if image_feats is None:
+            image_feats = self.engine.encode_images(images)   # once per image, shared by all response keys
+        feats = image_feats.contiguous()
+        if self.adapter.trainable and torch.is_grad_enabled():
+            logp, ent = _SeqLogprobs.apply(self._anchor, self, batch, feats, float(temperature))
+        else:
+            with torch.no_grad():
+                logp, ent, _ = self.engine.seq_logprobs_fwd(self.adapter, batch, feats, float(temperature), train=False)
+        out = {}
+        for i, k in enumerate(keys):
+            out[k + "_logprobs"] = logp[i * B:(i + 1) * B]
+            out[k + "_entropies"] = ent[i * B:(i + 1) * B]
+        return out

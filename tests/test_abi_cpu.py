@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/opadpo_hip.h
+declares with the argument lists the ctypes binding assumes (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "opadpo_hip.h")
+
+CTYPE = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+         "uint64_t": ctypes.c_uint64}
+
+
+def parse_header():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(int|void|const char\*)\s+(opadpo_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    types.append(ctypes.c_void_p)
+                else:
+                    types.append(CTYPE[a.replace("const ", "").split()[0]])
+        protos[name] = (ret, types)
+    return protos
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("opadpo_build", os.path.join(REPO, "opa-dpo_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(verbose=False)
+
+
+def test_header_declares_the_path():
+    protos = parse_header()
+    assert len(protos) >= 27
+    for need in ("opadpo_gemm_nt", "opadpo_gemm_tn", "opadpo_attn_fwd", "opadpo_attn_bwd", "opadpo_head_fwd",
+                 "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_embed_splice"):
+        assert need in protos
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    lib = ctypes.CDLL(built_lib)
+    for name in parse_header():
+        assert hasattr(lib, name), f"{name} declared in include/opadpo_hip.h but not exported"
+    lib.opadpo_abi_version.restype = ctypes.c_int
+    assert lib.opadpo_abi_version() == 1
+
+
+def test_binding_matches_header(built_lib):
+    from opadpo_amd import lib as L
+    protos = parse_header()
+    bound = set(L.SIGNATURES) | set(L.OTHER_SYMBOLS)
+    assert bound == set(protos), bound ^ set(protos)
+    for name, argtypes in L.SIGNATURES.items():
+        ret, types = protos[name]
+        assert ret == "int"
+        assert [t for t in argtypes] == types, f"{name}: binding {argtypes} != header {types}"
+    L.load()
+
+
+def test_host_side_validation_needs_no_gpu(built_lib):
+    """Shape validation happens before any launch: a bad call fails loudly with a message."""
+    lib = ctypes.CDLL(built_lib)
+    lib.opadpo_last_error.restype = ctypes.c_char_p
+    fn = lib.opadpo_gemm_nt
+    from opadpo_amd import lib as L
+    fn.argtypes = L.SIGNATURES["opadpo_gemm_nt"]
+    fn.restype = ctypes.c_int
+    rc = fn(None, 64, None, 64, 64, None, 0, None, 0, 0, 0, 0, None, 100, 0, None, 0, None, 10, 100, 1.0, 0, None)
+    assert rc != 0 and b"multiple of 128" in lib.opadpo_last_error()

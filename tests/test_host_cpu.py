@@ -1,0 +1,153 @@
+"""CPU: host-side logic of the product package (no kernels): the loss / statistics mirror against the
+reference's golden vectors, batch stacking, schedules, checkpoint naming, geometry arithmetic."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from opadpo_amd import dims as DM
+from opadpo_amd import losses as LS
+from opadpo_amd.optim import cosine_lr, shard_bounds
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_product_dpo_loss_matches_reference(golden_dir):
+    g = load(golden_dir, "ref_dpo_loss.npz")
+    pc, pr, rc, rr, sc, sr = (t(g[k]) for k in ("pc", "pr", "rc", "rr", "sc", "sr"))
+    for i, meta in enumerate(g["meta"]):
+        fdiv, ls, rf, scores = str(meta).split("|")
+        a = LS.DPOArgs(f_divergence_type=fdiv, label_smoothing=float(ls), reference_free=bool(int(rf)))
+        out = LS.dpo_loss(a, pc, pr, rc, rr, sc if int(scores) else None, sr if int(scores) else None)
+        for got, key in zip(out, ("losses", "c", "r")):
+            np.testing.assert_allclose(got.numpy(), g[f"case{i}_{key}"], rtol=1e-6, atol=1e-7)
+
+
+def test_product_policy_loss_matches_reference(golden_dir):
+    g = load(golden_dir, "ref_policy_loss.npz")
+    for ci, meta in enumerate(g["meta"]):
+        CoPO, AncPO, mdpo, detailed = (bool(int(x)) for x in str(meta).split("|"))
+        pre = f"c{ci}_"
+        rollouts = {k[len(pre) + 3:]: t(v) for k, v in g.items() if k.startswith(pre + "in_")}
+        pol = {k[len(pre) + 4:]: t(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith(pre + "pol_")}
+        a = LS.DPOArgs(CoPO=CoPO, AncPO=AncPO, mDPO_anchor=mdpo, detailed_report=detailed)
+        loss, stats = LS.policy_loss(a, rollouts, {k: v for k, v in pol.items() if not k.startswith("mask_")},
+                                     {k: v for k, v in pol.items() if k.startswith("mask_")} if CoPO else None)
+        np.testing.assert_allclose(loss.item(), g[pre + "loss"], rtol=1e-6)
+        loss.backward()
+        for k, v in pol.items():
+            want = g[pre + "grad_" + k]
+            got = v.grad.numpy() if v.grad is not None else np.zeros_like(want)
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-8)
+        for k, v in g.items():
+            if k.startswith(pre + "stat_"):
+                np.testing.assert_allclose(stats[k[len(pre) + 5:].replace("__", "/")].numpy(), v, rtol=1e-5, atol=1e-7)
+        assert len(stats) == 32
+
+
+def test_mask_image_matches_reference(golden_dir):
+    g = load(golden_dir, "ref_mask_image.npz")
+    torch.manual_seed(99)
+    np.testing.assert_array_equal(LS.mask_single_image(t(g["img"]), 0.3, "random").numpy(), g["random"])
+    torch.manual_seed(99)
+    np.testing.assert_array_equal(LS.mask_single_image(t(g["img"]), 0.3, "blockwise").numpy(), g["blockwise"])
+
+
+def test_build_batch_stacking(golden_dir):
+    """kwarg filter, key order on the batch dimension and masks of rl_models.py:91-112."""
+    from opadpo_amd.policy import AutoregressivePolicy, response_keys
+    kw = dict(standard_response=1, standard_response_attention_mask=2, AI_pseudo_response_scores=3,
+              AI_pseudo_response_image_relations=4, original_generate_response=5, mask_standard_response=6)
+    assert response_keys(kw) == ["standard_response", "original_generate_response", "mask_standard_response"]
+    eng = types.SimpleNamespace(dev=torch.device("cpu"), d=DM.LlavaDims.tiny())
+    ad = types.SimpleNamespace(trainable=False)
+    pol = AutoregressivePolicy(eng, ad, response_len=5)
+    g = load(golden_dir, "ref_policy_forward.npz")
+    queries, qmask = t(g["queries"]), t(g["qmask"]).bool()
+    resp = {k[5:]: t(v) for k, v in g.items() if k.startswith("resp_")}
+    keys, b = pol.build_batch(queries, qmask, resp)
+    from oracle import dpo_ref as D
+    ids, mask = D.stack_policy_inputs(queries, qmask, resp)
+    assert keys == D.response_keys(resp)
+    assert torch.equal(b.ids.long(), ids) and torch.equal(b.text_mask.bool(), mask)
+    assert b.feat_row.tolist() == [0, 1, 0, 1] and b.T == 5
+    # CoPO 'attention': [image mask (P) | query mask (Q)]
+    P = eng.d.n_patches
+    im = torch.ones(2, P, dtype=torch.bool)
+    im[0, 3] = False
+    keys, b2 = pol.build_batch(queries, torch.cat([im, qmask], 1), resp)
+    assert torch.equal(b2.text_mask.bool(), mask) and torch.equal(b2.image_mask.bool(), im.repeat(2, 1))
+
+
+def test_schedule_shards_and_arith():
+    assert cosine_lr(0, 1e-6, 5, 300) == 0.0 and abs(cosine_lr(5, 1e-6, 5, 300) - 1e-6) < 1e-18
+    assert cosine_lr(300, 1e-6, 5, 300) < 1e-12
+    n = 639_631_360
+    covered = 0
+    for r in range(8):
+        lo, hi, per = shard_bounds(n, 8, r)
+        assert per % 256 == 0 and lo == min(n, r * per)
+        covered += hi - lo
+    assert covered == n
+    d = DM.LlavaDims()
+    assert DM.lora_param_count(d) == 639_631_360
+    assert DM.lora_param_count(DM.LlavaDims.llava15_13b()) == 1_001_390_080
+    assert abs(DM.pair_flops(d, 128, 384) / 1e12 - 101.8) < 0.5
+    d.validate()
+    DM.LlavaDims.llava15_13b().validate()
+    DM.LlavaDims.tiny().validate()
+
+
+def test_checkpoint_layout(tmp_path, golden_dir):
+    from opadpo_amd.trainer import get_last_checkpoint, save_adapter
+    g = load(golden_dir, "ref_last_checkpoint.npz")
+    run = tmp_path / "run"
+    assert [str(x) for x in get_last_checkpoint(str(tmp_path / "nope"))] == list(g["first"])
+    (run / "checkpoint-75").mkdir(parents=True)
+    (run / "checkpoint-150").mkdir()
+    (run / "checkpoint-final").mkdir()
+    path, done = get_last_checkpoint(str(run))
+    assert [os.path.basename(path), str(done)] == list(g["found"])
+    (run / "completed").touch()
+    assert [str(x) for x in get_last_checkpoint(str(run))] == list(g["done"])
+
+    d = DM.LlavaDims.tiny()
+
+    class FakeAdapter:
+        def to_peft_state(self):
+            return {"base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight": torch.zeros(d.lora_r, d.hidden, dtype=torch.bfloat16)}
+
+    out = tmp_path / "ckpt" / "adapter_model" / "lora_policy"
+    save_adapter(FakeAdapter(), str(out), d, "llava-1.5-7b")
+    cfg = json.load(open(out / "adapter_config.json"))
+    assert cfg["peft_type"] == "LORA" and cfg["r"] == d.lora_r and cfg["inference_mode"] is True
+    assert cfg["target_modules"] == ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+    sd = torch.load(out / "adapter_model.bin")
+    assert list(sd) == ["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"]
+
+
+def test_lora_flat_layout_roundtrip():
+    """PEFT key layout <-> fused flat buffer (CPU tensors; no kernels involved for a frozen adapter)."""
+    from opadpo_amd.model import LoraAdapter
+    from opadpo_amd.synth import init_lora
+    d = DM.LlavaDims.tiny()
+    st = init_lora(d, seed=3)
+    ad = LoraAdapter(d, st, torch.device("cpu"), trainable=False)
+    assert ad.numel == DM.lora_param_count(d)
+    back = ad.to_peft_state()
+    assert set(back) == set(st)
+    for k in st:
+        assert torch.equal(back[k], st[k].to(torch.bfloat16)), k
+    r, H = d.lora_r, d.hidden
+    assert torch.equal(ad.w(1, "a_qkv")[r:2 * r], st["base_model.model.model.layers.1.self_attn.k_proj.lora_A.weight"])
+    assert torch.equal(ad.w(0, "b_gu")[d.ffn:], st["base_model.model.model.layers.0.mlp.up_proj.lora_B.weight"])

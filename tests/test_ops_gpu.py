@@ -1,0 +1,435 @@
+"""GPU: every kernel of libopadpo_hip.so, called through the C ABI, against a torch fp32 reference of
+the same op (floating-point kernels -> tolerance stated per test).  Variant switches (global_load_lds
+staging, ds_read_b64_tr_b16 transposed reads) are exercised both ways."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd import lib
+    lib.load()
+    yield lib
+    lib.set_flags(True, True)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).to(dev())
+
+
+def relerr(got, want):
+    got, want = got.float(), want.float()
+    return float((got - want).norm() / (want.norm() + 1e-12))
+
+
+def maxabs(got, want):
+    return float((got.float() - want.float()).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K1,K2,groups", [(300, 256, 128, 0, 0), (1, 128, 64, 0, 0), (129, 384, 192, 128, 3),
+                                              (1000, 1024, 512, 128, 2), (257, 128, 64, 64, 1)])
+def test_gemm_nt(L, glds, M, N, K1, K2, groups):
+    L.set_flags(bool(glds), True)
+    a1 = rnd(M, K1, seed=1)
+    b1 = rnd(N, K1, seed=2)
+    out = torch.empty(M, N, dtype=BF, device=dev())
+    want = a1.float() @ b1.float().t()
+    kw = {}
+    if K2:
+        G = max(groups, 1)
+        a2 = rnd(M, G * K2, seed=3)
+        b2 = rnd(N, K2, seed=4)
+        kw = dict(a2=a2, b2=b2, a2_group_n=(N // G if groups > 1 else 0), a2_group_stride=(K2 if groups > 1 else 0))
+        if groups > 1:
+            ng = N // G
+            for g in range(G):
+                want[:, g * ng:(g + 1) * ng] += a2[:, g * K2:(g + 1) * K2].float() @ b2[g * ng:(g + 1) * ng].float().t()
+        else:
+            want += a2[:, :K2].float() @ b2.float().t()
+    L.gemm_nt(a1, b1, out, **kw)
+    torch.cuda.synchronize()
+    e = relerr(out, want)
+    assert e < 6e-3, f"gemm_nt rel err {e}"   # bf16 output rounding ~ 2^-9
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt_epilogue(L, act):
+    L.set_flags(True, True)
+    M, N, K = 200, 256, 128
+    a, b = rnd(M, K, scale=0.5, seed=1), rnd(N, K, scale=0.5, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.empty(M, N, dtype=BF, device=dev())
+    L.gemm_nt(a, b, out, bias=bias, residual=res, alpha=0.5, act=act)
+    v = 0.5 * (a.float() @ b.float().t()) + bias.float()
+    if act == 1:
+        v = v * torch.sigmoid(1.702 * v)
+    elif act == 2:
+        v = torch.nn.functional.gelu(v)
+    want = v + res.float()
+    assert relerr(out, want) < 6e-3
+    out32 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    L.gemm_nt(a, b, out32)
+    assert relerr(out32, a.float() @ b.float().t()) < 1e-5
+    # strided views (leading dimension != width)
+    big = rnd(M, 3 * K, seed=5)
+    outw = torch.zeros(M, 2 * N, dtype=BF, device=dev())
+    L.gemm_nt(big[:, K:2 * K], b, outw[:, N:])
+    assert relerr(outw[:, N:], big[:, K:2 * K].float() @ b.float().t()) < 6e-3
+    assert float(outw[:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0)])
+def test_gemm_tn(L, tr, M, N1, N2, groups):
+    L.set_flags(True, bool(tr))
+    p = rnd(M, N1, seed=1)
+    G = max(groups, 1)
+    q = rnd(M, G * N2, seed=2)
+    c0 = torch.randn(N1, N2, device=dev())
+    c = c0.clone()
+    if groups:
+        L.gemm_tn(p, q, c, n2=N2, q_group_n1=N1 // G, q_group_stride=N2, alpha=2.0)
+        want = c0.clone()
+        ng = N1 // G
+        for g in range(G):
+            want[g * ng:(g + 1) * ng] += 2.0 * (p[:, g * ng:(g + 1) * ng].float().t() @ q[:, g * N2:(g + 1) * N2].float())
+    else:
+        L.gemm_tn(p, q, c, alpha=2.0)
+        want = c0 + 2.0 * (p.float().t() @ q.float())
+    e = relerr(c, want)
+    assert e < 1e-4, f"gemm_tn rel err {e}"
+
+
+def ref_attention(q, k, v, key_mask, causal, scale):
+    """q,k,v [S,L,nh,hd] fp32 -> o [S,L,nh,hd], fully-masked rows -> 0."""
+    S, Ln, nh, hd = q.shape
+    sc = torch.einsum("sqhd,skhd->shqk", q, k) * scale
+    allow = torch.ones(S, 1, Ln, Ln, dtype=torch.bool, device=q.device)
+    if causal:
+        allow = allow & torch.tril(torch.ones(Ln, Ln, dtype=torch.bool, device=q.device))[None, None]
+    if key_mask is not None:
+        allow = allow & key_mask.bool()[:, None, None, :]
+    sc = sc.masked_fill(~allow, float("-inf"))
+    p = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0)
+    return torch.einsum("shqk,skhd->sqhd", p, v)
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("S,Ln,nh,hd,causal,masked", [(2, 200, 2, 128, 1, True), (1, 64, 1, 128, 1, False),
+                                                       (2, 77, 2, 64, 0, False), (1, 300, 1, 64, 1, True)])
+def test_attn_fwd(L, tr, S, Ln, nh, hd, causal, masked):
+    L.set_flags(True, bool(tr))
+    H = nh * hd
+    qkv = rnd(S * Ln, 3 * H, scale=1.0, seed=7)
+    km = None
+    if masked:
+        km = torch.ones(S, Ln, dtype=torch.uint8, device=dev())
+        km[0, :5] = 0
+        km[-1, Ln - 9:] = 0
+        km[0, 40:44] = 0
+    o = torch.zeros(S * Ln, H, dtype=BF, device=dev())
+    lse = torch.zeros(S, nh, Ln, device=dev())
+    st = L.stream()
+    L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, causal, hd ** -0.5, st)
+    torch.cuda.synchronize()
+    q4 = qkv[:, :H].float().view(S, Ln, nh, hd)
+    k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd)
+    v4 = qkv[:, 2 * H:].float().view(S, Ln, nh, hd)
+    want = ref_attention(q4, k4, v4, km, causal, hd ** -0.5).reshape(S * Ln, H)
+    e = maxabs(o, want)
+    assert e < 3e-2, f"attn_fwd max abs err {e} (|o| ~ {float(want.abs().max()):.2f})"
+    assert relerr(o, want) < 1e-2
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("S,Ln,nh,hd,masked", [(2, 150, 2, 128, True), (1, 64, 1, 128, False), (1, 200, 2, 64, True)])
+def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
+    L.set_flags(True, bool(tr))
+    H = nh * hd
+    qkv = rnd(S * Ln, 3 * H, scale=0.7, seed=11)
+    dout = rnd(S * Ln, H, scale=1.0, seed=12)
+    km = None
+    if masked:
+        km = torch.ones(S, Ln, dtype=torch.uint8, device=dev())
+        km[0, :7] = 0
+        km[-1, Ln - 11:] = 0
+    o = torch.zeros(S * Ln, H, dtype=BF, device=dev())
+    lse = torch.zeros(S, nh, Ln, device=dev())
+    st = L.stream()
+    scale = hd ** -0.5
+    L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, 1, scale, st)
+    dq_acc = torch.zeros(S * Ln, H, device=dev())
+    dqkv = torch.zeros(S * Ln, 3 * H, dtype=BF, device=dev())
+    delta = torch.zeros(S, nh, Ln, device=dev())
+    L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+           dout.data_ptr(), H, lse.data_ptr(), L.ptr(km), dq_acc.data_ptr(), dqkv.data_ptr() + 2 * H,
+           dqkv.data_ptr() + 4 * H, delta.data_ptr(), S, Ln, nh, hd, 1, scale, st)
+    torch.cuda.synchronize()
+    q4 = qkv[:, :H].float().view(S, Ln, nh, hd).requires_grad_(True)
+    k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd).requires_grad_(True)
+    v4 = qkv[:, 2 * H:].float().view(S, Ln, nh, hd).requires_grad_(True)
+    want = ref_attention(q4, k4, v4, km, 1, scale)
+    want.backward(dout.float().view(S, Ln, nh, hd))
+    for name, got, ref in (("dq", dq_acc, q4.grad.reshape(S * Ln, H)), ("dk", dqkv[:, H:2 * H], k4.grad.reshape(S * Ln, H)),
+                           ("dv", dqkv[:, 2 * H:], v4.grad.reshape(S * Ln, H))):
+        e = relerr(got, ref)
+        assert e < 2e-2, f"attn_bwd {name} rel err {e}"
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_rmsnorm(L):
+    rows, H = 37, 512
+    x, w = rnd(rows, H, seed=1), (1 + 0.1 * torch.randn(H)).to(BF).to(dev())
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, device=dev())
+    L.call("opadpo_rmsnorm_fwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, H, 1e-5, L.stream())
+    xf = x.float().requires_grad_(True)
+    r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
+    want = xf * r * w.float()
+    assert relerr(y, want) < 4e-3
+    assert relerr(rstd, r.squeeze(-1)) < 1e-5
+    dy, dres = rnd(rows, H, seed=2), rnd(rows, H, seed=3)
+    dx = torch.empty_like(x)
+    L.call("opadpo_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dres.data_ptr(), dx.data_ptr(),
+           rows, H, L.stream())
+    want.backward(dy.float())
+    assert relerr(dx, xf.grad + dres.float()) < 4e-3
+
+
+def test_layernorm(L):
+    rows, H = 19, 256
+    x, w, b = rnd(rows, H, seed=1), rnd(H, seed=2), rnd(H, seed=3)
+    y = torch.empty_like(x)
+    L.call("opadpo_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, H, 1e-5, L.stream())
+    want = torch.nn.functional.layer_norm(x.float(), (H,), w.float(), b.float(), 1e-5)
+    assert relerr(y, want) < 4e-3
+
+
+def test_rope(L):
+    S, Ln, nh, hd = 2, 33, 2, 128
+    H = nh * hd
+    qkv = rnd(S * Ln, 3 * H, seed=1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    f = torch.outer(torch.arange(Ln).float(), inv)
+    cos, sin = f.cos().to(dev()).contiguous(), f.sin().to(dev()).contiguous()
+    x = qkv.clone()
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, L.stream())
+    ref = qkv.float().view(S, Ln, 3 * nh, hd)
+    c = torch.cat([f, f], -1).cos().to(dev())[None, :, None, :]
+    s = torch.cat([f, f], -1).sin().to(dev())[None, :, None, :]
+    rot = torch.cat([-ref[..., hd // 2:], ref[..., : hd // 2]], -1)
+    want = ref.clone()
+    want[:, :, : 2 * nh] = (ref * c + rot * s)[:, :, : 2 * nh]
+    assert relerr(x, want.reshape(S * Ln, 3 * H)) < 4e-3
+    assert torch.equal(x[:, 2 * H:], qkv[:, 2 * H:])          # v untouched
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, L.stream())
+    assert relerr(x, qkv) < 8e-3                               # inverse rotation restores the input
+
+
+def test_silu_mul(L):
+    rows, F = 21, 384
+    gu = rnd(rows, 2 * F, seed=1)
+    act = torch.empty(rows, F, dtype=BF, device=dev())
+    L.call("opadpo_silu_mul_fwd", gu.data_ptr(), act.data_ptr(), rows, F, L.stream())
+    g = gu[:, :F].float().requires_grad_(True)
+    u = gu[:, F:].float().requires_grad_(True)
+    want = torch.nn.functional.silu(g) * u
+    assert relerr(act, want) < 4e-3
+    dact = rnd(rows, F, seed=2)
+    dgu = torch.empty_like(gu)
+    L.call("opadpo_silu_mul_bwd", dact.data_ptr(), gu.data_ptr(), dgu.data_ptr(), rows, F, L.stream())
+    want.backward(dact.float())
+    assert relerr(dgu[:, :F], g.grad) < 4e-3 and relerr(dgu[:, F:], u.grad) < 4e-3
+
+
+def test_embed_splice(L):
+    S, n_txt, P, H, V = 3, 10, 4, 128, 50
+    embed, feats = rnd(V, H, seed=1), rnd(2, P, H, seed=2)
+    ids = torch.randint(1, V, (S, n_txt))
+    ids[0, 2] = -200
+    ids[1, 0] = -200
+    ids[2, 6] = -200
+    tm = torch.ones(S, n_txt, dtype=torch.uint8)
+    tm[0, :2] = 0
+    tm[2, 8:] = 0
+    feat_row = torch.tensor([0, 1, 0], dtype=torch.int32)
+    im = torch.ones(S, P, dtype=torch.uint8)
+    im[1, 1] = 0
+    x = torch.zeros(S, n_txt + P - 1, H, dtype=BF, device=dev())
+    km = torch.zeros(S, n_txt + P - 1, dtype=torch.uint8, device=dev())
+    L.call("opadpo_embed_splice", ids.to(torch.int32).to(dev()).data_ptr(), tm.to(dev()).data_ptr(), embed.data_ptr(),
+           feats.data_ptr(), feat_row.to(dev()).data_ptr(), im.to(dev()).data_ptr(), x.data_ptr(), km.data_ptr(),
+           S, n_txt, P, H, -200, L.stream())
+    torch.cuda.synchronize()
+    for s in range(S):
+        p = int((ids[s] == -200).nonzero()[0, 0])
+        e = embed[ids[s].clamp_min(0).to(dev())]
+        want = torch.cat([e[:p], feats[feat_row[s]], e[p + 1:]], 0)
+        wm = torch.cat([tm[s, :p], im[s], tm[s, p + 1:]], 0)
+        assert torch.equal(x[s], want), f"row {s}"
+        assert torch.equal(km[s].cpu(), wm), f"mask row {s}"
+
+
+def test_vision_embed_pieces(L):
+    B, IS, patch, h = 2, 28, 14, 128
+    G = IS // patch
+    P = G * G
+    kpad = 640
+    px = rnd(B, 3, IS, IS, seed=1)
+    cols = torch.empty(B * P, kpad, dtype=BF, device=dev())
+    L.call("opadpo_im2col", px.data_ptr(), cols.data_ptr(), B, IS, patch, kpad, L.stream())
+    want = torch.nn.functional.unfold(px.float(), patch, stride=patch).transpose(1, 2).reshape(B * P, -1)
+    assert torch.equal(cols[:, :588].float(), want) and float(cols[:, 588:].abs().max()) == 0.0
+    patches, cls, pos = rnd(B * P, h, seed=2), rnd(h, seed=3), rnd(P + 1, h, seed=4)
+    x = torch.empty(B, P + 1, h, dtype=BF, device=dev())
+    L.call("opadpo_vision_embed", patches.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), B, P, h, L.stream())
+    w = torch.cat([cls.float().expand(B, 1, h), patches.float().view(B, P, h)], 1) + pos.float()[None]
+    assert relerr(x, w) < 4e-3
+
+
+def test_data_movement(L):
+    src = rnd(40, 256, seed=1)
+    idx = torch.tensor([5, 0, 39, 7], dtype=torch.int32, device=dev())
+    dst = torch.empty(4, 128, dtype=BF, device=dev())
+    L.call("opadpo_gather_rows", src.data_ptr(), 256, idx.data_ptr(), dst.data_ptr(), 4, 128, L.stream())
+    assert torch.equal(dst, src[idx.long(), :128])
+    back = torch.zeros(40, 256, dtype=BF, device=dev())
+    L.call("opadpo_scatter_rows", dst.data_ptr(), idx.data_ptr(), back.data_ptr(), 256, 4, 128, L.stream())
+    assert torch.equal(back[idx.long(), :128], dst) and float(back.float().abs().sum()) == float(dst.float().abs().sum())
+    a = rnd(100, 70, seed=2)
+    t = torch.empty(70, 100, dtype=BF, device=dev())
+    L.call("opadpo_transpose", a.data_ptr(), t.data_ptr(), 100, 70, L.stream())
+    assert torch.equal(t, a.t().contiguous())
+    f = torch.randn(1003, device=dev())
+    o = torch.empty(1003, dtype=BF, device=dev())
+    L.call("opadpo_f32_to_bf16", f.data_ptr(), o.data_ptr(), 1003, L.stream())
+    assert torch.equal(o, f.to(BF))
+    f2 = torch.randn(9, 64, device=dev())
+    o2 = torch.zeros(9, 192, dtype=BF, device=dev())
+    L.call("opadpo_f32_to_bf16_strided", f2.data_ptr(), o2.data_ptr(), 9, 64, 192, L.stream())
+    assert torch.equal(o2[:, :64], f2.to(BF)) and float(o2[:, 64:].abs().max()) == 0.0
+
+
+def test_head(L):
+    rows, V = 23, 512
+    logits = torch.randn(rows, V, device=dev()) * 3
+    labels = torch.randint(1, V, (rows,), dtype=torch.int32, device=dev())
+    labels[3] = 0
+    labels[10] = 0
+    logp, ent, lse = (torch.empty(rows, device=dev()) for _ in range(3))
+    temp = 0.7
+    L.call("opadpo_head_fwd", logits.data_ptr(), V, labels.data_ptr(), 1 / temp, logp.data_ptr(), ent.data_ptr(),
+           lse.data_ptr(), rows, V, L.stream())
+    z = (logits / temp).requires_grad_(True)
+    lsm = torch.log_softmax(z, -1)
+    want_lp = lsm.gather(-1, labels.long().unsqueeze(-1)).squeeze(-1) * (labels != 0)
+    want_ent = -(lsm.exp() * lsm).sum(-1) * (labels != 0)
+    assert maxabs(logp, want_lp) < 1e-4 and maxabs(ent, want_ent) < 1e-4
+    assert float(logp[3]) == 0.0 and math.copysign(1.0, float(logp[3])) == -1.0     # -0.0 on pad (Quirk Q4)
+    dlogp = torch.randn(rows, device=dev())
+    dz = torch.empty(rows, V, dtype=BF, device=dev())
+    L.call("opadpo_head_bwd", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), dlogp.data_ptr(), 1 / temp,
+           dz.data_ptr(), V, rows, V, L.stream())
+    (want_lp * dlogp).sum().backward()
+    want_dz = z.grad / temp      # d/d logits
+    assert relerr(dz, want_dz) < 5e-3
+    assert float(dz[3].float().abs().max()) == 0.0
+
+
+def test_adamw_and_sumsq(L):
+    n = 100_003
+    torch.manual_seed(0)
+    p = torch.randn(n, device=dev())
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pb = torch.empty(n, dtype=BF, device=dev())
+    ss = torch.zeros(1, device=dev())
+    for step in range(1, 5):
+        g = torch.randn(n, device=dev()) * (5.0 if step % 2 else 0.001)
+        ss.zero_()
+        L.call("opadpo_sumsq", g.data_ptr(), n, ss.data_ptr(), L.stream())
+        assert abs(float(ss) - float((g.double() ** 2).sum())) / float((g.double() ** 2).sum()) < 1e-4
+        L.call("opadpo_adamw", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), pb.data_ptr(), n, 1e-3, 0.9, 0.999,
+               1e-8, 0.01, step, ss.data_ptr(), 1.0, 0.5, L.stream())
+        ref.grad = g.clone() * 0.5
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        assert maxabs(p, ref.detach()) < 2e-6, f"step {step}"
+        assert torch.equal(pb, p.to(BF))
+
+
+def test_attn_decode(L):
+    B, nh, hd, ctx, max_ctx = 3, 2, 128, 70, 96
+    H = nh * hd
+    q = rnd(B, H, seed=1)
+    kc, vc = rnd(B, max_ctx, H, seed=2), rnd(B, max_ctx, H, seed=3)
+    km = torch.ones(B, max_ctx, dtype=torch.uint8, device=dev())
+    km[0, :4] = 0
+    o = torch.empty(B, H, dtype=BF, device=dev())
+    L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o.data_ptr(), km.data_ptr(), B, nh, hd, ctx,
+           max_ctx, hd ** -0.5, L.stream())
+    qf = q.float().view(B, nh, hd)
+    kf = kc.float().view(B, max_ctx, nh, hd)[:, :ctx]
+    vf = vc.float().view(B, max_ctx, nh, hd)[:, :ctx]
+    sc = torch.einsum("bhd,bkhd->bhk", qf, kf) * hd ** -0.5
+    sc = sc.masked_fill(~km[:, None, :ctx].bool(), float("-inf"))
+    want = torch.einsum("bhk,bkhd->bhd", torch.softmax(sc, -1), vf).reshape(B, H)
+    assert relerr(o, want) < 6e-3
+
+
+def test_sampler_distribution(L):
+    V, rows = 512, 4000
+    torch.manual_seed(3)
+    base = torch.randn(V, device=dev()) * 2
+    logits = base[None].repeat(rows, 1).contiguous()
+    out = torch.empty(rows, dtype=torch.int32, device=dev())
+    fin = torch.zeros(rows, dtype=torch.uint8, device=dev())
+    fin[7] = 1
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 5, fin.data_ptr(), 0, out.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    assert int(out[7]) == 0
+    z = base / 0.8
+    kth = torch.topk(z, 30).values[-1]
+    z = z.masked_fill(z < kth, float("-inf"))
+    s, idx = torch.sort(z)
+    rem = torch.softmax(s, -1).cumsum(-1) <= 0.05
+    rem[-1] = False
+    z[idx[rem]] = float("-inf")
+    p = torch.softmax(z, -1)
+    picks = out.long()[fin == 0]
+    assert bool((p[picks] > 0).all()), "sampled a filtered token"
+    emp = torch.bincount(picks, minlength=V).float() / picks.numel()
+    assert float((emp - p).abs().max()) < 0.03
+    # determinism for (seed, step, row) and pure multinomial path
+    out2 = torch.empty_like(out)
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 5, fin.data_ptr(), 0, out2.data_ptr(), L.stream())
+    assert torch.equal(out, out2)
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 1.0, 0, 1.0, 99, 0, None, 0, out2.data_ptr(), L.stream())
+    emp = torch.bincount(out2.long(), minlength=V).float() / rows
+    assert float((emp - torch.softmax(base, -1)).abs().max()) < 0.03
+
+
+def test_errors_are_loud(L):
+    a, b = rnd(10, 64), rnd(100, 64)   # N not a multiple of 128
+    out = torch.empty(10, 100, dtype=BF, device=dev())
+    with pytest.raises(L.OpadpoError):
+        L.gemm_nt(a, b, out)

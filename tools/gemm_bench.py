@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the bf16 MFMA GEMMs at the LLaVA-1.5-7B seq512 shapes (run on the GPU box)."""
+import json
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "opa-dpo_amd"))
+from opadpo_amd import lib as L  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    L.load()
+    dev = torch.device("cuda:0")
+    res = []
+    M = int(os.environ.get("GB_M", 8 * 1087))
+    shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
+              ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
+    for glds in (1, 0):
+        L.set_flags(bool(glds), True)
+        for name, N, K1, K2, grp in shapes:
+            a1 = torch.randn(M, K1, device=dev).to(BF)
+            b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            kw = {}
+            if K2:
+                G = N // grp if grp else 1
+                kw = dict(a2=torch.randn(M, G * K2, device=dev).to(BF), b2=(torch.randn(N, K2, device=dev) * 0.02).to(BF),
+                          a2_group_n=grp, a2_group_stride=K2 if grp else 0)
+            t = timeit(lambda: L.gemm_nt(a1, b1, out, **kw))
+            tf = 2.0 * M * N * (K1 + K2) / t / 1e12
+            res.append(dict(kernel="gemm_nt", glds=glds, name=name, M=M, N=N, K=K1 + K2, ms=t * 1e3, tflops=tf))
+            print(res[-1], flush=True)
+    L.set_flags(True, True)
+    for tr in (1, 0):
+        L.set_flags(True, bool(tr))
+        for name, N1, N2 in (("dB_qkv", 12288, 256), ("dA_qkv", 768, 4096), ("dB_d", 4096, 256), ("dA_d", 256, 11008)):
+            p = torch.randn(M, N1, device=dev).to(BF)
+            q = torch.randn(M, N2, device=dev).to(BF)
+            c = torch.zeros(N1, N2, device=dev)
+            t = timeit(lambda: L.gemm_tn(p, q, c))
+            res.append(dict(kernel="gemm_tn", tr=tr, name=name, M=M, N1=N1, N2=N2, ms=t * 1e3, tflops=2.0 * M * N1 * N2 / t / 1e12))
+            print(res[-1], flush=True)
+    # attention
+    S, Ln, nh, hd = 8, 1087, 32, 128
+    H = nh * hd
+    qkv = torch.randn(S * Ln, 3 * H, device=dev).to(BF)
+    o = torch.empty(S * Ln, H, dtype=BF, device=dev)
+    lse = torch.empty(S, nh, Ln, device=dev)
+    for tr in (1, 0):
+        L.set_flags(True, bool(tr))
+        f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+                           lse.data_ptr(), None, S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
+        t = timeit(f)
+        fl = S * nh * 2 * Ln * Ln * hd * 2 / 2
+        res.append(dict(kernel="attn_fwd", tr=tr, ms=t * 1e3, tflops=fl / t / 1e12))
+        print(res[-1], flush=True)
+        dq = torch.zeros(S * Ln, H, device=dev)
+        dqkv = torch.empty(S * Ln, 3 * H, dtype=BF, device=dev)
+        delta = torch.empty(S, nh, Ln, device=dev)
+        do = torch.randn(S * Ln, H, device=dev).to(BF)
+        f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+                           do.data_ptr(), H, lse.data_ptr(), None, dq.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
+                           delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
+        t = timeit(f)
+        res.append(dict(kernel="attn_bwd", tr=tr, ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
+        print(res[-1], flush=True)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
