@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: preference-pairs/sec, LLaVA-1.5-7B LoRA DPO, seq_len 512 (query 128 + response 384,
+L = 1087 LLM positions), synthetic image+text batches, random-init weights of the 7B architecture.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One STEP = one optimizer step on every rank: `accum` micro-batches of `pairs` (image, chosen, rejected)
+pairs -> vision encode (once per image) -> frozen-reference forward (no grad) -> policy forward (activations
+resident) -> token-level DPO loss -> LoRA backward -> [RCCL exchange of the flat LoRA gradient] -> global-norm
+clip + AdamW -> refresh of the transposed LoRA copies.  Nothing is skipped or cached across steps.
+Weak scaling: per-GPU work is fixed, value = total pairs of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "opa-dpo_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+
+
+def cpu_baseline(dims_kw, q_len, t_len):
+    """Reported CPU baseline: the oracle (the parity-checked CPU restatement of the reference's forward, kind
+    'port') on the host cores, on a bounded sample: ONE of the 32 decoder layers at 7B width, one pair =
+    4 sequence forwards (2 of them under autograd + backward through the LoRA tensors) at L = 1087; scaled by
+    n_layers to a full-model pair (head + vision, <2 % of the FLOPs, not included)."""
+    from oracle import llava_ref as LR
+    torch.set_num_threads(os.cpu_count())
+    d = LR.LlavaDims(**dims_kw)
+    d1 = LR.LlavaDims(**{**dims_kw, "n_layers": 1})
+    g = torch.Generator().manual_seed(0)
+    W, lora = {}, {}
+    p = "model.layers.0."
+    for lin in LR.LLM_LINEARS:
+        o, i = LR.llm_linear_shape(d1, lin)
+        W[p + lin + ".weight"] = torch.randn(o, i, generator=g) * 0.02
+        lora[f"base_model.model.{p}{lin}.lora_A.weight"] = (torch.randn(d.lora_r, i, generator=g) * 0.01).requires_grad_(True)
+        lora[f"base_model.model.{p}{lin}.lora_B.weight"] = (torch.randn(o, d.lora_r, generator=g) * 0.01).requires_grad_(True)
+    W[p + "input_layernorm.weight"] = torch.ones(d.hidden)
+    W[p + "post_attention_layernorm.weight"] = torch.ones(d.hidden)
+    L = q_len + t_len + d.n_patches - 1
+    x = torch.randn(2, L, d.hidden, generator=g)
+    km = torch.ones(2, L, dtype=torch.bool)
+    t0 = time.time()
+    with torch.no_grad():
+        LR.llama_decoder(x, km, W, {k: v.detach() for k, v in lora.items()}, d1)      # reference adapter, 2 sequences
+    y = LR.llama_decoder(x, km, W, lora, d1)                                           # policy, 2 sequences
+    y.sum().backward()
+    dt = time.time() - t0
+    pair_s = dt * d.n_layers
+    return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), 4 seq-forwards + LoRA backward "
+                      f"of 2 at L={L}: {dt:.1f} s, scaled x{d.n_layers}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 8)), help="pairs per micro-batch per GPU")
+    ap.add_argument("--accum", type=int, default=int(os.environ.get("OPADPO_BENCH_ACCUM", 2)), help="micro-batches per optimizer step")
+    ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
+    ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from opadpo_amd import lib as L
+    from opadpo_amd.dims import LlavaDims, pair_flops
+    from opadpo_amd.losses import DPOArgs, pair_loss
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
+    from opadpo_amd.optim import FlatAdamW
+    from opadpo_amd.policy import AutoregressivePolicy
+    from opadpo_amd.synth import init_lora, init_weights, synth_pairs
+    L.load()
+
+    d = {"7b": LlavaDims.llava15_7b, "13b": LlavaDims.llava15_13b, "tiny": LlavaDims.tiny}[args.model]()
+    q_len, t_len = (128, 384) if args.model != "tiny" else (16, 16)
+    W = init_weights(d, seed=0, device=dev)
+    base = BaseWeights(d, W, dev, need_backward=True)
+    del W
+    eng = LlavaEngine(base)
+    pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
+    ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
+    torch.cuda.empty_cache()
+    policy = AutoregressivePolicy(eng, pol_ad, t_len)
+    ref_policy = AutoregressivePolicy(eng, ref_ad, t_len)
+    opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode)
+    largs = DPOArgs()
+    batches = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(args.accum)]
+
+    def step():
+        for b in batches:
+            feats = eng.encode_images(b["images"])
+            kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
+                      chosen_response=b["chosen"], rejected_response=b["rejected"])
+            with torch.no_grad():
+                r = ref_policy(**kw)
+            o = policy(**kw)
+            loss, _, _ = pair_loss(largs, o["chosen_response_logprobs"], o["rejected_response_logprobs"],
+                                   r["chosen_response_logprobs"], r["rejected_response_logprobs"])
+            loss.backward()
+        opt.step(grad_accum_div=args.accum)
+        opt.zero_grad()
+        pol_ad.refresh_transposed()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    L.PROFILE = [] if rank == 0 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, L.PROFILE = L.PROFILE, None
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    pairs_per_step = args.pairs * args.accum * world
+    value = pairs_per_step * args.steps / dt
+    if rank == 0:
+        fl = pair_flops(d, q_len, t_len)
+        roof = None
+        if prof:
+            tot_f = sum(p[0] for p in prof)
+            tot_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+            ach = tot_f / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<glds> (bf16 MFMA GEMM with fused LoRA tail)",
+                    "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                    "traffic": None, "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
+        out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": value, "unit": "pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"LLaVA-1.5-{args.model.upper()} LoRA(r={d.lora_r}) DPO, 1xMI355X per rank, query {q_len} + response {t_len} "
+                                      f"(L={q_len + t_len + d.n_patches - 1}), random-init weights, synthetic pairs",
+                          "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
+                          "global_pairs_per_step": pairs_per_step, "seq_len": q_len + t_len,
+                          "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
+                          "loss": float(loss)},
+               "model_flops_per_pair_TF": fl / 1e12,
+               "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+               "roofline": roof}
+        if args.model == "7b" and world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(dict(hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim,
+                                                        ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,11 +40,12 @@ void opadpo_set_flags(int use_glds, int use_tr);
  * from rl_models.py:120, and their dgrad in backward (rl_trainer.py:162).
  * A2's column offset for output column n0 is (n0 / a2_group_n) * a2_group_stride (fused q|k|v and
  * gate|up projections); pass a2_group_n = 0 for a single group.  N % 128 == 0, K1 % 64 == 0,
- * K2 % 64 == 0; M arbitrary.  out_f32: C is float32 instead of bf16. */
+ * K2 % 64 == 0; M arbitrary.  out_f32: C is float32 instead of bf16; res_f32: R is float32 (the LLM
+ * residual stream is kept in fp32 so bf16 rounding does not accumulate over 2*n_layers additions). */
 int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
                    const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
                    int a2_group_n, int a2_group_stride,
-                   void* C, int ldc, int out_f32, const uint16_t* R, int ldr, const uint16_t* bias,
+                   void* C, int ldc, int out_f32, const void* R, int ldr, int res_f32, const uint16_t* bias,
                    int M, int N, float alpha, int act, void* stream);
 
 /* LoRA weight gradients: C[N1,N2] (fp32) += alpha * sum_m P[m,N1] * Q[m,N2]   (dB = dY^T t,
@@ -69,9 +70,11 @@ int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
                     int S, int L, int nh, int hd, int causal, float scale, void* stream);
 
 /* ---- norms / rotary / SwiGLU (transformers modeling_llama.py / modeling_clip.py) -------------- */
-int opadpo_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream);
-int opadpo_rmsnorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const float* rstd,
-                       const uint16_t* dres, uint16_t* dx, int rows, int H, void* stream);
+/* x: bf16 or (x_f32) float32 rows; y bf16; rstd fp32 [rows] (nullable). */
+int opadpo_rmsnorm_fwd(const void* x, int x_f32, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream);
+/* dx = rmsnorm'(dy) + dres; written as float32 (dx_f32, nullable) and/or bf16 (dx_bf16, nullable). */
+int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint16_t* w, const float* rstd,
+                       const void* dres, int dres_f32, float* dx_f32, uint16_t* dx_bf16, int rows, int H, void* stream);
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
 /* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position r % L);
  * cos/sin: fp32 [L, hd/2]; inverse=1 applies the transposed rotation (gradient). */
@@ -82,9 +85,10 @@ int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu,
 
 /* ---- embedding gather + multimodal splice (LLaVA prepare_inputs_labels_for_multimodal) ------------
  * ids/text_mask [S,n_txt]; each row holds exactly one image_token, replaced by the P rows
- * feats[feat_row[s]] -> x [S, n_txt+P-1, H], key_mask [S, n_txt+P-1].  image_mask [S,P] or NULL. */
+ * feats[feat_row[s]] -> x [S, n_txt+P-1, H] (bf16, or float32 when x_f32), key_mask [S, n_txt+P-1].
+ * image_mask [S,P] or NULL. */
 int opadpo_embed_splice(const int32_t* ids, const uint8_t* text_mask, const uint16_t* embed, const uint16_t* feats,
-                        const int32_t* feat_row, const uint8_t* image_mask, uint16_t* x, uint8_t* key_mask,
+                        const int32_t* feat_row, const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                         int S, int n_txt, int P, int H, int image_token, void* stream);
 
 /* ---- CLIP patch embedding (Conv2d k=s=patch as im2col + gemm_nt) ---------------------------------- */

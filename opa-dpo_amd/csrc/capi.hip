@@ -29,7 +29,7 @@ void opadpo_set_flags(int use_glds, int use_tr) { opadpo_set_flags_impl(use_glds
 int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
                    const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
                    int a2_group_n, int a2_group_stride,
-                   void* C, int ldc, int out_f32, const uint16_t* R, int ldr, const uint16_t* bias,
+                   void* C, int ldc, int out_f32, const void* R, int ldr, int res_f32, const uint16_t* bias,
                    int M, int N, float alpha, int act, void* stream) {
   if (M < 0 || N <= 0 || N % 128) return bad("opadpo_gemm_nt", "N must be a positive multiple of 128");
   if (K1 < 0 || K2 < 0 || K1 % 64 || K2 % 64 || K1 + K2 == 0) return bad("opadpo_gemm_nt", "K1/K2 must be multiples of 64");
@@ -42,7 +42,7 @@ int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, i
   a.M = M; a.N = N; a.K1 = K1; a.K2 = K2;
   a.lda1 = lda1; a.ldb1 = ldb1; a.lda2 = lda2; a.ldb2 = ldb2; a.ldc = ldc; a.ldr = ldr;
   a.a2_group_n = a2_group_n; a.a2_group_stride = a2_group_stride;
-  a.alpha = alpha; a.act = act; a.out_f32 = out_f32;
+  a.alpha = alpha; a.act = act; a.out_f32 = out_f32; a.r_f32 = res_f32;
   return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt");
 }
 
@@ -85,12 +85,13 @@ int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
   return done(launch_attn_bwd(a, S(stream)), "opadpo_attn_bwd");
 }
 
-int opadpo_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream) {
-  return done(launch_rmsnorm_fwd(x, w, y, rstd, rows, H, eps, S(stream)), "opadpo_rmsnorm_fwd");
+int opadpo_rmsnorm_fwd(const void* x, int x_f32, const uint16_t* w, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream) {
+  return done(launch_rmsnorm_fwd(x, x_f32, w, y, rstd, rows, H, eps, S(stream)), "opadpo_rmsnorm_fwd");
 }
-int opadpo_rmsnorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const float* rstd,
-                       const uint16_t* dres, uint16_t* dx, int rows, int H, void* stream) {
-  return done(launch_rmsnorm_bwd(dy, x, w, rstd, dres, dx, rows, H, S(stream)), "opadpo_rmsnorm_bwd");
+int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint16_t* w, const float* rstd,
+                       const void* dres, int dres_f32, float* dx_f32, uint16_t* dx_bf16, int rows, int H, void* stream) {
+  if (!dx_f32 && !dx_bf16) return bad("opadpo_rmsnorm_bwd", "no output buffer");
+  return done(launch_rmsnorm_bwd(dy, x, x_f32, w, rstd, dres, dres_f32, dx_f32, dx_bf16, rows, H, S(stream)), "opadpo_rmsnorm_bwd");
 }
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream) {
   return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
@@ -107,10 +108,10 @@ int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu,
   return done(launch_silu_mul_bwd(dact, gu, dgu, rows, F, S(stream)), "opadpo_silu_mul_bwd");
 }
 int opadpo_embed_splice(const int32_t* ids, const uint8_t* text_mask, const uint16_t* embed, const uint16_t* feats,
-                        const int32_t* feat_row, const uint8_t* image_mask, uint16_t* x, uint8_t* key_mask,
+                        const int32_t* feat_row, const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                         int S_, int n_txt, int P, int H, int image_token, void* stream) {
   if (!ids || !text_mask || !embed || !feats || !feat_row || !x || !key_mask) return bad("opadpo_embed_splice", "null operand");
-  return done(launch_embed_splice(ids, text_mask, embed, feats, feat_row, image_mask, x, key_mask, S_, n_txt, P, H,
+  return done(launch_embed_splice(ids, text_mask, embed, feats, feat_row, image_mask, x, x_f32, key_mask, S_, n_txt, P, H,
                                   image_token, S(stream)), "opadpo_embed_splice");
 }
 int opadpo_im2col(const uint16_t* pixels, uint16_t* out, int B, int image_size, int patch, int kpad, void* stream) {

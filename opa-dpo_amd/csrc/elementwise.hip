@@ -5,16 +5,29 @@
 namespace {
 
 // ---- RMSNorm ------------------------------------------------------------------------------
-// one block (256 threads) per row; H % 8 == 0.  y = x * rsqrt(mean(x^2) + eps) * w
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd,
+// one block (256 threads) per row; H % 8 == 0.  y = x * rsqrt(mean(x^2) + eps) * w.  The residual
+// stream x may be fp32 (XF) — the LLM keeps it in fp32 so that bf16 rounding does not accumulate
+// across the 2*n_layers residual additions.
+template <bool XF>
+__device__ __forceinline__ void load8(const void* base, size_t idx, float* f) {
+  if constexpr (XF) {
+    const float4 a = *(const float4*)((const float*)base + idx);
+    const float4 b = *(const float4*)((const float*)base + idx + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    unpack8(*(const uint4*)((const bf16_t*)base + idx), f);
+  }
+}
+
+template <bool XF>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* x, const bf16_t* w, bf16_t* y, float* rstd,
                                                            int H, float eps) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
-  const bf16_t* xr = x + row * H;
   float ss = 0.f;
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8];
-    unpack8(*(const uint4*)(xr + i), f);
+    load8<XF>(x, row * H + i, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
   }
@@ -23,7 +36,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const
   if (rstd && threadIdx.x == 0) rstd[row] = r;
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8], g[8];
-    unpack8(*(const uint4*)(xr + i), f);
+    load8<XF>(x, row * H + i, f);
     unpack8(*(const uint4*)(w + i), g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = f[j] * r * g[j];
@@ -31,9 +44,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* x, const
   }
 }
 
-// dx = rstd * (g - xhat * mean(g * xhat)) (+ dres),  g = dy * w, xhat = x * rstd
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* w,
-                                                           const float* rstd, const bf16_t* dres, bf16_t* dx, int H) {
+// dx = rstd * (g - xhat * mean(g * xhat)) (+ dres),  g = dy * w, xhat = x * rstd.
+// Writes the fp32 gradient residual stream (dx_f32) and/or its bf16 copy (dx_bf16, GEMM operand).
+template <bool XF, bool RF>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const void* x, const bf16_t* w,
+                                                           const float* rstd, const void* dres, float* dx_f32,
+                                                           bf16_t* dx_bf16, int H) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   const float r = rstd[row];
@@ -41,7 +57,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float a[8], b[8], c[8];
     unpack8(*(const uint4*)(dy + row * H + i), a);
-    unpack8(*(const uint4*)(x + row * H + i), b);
+    load8<XF>(x, row * H + i, b);
     unpack8(*(const uint4*)(w + i), c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) dot += a[j] * c[j] * b[j] * r;
@@ -50,17 +66,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float a[8], b[8], c[8], o[8];
     unpack8(*(const uint4*)(dy + row * H + i), a);
-    unpack8(*(const uint4*)(x + row * H + i), b);
+    load8<XF>(x, row * H + i, b);
     unpack8(*(const uint4*)(w + i), c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = r * (a[j] * c[j] - b[j] * r * dot);
     if (dres) {
       float d[8];
-      unpack8(*(const uint4*)(dres + row * H + i), d);
+      load8<RF>(dres, row * H + i, d);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] += d[j];
     }
-    *(uint4*)(dx + row * H + i) = pack8(o);
+    if (dx_f32) {
+      *(float4*)(dx_f32 + row * H + i) = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)(dx_f32 + row * H + i + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (dx_bf16) *(uint4*)(dx_bf16 + row * H + i) = pack8(o);
   }
 }
 
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* dact, c
 // position.  Also emits the key mask [S,L].
 __global__ __launch_bounds__(256) void embed_splice_kernel(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed,
                                                             const bf16_t* feats, const int32_t* feat_row,
-                                                            const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                                                            const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                                                             int n_txt, int P, int H, int image_token) {
   __shared__ int img_pos;
   const int s = blockIdx.y, pos = blockIdx.x;
@@ -201,8 +221,18 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const int32_t* ids, c
     src = embed + (size_t)max(id, 0) * H;
     m = text_mask[(size_t)s * n_txt + min(t, n_txt - 1)];
   }
-  bf16_t* dst = x + ((size_t)s * L + pos) * H;
-  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) *(uint4*)(dst + i) = *(const uint4*)(src + i);
+  const size_t orow = ((size_t)s * L + pos) * H;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    const uint4 v = *(const uint4*)(src + i);
+    if (x_f32) {
+      float f[8];
+      unpack8(v, f);
+      *(float4*)((float*)x + orow + i) = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)((float*)x + orow + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+      *(uint4*)((bf16_t*)x + orow + i) = v;
+    }
+  }
   if (threadIdx.x == 0) key_mask[(size_t)s * L + pos] = m;
 }
 
@@ -308,17 +338,23 @@ inline int ew_grid(size_t total_threads) {
 
 }  // namespace
 
-hipError_t launch_rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st) {
+hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
+  if (x_f32) hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
+  else hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
   return hipGetLastError();
 }
-hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                              bf16_t* dx, int rows, int H, hipStream_t st) {
+hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
+                              int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, rstd, dres, dx, H);
+#define RB(XF, RF) hipLaunchKernelGGL((rmsnorm_bwd_kernel<XF, RF>), dim3(rows), dim3(256), 0, st, dy, x, w, rstd, dres, dx_f32, dx_bf16, H)
+  if (x_f32 && dres_f32) RB(true, true);
+  else if (x_f32) RB(true, false);
+  else if (dres_f32) RB(false, true);
+  else RB(false, false);
+#undef RB
   return hipGetLastError();
 }
 hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st) {
@@ -348,12 +384,12 @@ hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu
   return hipGetLastError();
 }
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
-                               const int32_t* feat_row, const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                               const int32_t* feat_row, const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                                int S, int n_txt, int P, int H, int image_token, hipStream_t st) {
   if (S <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_splice_kernel, dim3(n_txt + P - 1, S), dim3(256), 0, st, ids, text_mask, embed, feats, feat_row,
-                     image_mask, x, key_mask, n_txt, P, H, image_token);
+                     image_mask, x, x_f32, key_mask, n_txt, P, H, image_token);
   return hipGetLastError();
 }
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st) {

@@ -158,9 +158,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], p.act);
       }
       if (p.R) {
-        const uint2 r = *(const uint2*)(p.R + (size_t)m * p.ldr + n);
-        v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-        v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+        if (p.r_f32) {
+          const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        } else {
+          const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+        }
       }
       if (p.out_f32) {
         *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);

@@ -10,7 +10,7 @@ struct GemmNTArgs {
   const bf16_t* A1; const bf16_t* B1;   // [M,K1] lda1 ; [N,K1] ldb1
   const bf16_t* A2; const bf16_t* B2;   // LoRA tail: [M,*] lda2 ; [N,K2] ldb2 (may be null, K2 = 0)
   void* C;                              // [M,N] ldc, bf16 or fp32
-  const bf16_t* R;                      // residual [M,N] ldr (nullable)
+  const void* R;                        // residual [M,N] ldr (nullable), bf16 or fp32 (r_f32)
   const bf16_t* bias;                   // [N] (nullable)
   int M, N, K1, K2;
   int lda1, ldb1, lda2, ldb2, ldc, ldr;
@@ -18,6 +18,7 @@ struct GemmNTArgs {
   float alpha;
   int act;
   int out_f32;
+  int r_f32;
 };
 
 struct GemmTNArgs {
@@ -55,16 +56,16 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st);
 
-hipError_t launch_rmsnorm_fwd(const bf16_t* x, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st);
-hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const float* rstd, const bf16_t* dres,
-                              bf16_t* dx, int rows, int H, hipStream_t st);
+hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st);
+hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
+                              int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
 hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
                        int inverse, hipStream_t st);
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
-                               const int32_t* feat_row, const uint8_t* image_mask, bf16_t* x, uint8_t* key_mask,
+                               const int32_t* feat_row, const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                                int S, int n_txt, int P, int H, int image_token, hipStream_t st);
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st);
 hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st);

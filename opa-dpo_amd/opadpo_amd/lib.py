@@ -24,17 +24,17 @@ _u64 = C.c_uint64
 
 # name -> argtypes (restype is int unless noted).  Must list EVERY symbol of include/opadpo_hip.h.
 SIGNATURES = {
-    "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _f, _i, _p],
+    "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "opadpo_rmsnorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
-    "opadpo_rmsnorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_rmsnorm_bwd": [_p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "opadpo_silu_mul_fwd": [_p, _p, _i, _i, _p],
     "opadpo_silu_mul_bwd": [_p, _p, _p, _i, _i, _p],
-    "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "opadpo_im2col": [_p, _p, _i, _i, _i, _i, _p],
     "opadpo_vision_embed": [_p, _p, _p, _p, _i, _i, _i, _p],
     "opadpo_gather_rows": [_p, _i, _p, _p, _i, _i, _p],
@@ -116,6 +116,11 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise OpadpoError(f"{name}: innermost dimension must be contiguous")
 
 
+# Optional live profiling of the dominant kernel (bench.py): when PROFILE is a list, every gemm_nt launch
+# is bracketed by HIP events recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
 def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
             b2: Optional[torch.Tensor] = None, a2_group_n: int = 0, a2_group_stride: int = 0,
             residual: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
@@ -133,10 +138,19 @@ def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Option
         assert b2.shape[0] == N and a2.shape[0] == M
     out_f32 = out.dtype == torch.float32
     assert out_f32 or out.dtype == torch.bfloat16
+    res_f32 = residual is not None and residual.dtype == torch.float32
+    assert residual is None or res_f32 or residual.dtype == torch.bfloat16
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("opadpo_gemm_nt", ptr(a1), a1.stride(0), ptr(b1), b1.stride(0), K1,
          ptr(a2), a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
          a2_group_n, a2_group_stride, ptr(out), out.stride(0), int(out_f32),
-         ptr(residual), residual.stride(0) if residual is not None else 0, ptr(bias), M, N, float(alpha), act, stream())
+         ptr(residual), residual.stride(0) if residual is not None else 0, int(res_f32), ptr(bias), M, N, float(alpha), act,
+         stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((2.0 * M * N * (K1 + K2), e0, e1))
     return out
 
 

@@ -151,7 +151,8 @@ class LoraAdapter:
         blocks = lora_blocks(d)
         self.layer_numel = sum(r * c for _, r, c in blocks)
         self.numel = self.layer_numel * d.n_layers
-        flat = torch.empty(self.numel, dtype=torch.float32)
+        build_dev = next(iter(peft_state.values())).device      # assemble where the tensors already live
+        flat = torch.empty(self.numel, dtype=torch.float32, device=build_dev)
         self.offsets: List[Dict[str, tuple]] = []
         pm = _peft_map(d)
         off = 0
@@ -223,6 +224,16 @@ class LoraAdapter:
                 for mod, ab, r0, nr in pm[name]:
                     out[f"{PEFT_PREFIX}{LLM_PREFIX}layers.{i}.{mod}.{ab}.weight"] = view[r0: r0 + nr].to(BF).cpu().clone()
         return out
+
+
+def _dbg(name: str, t: torch.Tensor) -> None:
+    """OPADPO_DEBUG_NAN=1: report non-finite intermediates (diagnostics only)."""
+    import os
+    if os.environ.get("OPADPO_DEBUG_NAN"):
+        torch.cuda.synchronize()
+        f = t.float()
+        bad = int((~torch.isfinite(f)).sum())
+        print(f"[dbg] {name}: shape={tuple(t.shape)} nonfinite={bad} absmax={float(f[torch.isfinite(f)].abs().max()) if bad < f.numel() else float('nan'):.4g}", flush=True)
 
 
 @dataclass
@@ -318,7 +329,7 @@ class LlavaEngine:
         sv.S, sv.L, sv.T, sv.M, sv.train = S, Lp, T, M, train
         nb = nl if train else 1
         e = lambda shape, dtype=BF: torch.empty(*shape, dtype=dtype, device=self.dev)
-        sv.x = e((nl + 1 if train else 2, M, H))
+        sv.x = e((nl + 1 if train else 2, M, H), torch.float32)     # fp32 residual stream
         sv.n1 = e((nb, M, H))
         sv.rstd1 = e((nb, M), torch.float32)
         sv.qkv = e((nb, M, 3 * H))
@@ -326,7 +337,7 @@ class LlavaEngine:
         sv.attn = e((nb, M, H))
         sv.lse = e((nb, S, d.n_heads, Lp), torch.float32)
         sv.t_o = e((nb, M, r))
-        sv.h = e((nb, M, H))
+        sv.h = e((nb, M, H), torch.float32)
         sv.n2 = e((nb, M, H))
         sv.rstd2 = e((nb, M), torch.float32)
         sv.t_gu = e((nb, M, 2 * r))
@@ -335,7 +346,7 @@ class LlavaEngine:
         sv.t_d = e((nb, M, r))
         R = S * T
         sv.key_mask = e((S, Lp), torch.uint8)
-        sv.hs = e((R, H))
+        sv.hs = e((R, H), torch.float32)
         sv.hn = e((R, H))
         sv.rstd_f = e((R,), torch.float32)
         sv.logits = e((R, d.vocab), torch.float32)
@@ -360,7 +371,7 @@ class LlavaEngine:
         sv.temperature = temperature
         x0 = sv.x[0]
         L.call("opadpo_embed_splice", L.ptr(batch.ids), L.ptr(batch.text_mask), L.ptr(b.embed), L.ptr(feats),
-               L.ptr(batch.feat_row), L.ptr(batch.image_mask), L.ptr(x0), L.ptr(sv.key_mask), S, n_txt, P, H,
+               L.ptr(batch.feat_row), L.ptr(batch.image_mask), L.ptr(x0), 1, L.ptr(sv.key_mask), S, n_txt, P, H,
                IMAGE_TOKEN_INDEX, st)
         cos, sin = b.rope_tables(Lp)
         for i, w in enumerate(b.layers):
@@ -369,7 +380,7 @@ class LlavaEngine:
             xo = sv.x[i + 1 if train else ((i + 1) & 1)]
             n1, qkv, t_qkv, attn, t_o, h, n2, t_gu, gu, act, t_d = (sv.n1[k], sv.qkv[k], sv.t_qkv[k], sv.attn[k], sv.t_o[k],
                                                                      sv.h[k], sv.n2[k], sv.t_gu[k], sv.gu[k], sv.act[k], sv.t_d[k])
-            L.call("opadpo_rmsnorm_fwd", L.ptr(x), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
+            L.call("opadpo_rmsnorm_fwd", L.ptr(x), 1, L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
             L.gemm_nt(n1, adapter.w(i, "a_qkv"), t_qkv, alpha=s)
             L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
             L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, st)
@@ -377,7 +388,7 @@ class LlavaEngine:
                    L.ptr(sv.lse[k]), L.ptr(sv.key_mask), S, Lp, nh, hd, 1, hd ** -0.5, st)
             L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
             L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
-            L.call("opadpo_rmsnorm_fwd", L.ptr(h), L.ptr(w["ln2"]), L.ptr(n2), L.ptr(sv.rstd2[k]), M, H, d.rms_eps, st)
+            L.call("opadpo_rmsnorm_fwd", L.ptr(h), 1, L.ptr(w["ln2"]), L.ptr(n2), L.ptr(sv.rstd2[k]), M, H, d.rms_eps, st)
             L.gemm_nt(n2, adapter.w(i, "a_gu"), t_gu, alpha=s)
             L.gemm_nt(n2, w["wgu"], gu, a2=t_gu, b2=adapter.w(i, "b_gu"), a2_group_n=F, a2_group_stride=r)
             L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
@@ -390,8 +401,8 @@ class LlavaEngine:
                 + torch.arange(Lp - T - 1, Lp - 1, device=self.dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
         labels = batch.ids[:, n_txt - T:].contiguous().view(-1)
         sv.rows, sv.labels = rows, labels
-        L.call("opadpo_gather_rows", L.ptr(xf), H, L.ptr(rows), L.ptr(sv.hs), R, H, st)
-        L.call("opadpo_rmsnorm_fwd", L.ptr(sv.hs), L.ptr(b.norm), L.ptr(sv.hn), L.ptr(sv.rstd_f), R, H, d.rms_eps, st)
+        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(rows), L.ptr(sv.hs), R, 2 * H, st)   # fp32 rows = 2H bf16 units
+        L.call("opadpo_rmsnorm_fwd", L.ptr(sv.hs), 1, L.ptr(b.norm), L.ptr(sv.hn), L.ptr(sv.rstd_f), R, H, d.rms_eps, st)
         L.gemm_nt(sv.hn, b.lm_head, sv.logits)
         logp = torch.empty(R, dtype=torch.float32, device=self.dev)
         ent = torch.empty(R, dtype=torch.float32, device=self.dev)
@@ -414,12 +425,16 @@ class LlavaEngine:
                1.0 / sv.temperature, L.ptr(dz), V, R, V, st)
         d_hn = self.buf("bw_dhn", (R, H))
         L.gemm_nt(dz, b.lm_head_t, d_hn)
-        d_hs = self.buf("bw_dhs", (R, H))
-        L.call("opadpo_rmsnorm_bwd", L.ptr(d_hn), L.ptr(sv.hs), L.ptr(b.norm), L.ptr(sv.rstd_f), None, L.ptr(d_hs), R, H, st)
-        dX = self.buf("bw_dX", (M, H))
+        d_hs = self.buf("bw_dhs", (R, H), torch.float32)
+        L.call("opadpo_rmsnorm_bwd", L.ptr(d_hn), L.ptr(sv.hs), 1, L.ptr(b.norm), L.ptr(sv.rstd_f), None, 0, L.ptr(d_hs), None, R, H, st)
+        dX = self.buf("bw_dX", (M, H), torch.float32)      # fp32 gradient residual stream ...
+        dXb = self.buf("bw_dXb", (M, H))                    # ... and its bf16 copy (GEMM operand)
         dX.zero_()
-        L.call("opadpo_scatter_rows", L.ptr(d_hs), L.ptr(sv.rows), L.ptr(dX), H, R, H, st)
-        d_h = self.buf("bw_dh", (M, H))
+        L.call("opadpo_scatter_rows", L.ptr(d_hs), L.ptr(sv.rows), L.ptr(dX), 2 * H, R, 2 * H, st)
+        L.call("opadpo_f32_to_bf16", L.ptr(dX), L.ptr(dXb), M * H, st)
+        _dbg("dz", dz); _dbg("d_hn", d_hn); _dbg("d_hs", d_hs); _dbg("dX0", dX)
+        d_h = self.buf("bw_dh", (M, H), torch.float32)
+        d_hb = self.buf("bw_dhb", (M, H))
         d_n = self.buf("bw_dn", (M, H))
         d_act = self.buf("bw_dact", (M, F))
         d_gu = self.buf("bw_dgu", (M, 2 * F))
@@ -433,32 +448,38 @@ class LlavaEngine:
         cos, sin = b.rope_tables(Lp)
         for i in range(d.n_layers - 1, -1, -1):
             w = b.layers[i]
-            dY = dX
+            dY, dYf = dXb, dX
             # ---- MLP -------------------------------------------------------------------------------
             L.gemm_nt(dY, adapter.wt(i, "b_d")[0], dt_r, alpha=s)
             L.gemm_tn(dY, sv.t_d[i], adapter.g(i, "b_d"))
             L.gemm_tn(dt_r, sv.act[i], adapter.g(i, "a_d"))
             L.gemm_nt(dY, w["wd_t"], d_act, a2=dt_r, b2=adapter.wt(i, "a_d"))
             L.call("opadpo_silu_mul_bwd", L.ptr(d_act), L.ptr(sv.gu[i]), L.ptr(d_gu), M, F, st)
+            _dbg(f"L{i} d_act", d_act); _dbg(f"L{i} d_gu", d_gu)
             bgt = adapter.wt(i, "b_gu")
             for g in range(2):
                 L.gemm_nt(d_gu[:, g * F:(g + 1) * F], bgt[g], dt_2r[:, g * r:(g + 1) * r], alpha=s)
             L.gemm_tn(d_gu, sv.t_gu[i], adapter.g(i, "b_gu"), q_group_n1=F, q_group_stride=r)
             L.gemm_tn(dt_2r, sv.n2[i], adapter.g(i, "a_gu"))
             L.gemm_nt(d_gu, w["wgu_t"], d_n, a2=dt_2r, b2=adapter.wt(i, "a_gu"))
-            L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.h[i]), L.ptr(w["ln2"]), L.ptr(sv.rstd2[i]), L.ptr(dY), L.ptr(d_h), M, H, st)
+            L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.h[i]), 1, L.ptr(w["ln2"]), L.ptr(sv.rstd2[i]), L.ptr(dYf), 1,
+                   L.ptr(d_h), L.ptr(d_hb), M, H, st)
+            _dbg(f"L{i} d_n2", d_n); _dbg(f"L{i} d_h", d_h)
             # ---- attention -------------------------------------------------------------------------
-            L.gemm_nt(d_h, adapter.wt(i, "b_o")[0], dt_r, alpha=s)
-            L.gemm_tn(d_h, sv.t_o[i], adapter.g(i, "b_o"))
+            L.gemm_nt(d_hb, adapter.wt(i, "b_o")[0], dt_r, alpha=s)
+            L.gemm_tn(d_hb, sv.t_o[i], adapter.g(i, "b_o"))
             L.gemm_tn(dt_r, sv.attn[i], adapter.g(i, "a_o"))
-            L.gemm_nt(d_h, w["wo_t"], d_attn, a2=dt_r, b2=adapter.wt(i, "a_o"))
+            L.gemm_nt(d_hb, w["wo_t"], d_attn, a2=dt_r, b2=adapter.wt(i, "a_o"))
             dq_acc.zero_()
             qkv = sv.qkv[i]
             L.call("opadpo_attn_bwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(sv.attn[i]),
                    L.ptr(d_attn), H, L.ptr(sv.lse[i]), L.ptr(sv.key_mask), L.ptr(dq_acc), dqkv.data_ptr() + 2 * H,
                    dqkv.data_ptr() + 4 * H, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, st)
+            _dbg(f"L{i} d_attn", d_attn); _dbg(f"L{i} attn", sv.attn[i]); _dbg(f"L{i} lse", sv.lse[i]); _dbg(f"L{i} delta", delta)
+            _dbg(f"L{i} dq_acc", dq_acc); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
             L.call("opadpo_f32_to_bf16_strided", L.ptr(dq_acc), L.ptr(dqkv), M, H, 3 * H, st)
             L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, st)
+            _dbg(f"L{i} dqkv(after rope)", dqkv)
             bqt = adapter.wt(i, "b_qkv")
             for g in range(3):
                 L.gemm_nt(dqkv[:, g * H:(g + 1) * H], bqt[g], dt_3r[:, g * r:(g + 1) * r], alpha=s)
@@ -466,4 +487,5 @@ class LlavaEngine:
             L.gemm_tn(dt_3r, sv.n1[i], adapter.g(i, "a_qkv"))
             if i > 0:   # layer-0 input is the frozen embedding / image features: no further dgrad
                 L.gemm_nt(dqkv, w["wqkv_t"], d_n, a2=dt_3r, b2=adapter.wt(i, "a_qkv"))
-                L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.x[i]), L.ptr(w["ln1"]), L.ptr(sv.rstd1[i]), L.ptr(d_h), L.ptr(dX), M, H, st)
+                L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.x[i]), 1, L.ptr(w["ln1"]), L.ptr(sv.rstd1[i]), L.ptr(d_h), 1,
+                       L.ptr(dX), L.ptr(dXb), M, H, st)

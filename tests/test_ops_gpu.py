@@ -86,6 +86,10 @@ def test_gemm_nt_epilogue(L, act):
     out32 = torch.empty(M, N, dtype=torch.float32, device=dev())
     L.gemm_nt(a, b, out32)
     assert relerr(out32, a.float() @ b.float().t()) < 1e-5
+    res32 = torch.randn(M, N, device=dev())
+    o32 = torch.empty(M, N, device=dev())
+    L.gemm_nt(a, b, o32, residual=res32)
+    assert relerr(o32, a.float() @ b.float().t() + res32) < 1e-5
     # strided views (leading dimension != width)
     big = rnd(M, 3 * K, seed=5)
     outw = torch.zeros(M, 2 * N, dtype=BF, device=dev())
@@ -195,23 +199,28 @@ def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
 
 
 # ---------------------------------------------------------------------------------------------------
-def test_rmsnorm(L):
+@pytest.mark.parametrize("xf32", [0, 1])
+def test_rmsnorm(L, xf32):
     rows, H = 37, 512
-    x, w = rnd(rows, H, seed=1), (1 + 0.1 * torch.randn(H)).to(BF).to(dev())
-    y = torch.empty_like(x)
+    xb, w = rnd(rows, H, seed=1), (1 + 0.1 * torch.randn(H)).to(BF).to(dev())
+    x = xb.float().contiguous() if xf32 else xb
+    y = torch.empty(rows, H, dtype=BF, device=dev())
     rstd = torch.empty(rows, device=dev())
-    L.call("opadpo_rmsnorm_fwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, H, 1e-5, L.stream())
-    xf = x.float().requires_grad_(True)
+    L.call("opadpo_rmsnorm_fwd", x.data_ptr(), xf32, w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, H, 1e-5, L.stream())
+    xf = xb.float().requires_grad_(True)
     r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)
     want = xf * r * w.float()
     assert relerr(y, want) < 4e-3
     assert relerr(rstd, r.squeeze(-1)) < 1e-5
-    dy, dres = rnd(rows, H, seed=2), rnd(rows, H, seed=3)
-    dx = torch.empty_like(x)
-    L.call("opadpo_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), dres.data_ptr(), dx.data_ptr(),
-           rows, H, L.stream())
+    dy, dresb = rnd(rows, H, seed=2), rnd(rows, H, seed=3)
+    dres = dresb.float().contiguous() if xf32 else dresb
+    dx32 = torch.empty(rows, H, device=dev())
+    dx16 = torch.empty(rows, H, dtype=BF, device=dev())
+    L.call("opadpo_rmsnorm_bwd", dy.data_ptr(), x.data_ptr(), xf32, w.data_ptr(), rstd.data_ptr(), dres.data_ptr(), xf32,
+           dx32.data_ptr(), dx16.data_ptr(), rows, H, L.stream())
     want.backward(dy.float())
-    assert relerr(dx, xf.grad + dres.float()) < 4e-3
+    assert relerr(dx32, xf.grad + dresb.float()) < 1e-5
+    assert torch.equal(dx16, dx32.to(BF))
 
 
 def test_layernorm(L):
@@ -274,11 +283,17 @@ def test_embed_splice(L):
     im = torch.ones(S, P, dtype=torch.uint8)
     im[1, 1] = 0
     x = torch.zeros(S, n_txt + P - 1, H, dtype=BF, device=dev())
+    x32 = torch.zeros(S, n_txt + P - 1, H, device=dev())
     km = torch.zeros(S, n_txt + P - 1, dtype=torch.uint8, device=dev())
-    L.call("opadpo_embed_splice", ids.to(torch.int32).to(dev()).data_ptr(), tm.to(dev()).data_ptr(), embed.data_ptr(),
-           feats.data_ptr(), feat_row.to(dev()).data_ptr(), im.to(dev()).data_ptr(), x.data_ptr(), km.data_ptr(),
+    ids_d, tm_d, fr_d, im_d = ids.to(torch.int32).to(dev()), tm.to(dev()), feat_row.to(dev()), im.to(dev())   # keep alive
+    L.call("opadpo_embed_splice", ids_d.data_ptr(), tm_d.data_ptr(), embed.data_ptr(),
+           feats.data_ptr(), fr_d.data_ptr(), im_d.data_ptr(), x.data_ptr(), 0, km.data_ptr(),
+           S, n_txt, P, H, -200, L.stream())
+    L.call("opadpo_embed_splice", ids_d.data_ptr(), tm_d.data_ptr(), embed.data_ptr(),
+           feats.data_ptr(), fr_d.data_ptr(), im_d.data_ptr(), x32.data_ptr(), 1, km.data_ptr(),
            S, n_txt, P, H, -200, L.stream())
     torch.cuda.synchronize()
+    assert torch.equal(x32, x.float())
     for s in range(S):
         p = int((ids[s] == -200).nonzero()[0, 0])
         e = embed[ids[s].clamp_min(0).to(dev())]
