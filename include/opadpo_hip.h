@@ -62,11 +62,11 @@ int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float
 int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
                     float* lse, const uint8_t* key_mask, int S, int L, int nh, int hd, int causal, float scale,
                     void* stream);
-/* dq_acc: fp32 [S*L, nh*hd], zeroed by the caller; dk/dv bf16 with the k/v addressing;
- * delta: fp32 scratch [S,nh,L]. */
+/* dq/dk/dv: bf16 with the q/k/v addressing (ld); dq_f32: optional fp32 copy of dQ [S*L, nh*hd]
+ * (NULL in the product path); delta: fp32 scratch [S,nh,L].  Atomic-free (two passes: dK/dV, dQ). */
 int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
                     const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
-                    float* dq_acc, uint16_t* dk, uint16_t* dv, float* delta,
+                    uint16_t* dq, uint16_t* dk, uint16_t* dv, float* dq_f32, float* delta,
                     int S, int L, int nh, int hd, int causal, float scale, void* stream);
 
 /* ---- norms / rotary / SwiGLU (transformers modeling_llama.py / modeling_clip.py) -------------- */

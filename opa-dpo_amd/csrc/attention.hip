@@ -9,9 +9,17 @@
 // Masking: causal and/or an arbitrary per-key byte mask [S,L] (left-padded queries,
 // right-padded responses, CoPO 'attention' image-key dropping).
 //
-// Backward (FlashAttention-2 style): block = one KV tile (64 keys) of one (sequence, head),
-// wave w owns keys w*16..+15 (dK/dV in registers), loops over q tiles; dQ goes to an fp32
-// accumulation buffer with atomics.
+// Backward is two atomic-free kernels (the fp32-atomic dQ of a single KV-outer kernel was the
+// bottleneck on MI355X):
+//   dkdv : block = one KV tile (64 keys), wave w owns keys w*16..+15 (dK/dV in registers),
+//          loops over q tiles:  S, dP (contraction over d) ; dV += dO^T P, dK += Q^T dS
+//          (contraction over q through transposed LDS reads).
+//   dq   : block = 64 q rows (forward geometry), loops over KV tiles, recomputes S^T and dP^T in
+//          the swapped layout so that dS^T feeds  dQ^T[d][q] += K^T . dS^T  straight from registers.
+//
+// LDS tiles are [64][HD] bf16 with a 16-byte-chunk XOR swizzle that is conflict-free for BOTH
+// access patterns (row fragments via ds_read_b128, transposed fragments via ds_read_b64_tr_b16):
+//   HD=128 (256-B rows): chunk ^= (row & 7) << 1      HD=64 (128-B rows): chunk ^= ((row >> 1) & 3) << 1
 #include "common.h"
 #include "kernels.h"
 
@@ -19,23 +27,42 @@ namespace {
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// lane gets tile[r0 + j][c0 + c] (j = 0..3) and tile[r1 + j][c0 + c] (slots 4..7), c = lane & 15.
-// r0 / r1 already include the lane-group term.
-template <bool TR>
-__device__ __forceinline__ bf16x8_t lds_frag_rows2(const char* tile, int ld_bytes, int r0, int r1, int c0, int lane) {
+template <int HD>
+__device__ __forceinline__ int swz_mask(int row) {
+  return HD == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+}
+
+// address of element (row, col) [col in bf16 elements] inside a swizzled [64][HD] tile
+template <int HD>
+__device__ __forceinline__ const char* tile_at(const char* tile, int row, int col) {
+  const int b = col * 2;
+  return tile + row * (HD * 2) + ((((b >> 4) ^ swz_mask<HD>(row))) << 4) + (b & 15);
+}
+
+// operand fragment whose contraction index runs along d (row-contiguous): 8 bf16 of row `row`
+// starting at d = kk*32 + g*8
+template <int HD>
+__device__ __forceinline__ bf16x8_t frag_row(const char* tile, int row, int kk, int g) {
+  return *(const bf16x8_t*)(tile + row * (HD * 2) + (((kk * 4 + g) ^ swz_mask<HD>(row)) << 4));
+}
+
+// operand fragment whose contraction index runs along the tile ROWS: lane (c = lane&15) gets
+// tile[r0 + j][c0 + c] (slots 0..3) and tile[r1 + j][c0 + c] (slots 4..7); r0/r1 include the
+// lane-group term.  TR: gfx950 transpose read (inside a 16-lane group lane a supplies the 8-byte
+// address of row a>>2, column chunk a&3; lane c receives column c of that 4x16 block).
+template <int HD, bool TR>
+__device__ __forceinline__ bf16x8_t frag_col(const char* tile, int r0, int r1, int c0, int lane) {
   union { bf16x8_t v; s16x4_t h[2]; uint16_t s[8]; } u;
   const int c = lane & 15;
   if constexpr (TR) {
-    const int colb = (c0 + (c & 3) * 4) * 2;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile + (size_t)(r0 + (c >> 2)) * ld_bytes + colb));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile + (size_t)(r1 + (c >> 2)) * ld_bytes + colb));
+    const int col = c0 + (c & 3) * 4;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile_at<HD>(tile, r0 + (c >> 2), col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tile_at<HD>(tile, r1 + (c >> 2), col)));
   } else {
-    const char* p0 = tile + (size_t)r0 * ld_bytes + (c0 + c) * 2;
-    const char* p1 = tile + (size_t)r1 * ld_bytes + (c0 + c) * 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      u.s[j] = *(const uint16_t*)(p0 + j * ld_bytes);
-      u.s[4 + j] = *(const uint16_t*)(p1 + j * ld_bytes);
+      u.s[j] = *(const uint16_t*)tile_at<HD>(tile, r0 + j, c0 + c);
+      u.s[4 + j] = *(const uint16_t*)tile_at<HD>(tile, r1 + j, c0 + c);
     }
   }
   return u.v;
@@ -48,7 +75,7 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& a, const f32x4_t& b
   return u.v;
 }
 
-// stage a [64][HD] tile (rows = positions pos0.. of sequence s) into LDS row-major, zero past L
+// stage a [64][HD] tile (rows = positions pos0.. of sequence s) into swizzled LDS, zero past L
 template <int HD>
 __device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int ld, int s, int L, int pos0, int head, int tid) {
   constexpr int CPR = HD / 8;  // 16-byte chunks per row
@@ -59,22 +86,29 @@ __device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int ld,
     const int pos = pos0 + row;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (pos < L) v = *(const uint4*)(src + ((size_t)s * L + pos) * ld + head * HD + c16 * 8);
-    *(uint4*)(dst + row * (HD * 2) + c16 * 16) = v;
+    *(uint4*)(dst + row * (HD * 2) + ((c16 ^ swz_mask<HD>(row)) << 4)) = v;
   }
 }
 
+__device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, int s, int L, int k0, int tid) {
+  if (tid < 64) {
+    const int kp = k0 + tid;
+    Ms[tid] = (kp < L) ? (key_mask ? key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int HD, bool TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 64];
   char* Ks = smem;
   char* Vs = smem + 64 * HD * 2;
   uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
-  constexpr int KK = HD / 32, DF = HD / 16, LD = HD * 2;
+  constexpr int KK = HD / 32, DF = HD / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int s = blockIdx.z, h = blockIdx.y;
-  // heavier (later) causal tiles first
-  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;   // heavier (later) causal tiles first
   const int q0 = qt * 64;
   const int L = p.L;
   const int qpos = q0 + w * 16 + c;
@@ -99,10 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int k0 = kt * 64;
     stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
     stage_tile<HD>(Vs, p.v, p.ld, s, L, k0, h, tid);
-    if (tid < 64) {
-      const int kp = k0 + tid;
-      Ms[tid] = (kp < L) ? (p.key_mask ? p.key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
-    }
+    stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
 
     f32x4_t sc[4];
@@ -110,10 +141,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int kf = 0; kf < 4; ++kf) {
       sc[kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        const bf16x8_t kfr = *(const bf16x8_t*)(Ks + (kf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
-        sc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[kk], sc[kf], 0, 0, 0);
-      }
+      for (int kk = 0; kk < KK; ++kk)
+        sc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Ks, kf * 16 + c, kk, g), qf[kk], sc[kf], 0, 0, 0);
     }
     // sc[kf][r] = S^T[key = kf*16 + g*4 + r][q = c]
     float mx = NEG_BIG;
@@ -123,8 +152,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = kf * 16 + g * 4 + r;
-        const int kp = k0 + kl;
-        ok[kf][r] = Ms[kl] && (!p.causal || kp <= qpos);
+        ok[kf][r] = Ms[kl] && (!p.causal || (k0 + kl) <= qpos);
         sc[kf][r] = ok[kf][r] ? sc[kf][r] * p.scale : NEG_BIG;
         mx = fmaxf(mx, sc[kf][r]);
       }
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       const bf16x8_t pf = pack_frag(sc[2 * ks], sc[2 * ks + 1]);
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const bf16x8_t vf = lds_frag_rows2<TR>(Vs, LD, (2 * ks) * 16 + g * 4, (2 * ks + 1) * 16 + g * 4, d * 16, lane);
+        const bf16x8_t vf = frag_col<HD, TR>(Vs, (2 * ks) * 16 + g * 4, (2 * ks + 1) * 16 + g * 4, d * 16, lane);
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
       }
     }
@@ -196,16 +224,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
   }
 }
 
+// ---- backward part 1: dK, dV (KV-outer) ---------------------------------------------------------
 template <int HD, bool TR>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
-  constexpr int KK = HD / 32, DF = HD / 16, LD = HD * 2;
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+  constexpr int KK = HD / 32, DF = HD / 16;
   constexpr int TILE = 64 * HD * 2;
-  __shared__ __attribute__((aligned(16))) char smem[3 * TILE + 64 * 64 * 2 + 64 * 4 * 2 + 64];
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64 * 4 * 2 + 64];
   char* Qs = smem;
   char* dOs = smem + TILE;
-  char* Ks = smem + 2 * TILE;
-  char* dSs = smem + 3 * TILE;                       // [64 q][64 keys] bf16
-  float* lse_s = (float*)(dSs + 64 * 64 * 2);
+  float* lse_s = (float*)(smem + 2 * TILE);
   float* dlt_s = lse_s + 64;
   uint8_t* Ms = (uint8_t*)(dlt_s + 64);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -216,11 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   const int kpos = k0 + w * 16 + c;          // this lane's key (as fragment row / output row)
   const int krow = min(kpos, L - 1);
 
-  stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
-  if (tid < 64) {
-    const int kp = k0 + tid;
-    Ms[tid] = (kp < L) ? (p.key_mask ? p.key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
-  }
+  stage_mask(Ms, p.key_mask, s, L, k0, tid);
   bf16x8_t kf[KK], vf[KK];
   {
     const bf16_t* kp_ = p.k + ((size_t)s * L + krow) * p.ld + h * HD;
@@ -240,14 +263,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   const bool key_ok = Ms[w * 16 + c] != 0;
 
   const int n_qt = (L + 63) / 64;
-  const int qt_begin = p.causal ? kt : 0;
-  for (int qt = qt_begin; qt < n_qt; ++qt) {
+  for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {
     const int q0 = qt * 64;
     stage_tile<HD>(Qs, p.q, p.ld, s, L, q0, h, tid);
     stage_tile<HD>(dOs, p.dout, p.ldo, s, L, q0, h, tid);
     if (tid < 64) {
-      const int qp = q0 + tid;
-      const size_t li = ((size_t)s * p.nh + h) * L + min(qp, L - 1);
+      const size_t li = ((size_t)s * p.nh + h) * L + min(q0 + tid, L - 1);
       lse_s[tid] = p.lse[li];
       dlt_s[tid] = p.delta[li];
     }
@@ -260,11 +281,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       dp[qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        const bf16x8_t qfr = *(const bf16x8_t*)(Qs + (qf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
-        const bf16x8_t dofr = *(const bf16x8_t*)(dOs + (qf * 16 + c) * LD + (kk * 32 + g * 8) * 2);
         // D[i = q][j = key]: lane holds key = c, q = qf*16 + g*4 + r
-        sc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kk], sc[qf], 0, 0, 0);
-        dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[kk], dp[qf], 0, 0, 0);
+        sc[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Qs, qf * 16 + c, kk, g), kf[kk], sc[qf], 0, 0, 0);
+        dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(dOs, qf * 16 + c, kk, g), vf[kk], dp[qf], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -275,10 +294,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
         const int qp = q0 + ql;
         const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp);
         const float pv = ok ? __expf(sc[qf][r] * p.scale - lse_s[ql]) : 0.f;
-        const float ds = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
         sc[qf][r] = pv;
-        dp[qf][r] = ds;
-        *(bf16_t*)(dSs + ql * 128 + (w * 16 + c) * 2) = f2bf(ds);
+        dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
       }
     // dV^T[d][key] += dO^T . P ; dK^T[d][key] += Q^T . dS   (contraction over the 64 q rows)
 #pragma unroll
@@ -288,34 +305,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       const int r0 = (2 * ks) * 16 + g * 4, r1 = (2 * ks + 1) * 16 + g * 4;
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const bf16x8_t dof = lds_frag_rows2<TR>(dOs, LD, r0, r1, d * 16, lane);
-        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[d], 0, 0, 0);
-        const bf16x8_t qf2 = lds_frag_rows2<TR>(Qs, LD, r0, r1, d * 16, lane);
-        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf2, dsf, dk[d], 0, 0, 0);
-      }
-    }
-    __syncthreads();   // dS tile complete
-    // dQ[q = w*16 + c][d] = sum over the 64 keys of dS[q][key] * K[key][d]
-    {
-      f32x4_t dq[DF];
-#pragma unroll
-      for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8_t dsf = *(const bf16x8_t*)(dSs + (w * 16 + c) * 128 + (ks * 32 + g * 8) * 2);
-#pragma unroll
-        for (int d = 0; d < DF; ++d) {
-          const bf16x8_t kfr = lds_frag_rows2<TR>(Ks, LD, ks * 32 + g * 8, ks * 32 + g * 8 + 4, d * 16, lane);
-          dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf, dq[d], 0, 0, 0);
-        }
-      }
-      const int qp = q0 + w * 16 + c;
-      if (qp < L) {
-        float* dst = p.dq_acc + ((size_t)s * L + qp) * (p.nh * HD) + h * HD;
-#pragma unroll
-        for (int d = 0; d < DF; ++d)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(dst + d * 16 + g * 4 + r, dq[d][r]);
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_col<HD, TR>(dOs, r0, r1, d * 16, lane), pf, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_col<HD, TR>(Qs, r0, r1, d * 16, lane), dsf, dk[d], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -330,6 +321,100 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       b.x = pack_bf2(dv[d][0], dv[d][1]); b.y = pack_bf2(dv[d][2], dv[d][3]);
       *(uint2*)(dkp + d * 16 + g * 4) = a;
       *(uint2*)(dvp + d * 16 + g * 4) = b;
+    }
+  }
+}
+
+// ---- backward part 2: dQ (Q-outer, forward geometry, no atomics) ---------------------------------
+template <int HD, bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 64];
+  char* Ks = smem;
+  char* Vs = smem + 64 * HD * 2;
+  uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
+  constexpr int KK = HD / 32, DF = HD / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int s = blockIdx.z, h = blockIdx.y;
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int q0 = qt * 64;
+  const int L = p.L;
+  const int qpos = q0 + w * 16 + c;
+  const int qrow = min(qpos, L - 1);
+
+  bf16x8_t qf[KK], dof[KK];
+  {
+    const bf16_t* qp = p.q + ((size_t)s * L + qrow) * p.ld + h * HD;
+    const bf16_t* dp_ = p.dout + ((size_t)s * L + qrow) * p.ldo + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      uint4 a = *(const uint4*)(qp + kk * 32 + g * 8);
+      uint4 b = *(const uint4*)(dp_ + kk * 32 + g * 8);
+      qf[kk] = *(bf16x8_t*)&a;
+      dof[kk] = *(bf16x8_t*)&b;
+    }
+  }
+  const size_t li = ((size_t)s * p.nh + h) * L + qrow;
+  const float lse = p.lse[li], dlt = p.delta[li];
+  f32x4_t dq[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int k0 = kt * 64;
+    stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
+    stage_tile<HD>(Vs, p.v, p.ld, s, L, k0, h, tid);
+    stage_mask(Ms, p.key_mask, s, L, k0, tid);
+    __syncthreads();
+    f32x4_t sc[4], dp[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      sc[kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        // D[i = key][j = q]: lane holds q = c, key = kf*16 + g*4 + r
+        sc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Ks, kf * 16 + c, kk, g), qf[kk], sc[kf], 0, 0, 0);
+        dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Vs, kf * 16 + c, kk, g), dof[kk], dp[kf], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kl = kf * 16 + g * 4 + r;
+        const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos);
+        const float pv = ok ? __expf(sc[kf][r] * p.scale - lse) : 0.f;
+        dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
+      }
+    // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t dsf = pack_frag(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const bf16x8_t kfr = frag_col<HD, TR>(Ks, (2 * ks) * 16 + g * 4, (2 * ks + 1) * 16 + g * 4, d * 16, lane);
+        dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf, dq[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qpos < L) {
+    if (p.dq) {
+      bf16_t* dst = p.dq + ((size_t)s * L + qpos) * p.ld + h * HD;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        uint2 v;
+        v.x = pack_bf2(dq[d][0], dq[d][1]);
+        v.y = pack_bf2(dq[d][2], dq[d][3]);
+        *(uint2*)(dst + d * 16 + g * 4) = v;
+      }
+    }
+    if (p.dq_acc) {   // optional fp32 copy (diagnostics / tests)
+      float* dst = p.dq_acc + ((size_t)s * L + qpos) * (p.nh * HD) + h * HD;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) *(float4*)(dst + d * 16 + g * 4) = make_float4(dq[d][0], dq[d][1], dq[d][2], dq[d][3]);
     }
   }
 }
@@ -358,14 +443,15 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   const int total = a.S * a.L * a.nh;
   const dim3 grid((a.L + 63) / 64, a.nh, a.S);
   const bool tr = opadpo_flag_tr();
+#define LAUNCH_BWD(HD_, TR_)                                                                              \
+  hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((total + 3) / 4), dim3(256), 0, st, a);               \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 0, st, a);                        \
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
   if (a.hd == 128) {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3((total + 3) / 4), dim3(256), 0, st, a);
-    if (tr) hipLaunchKernelGGL((attn_bwd_kernel<128, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_kernel<128, false>), grid, dim3(256), 0, st, a);
+    if (tr) { LAUNCH_BWD(128, true); } else { LAUNCH_BWD(128, false); }
   } else {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((total + 3) / 4), dim3(256), 0, st, a);
-    if (tr) hipLaunchKernelGGL((attn_bwd_kernel<64, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_bwd_kernel<64, false>), grid, dim3(256), 0, st, a);
+    if (tr) { LAUNCH_BWD(64, true); } else { LAUNCH_BWD(64, false); }
   }
+#undef LAUNCH_BWD
   return hipGetLastError();
 }

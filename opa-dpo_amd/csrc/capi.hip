@@ -72,16 +72,16 @@ int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
 
 int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
                     const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
-                    float* dq_acc, uint16_t* dk, uint16_t* dv, float* delta,
+                    uint16_t* dq, uint16_t* dk, uint16_t* dv, float* dq_f32, float* delta,
                     int S_, int L, int nh, int hd, int causal, float scale, void* stream) {
   if (hd != 64 && hd != 128) return bad("opadpo_attn_bwd", "head_dim must be 64 or 128");
-  if (!q || !k || !v || !o || !dout || !lse || !dq_acc || !dk || !dv || !delta || ld % 8 || ldo % 8)
+  if (!q || !k || !v || !o || !dout || !lse || (!dq && !dq_f32) || !dk || !dv || !delta || ld % 8 || ldo % 8)
     return bad("opadpo_attn_bwd", "null operand or misaligned leading dimension");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.o = (uint16_t*)o; a.lse = (float*)lse; a.key_mask = key_mask;
   a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
-  a.dout = dout; a.dq_acc = dq_acc; a.dk = dk; a.dv = dv; a.delta = delta;
+  a.dout = dout; a.dq_acc = dq_f32; a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta;
   return done(launch_attn_bwd(a, S(stream)), "opadpo_attn_bwd");
 }
 

@@ -42,8 +42,8 @@ struct AttnArgs {
   float scale;
   // backward only
   const bf16_t* dout;                                   // ldo addressing
-  float* dq_acc;                                        // fp32 [S*L, nh*hd] accumulation buffer (zeroed by caller)
-  bf16_t* dk; bf16_t* dv;                               // ld addressing (same as k / v)
+  float* dq_acc;                                        // optional fp32 copy of dQ [S*L, nh*hd] (nullable)
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;                   // ld addressing (same as q / k / v)
   float* delta;                                         // [S, nh, L] scratch
 };
 

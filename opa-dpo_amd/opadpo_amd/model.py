@@ -440,7 +440,6 @@ class LlavaEngine:
         d_gu = self.buf("bw_dgu", (M, 2 * F))
         d_attn = self.buf("bw_dattn", (M, H))
         dqkv = self.buf("bw_dqkv", (M, 3 * H))
-        dq_acc = self.buf("bw_dqacc", (M, H), torch.float32)
         delta = self.buf("bw_delta", (S, nh, Lp), torch.float32)
         dt_r = self.buf("bw_dt_r", (M, r))
         dt_2r = self.buf("bw_dt_2r", (M, 2 * r))
@@ -470,14 +469,12 @@ class LlavaEngine:
             L.gemm_tn(d_hb, sv.t_o[i], adapter.g(i, "b_o"))
             L.gemm_tn(dt_r, sv.attn[i], adapter.g(i, "a_o"))
             L.gemm_nt(d_hb, w["wo_t"], d_attn, a2=dt_r, b2=adapter.wt(i, "a_o"))
-            dq_acc.zero_()
             qkv = sv.qkv[i]
             L.call("opadpo_attn_bwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(sv.attn[i]),
-                   L.ptr(d_attn), H, L.ptr(sv.lse[i]), L.ptr(sv.key_mask), L.ptr(dq_acc), dqkv.data_ptr() + 2 * H,
-                   dqkv.data_ptr() + 4 * H, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, st)
+                   L.ptr(d_attn), H, L.ptr(sv.lse[i]), L.ptr(sv.key_mask), L.ptr(dqkv), dqkv.data_ptr() + 2 * H,
+                   dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, st)
             _dbg(f"L{i} d_attn", d_attn); _dbg(f"L{i} attn", sv.attn[i]); _dbg(f"L{i} lse", sv.lse[i]); _dbg(f"L{i} delta", delta)
-            _dbg(f"L{i} dq_acc", dq_acc); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
-            L.call("opadpo_f32_to_bf16_strided", L.ptr(dq_acc), L.ptr(dqkv), M, H, 3 * H, st)
+            _dbg(f"L{i} dq", dqkv[:, :H]); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
             L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, st)
             _dbg(f"L{i} dqkv(after rope)", dqkv)
             bqt = adapter.wt(i, "b_qkv")

@@ -184,14 +184,15 @@ def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
     dqkv = torch.zeros(S * Ln, 3 * H, dtype=BF, device=dev())
     delta = torch.zeros(S, nh, Ln, device=dev())
     L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
-           dout.data_ptr(), H, lse.data_ptr(), L.ptr(km), dq_acc.data_ptr(), dqkv.data_ptr() + 2 * H,
-           dqkv.data_ptr() + 4 * H, delta.data_ptr(), S, Ln, nh, hd, 1, scale, st)
+           dout.data_ptr(), H, lse.data_ptr(), L.ptr(km), dqkv.data_ptr(), dqkv.data_ptr() + 2 * H,
+           dqkv.data_ptr() + 4 * H, dq_acc.data_ptr(), delta.data_ptr(), S, Ln, nh, hd, 1, scale, st)
     torch.cuda.synchronize()
     q4 = qkv[:, :H].float().view(S, Ln, nh, hd).requires_grad_(True)
     k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd).requires_grad_(True)
     v4 = qkv[:, 2 * H:].float().view(S, Ln, nh, hd).requires_grad_(True)
     want = ref_attention(q4, k4, v4, km, 1, scale)
     want.backward(dout.float().view(S, Ln, nh, hd))
+    assert torch.equal(dqkv[:, :H], dq_acc.to(BF))
     for name, got, ref in (("dq", dq_acc, q4.grad.reshape(S * Ln, H)), ("dk", dqkv[:, H:2 * H], k4.grad.reshape(S * Ln, H)),
                            ("dv", dqkv[:, 2 * H:], v4.grad.reshape(S * Ln, H))):
         e = relerr(got, ref)

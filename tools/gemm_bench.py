@@ -33,7 +33,8 @@ def main():
     M = int(os.environ.get("GB_M", 8 * 1087))
     shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
               ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
-    for glds in (1, 0):
+    only = os.environ.get("GB_ONLY", "")
+    for glds in ((1, 0) if not only else ((1,) if only == "gemm" else ())):
         L.set_flags(bool(glds), True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
@@ -49,7 +50,7 @@ def main():
             res.append(dict(kernel="gemm_nt", glds=glds, name=name, M=M, N=N, K=K1 + K2, ms=t * 1e3, tflops=tf))
             print(res[-1], flush=True)
     L.set_flags(True, True)
-    for tr in (1, 0):
+    for tr in ((1, 0) if not only else ((1,) if only == "gemm" else ())):
         L.set_flags(True, bool(tr))
         for name, N1, N2 in (("dB_qkv", 12288, 256), ("dA_qkv", 768, 4096), ("dB_d", 4096, 256), ("dA_d", 256, 11008)):
             p = torch.randn(M, N1, device=dev).to(BF)
@@ -77,8 +78,8 @@ def main():
         delta = torch.empty(S, nh, Ln, device=dev)
         do = torch.randn(S * Ln, H, device=dev).to(BF)
         f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
-                           do.data_ptr(), H, lse.data_ptr(), None, dq.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
-                           delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
+                           do.data_ptr(), H, lse.data_ptr(), None, dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
+                           None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
         t = timeit(f)
         res.append(dict(kernel="attn_bwd", tr=tr, ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
         print(res[-1], flush=True)
