@@ -30,7 +30,43 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-template <bool GLDS>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// epilogue for 4 consecutive output columns of one row
+__device__ __forceinline__ void epilogue4(const GemmNTArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
+  if (p.bias) {
+    const uint2 b = *(const uint2*)(p.bias + n);
+    v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
+    v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
+  }
+  if (p.act) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], p.act);
+  }
+  if (p.R) {
+    if (p.r_f32) {
+      const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    } else {
+      const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+      v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+      v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+    }
+  }
+  if (p.out_f32) {
+    *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 o;
+    o.x = pack_bf2(v[0], v[1]);
+    o.y = pack_bf2(v[2], v[3]);
+    *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+  }
+}
+
+// GLDS: stage through global_load_lds (LDS-DMA) instead of registers.  MF32: 32x32x16 MFMA fragments
+// (2x2 per wave) instead of 16x16x32 (4x4 per wave).
+template <bool GLDS, bool MF32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,90 +128,313 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   };
 
   const int wm = wave >> 1, wn = wave & 1;
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
   stage_issue(0, 0);
   stage_commit(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  if constexpr (!MF32) {
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchk = lane >> 4;
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
+      const char* As = smem + cur * STAGE_BYTES;
+      const char* Bs = As + TILE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8_t af[4], bfr[4];
+        const int c = kk * 4 + fchk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wm * 64 + i * 16 + frow;
+          af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wn * 64 + j * 16 + frow;
+          bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            // operands swapped (B-tile rows as the MFMA "A" side): the lane ends up holding 4
+            // consecutive output columns of one output row -> 8/16-byte stores.
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      if (t + 1 < nt) stage_commit(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    // lane holds C[m][n..n+3], m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        epilogue4(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  } else {
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int frow = lane & 31, fchk = lane >> 5;
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
+      const char* As = smem + cur * STAGE_BYTES;
+      const char* Bs = As + TILE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8_t af[2], bfr[2];
+        const int c = kk * 2 + fchk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = wm * 64 + i * 32 + frow;
+          af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = wn * 64 + j * 32 + frow;
+          bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      if (t + 1 < nt) stage_commit(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    // D[i' = n][j' = m]: lane holds m = m_base + i*32 + (lane&31); n = n_base + j*32 + 8*q + 4*(lane>>5) + (reg&3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          epilogue4(p, m, n0 + wn * 64 + j * 32 + q * 8 + fchk * 4, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
+                    acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt "ring" variant: 128x256 block tile, 4 waves x (128x64), BK = 32, THREE LDS stages fed by
+// LDS-DMA with a COUNTED s_waitcnt vmcnt (loads for K-tiles t+1 and t+2 stay in flight across the
+// single raw s_barrier per K-step; never drained to 0 in the main loop).  72 KiB LDS -> 2 blocks
+// per CU, so each SIMD hosts two waves of DIFFERENT blocks whose barriers are independent (natural
+// stagger: one computes while the other waits).  Per K-step and wave: 12 ds_read_b128 + 6 LDS-DMA
+// pieces feed 32 MFMAs (vs 16 + 8 in the 128x128 kernel).
+// LDS image: 64-byte rows (32 bf16), 16 rows per 1-KiB DMA piece; conflict-free swizzle
+// chunk ^= F((row >> 2) & 3), F = {0,2,3,1}, applied to the DMA source address and the read address.
+// ------------------------------------------------------------------------------------------
+constexpr int R_BM = 128, R_BN = 256, R_BK = 32, R_STAGES = 3;
+constexpr int R_A_BYTES = R_BM * R_BK * 2, R_B_BYTES = R_BN * R_BK * 2, R_ST_BYTES = R_A_BYTES + R_B_BYTES;
+
+__device__ __forceinline__ int swz64(int row) {
+  const int q = (row >> 2) & 3;
+  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_ring_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tiles_m = (p.M + R_BM - 1) / R_BM, tiles_n = p.N / R_BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * R_BM, n0 = tn * R_BN;
+
+  const int nt1 = p.K1 / R_BK, nt2 = p.K2 / R_BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+
+  const int srow = lane >> 2, spos = lane & 3;   // 16 rows x 4 chunks per DMA piece
+
+  auto issue = [&](int stage, int t) {
+    const bf16_t *Ab, *Bb;
+    int lda, ldb, k0;
+    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * R_BK; }
+    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * R_BK; }
+    char* base = smem + stage * R_ST_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {              // A: 8 pieces, 2 per wave
+      const int piece = wave * 2 + i;
+      const int r = piece * 16 + srow;
+      const int c = spos ^ swz64(r);
+      const int gr = min(m0 + r, p.M - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {              // B: 16 pieces, 4 per wave
+      const int piece = wave * 4 + i;
+      const int r = piece * 16 + srow;
+      const int c = spos ^ swz64(r);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8),
+                                       LDS_PTR(void, base + R_A_BYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  if (nt > 1) issue(1, 1);
+
+  const int frow = lane & 15, fchk = lane >> 4;
+  int stage = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) issue(stage == 0 ? 2 : stage - 1, t + 2);   // (stage + 2) % 3
+    const char* As = smem + stage * R_ST_BYTES;
+    const char* Bs = As + R_A_BYTES;
+    bf16x8_t af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 64 + j * 16 + frow;
+      bfr[j] = *(const bf16x8_t*)(Bs + row * 64 + ((fchk ^ swz64(row)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 16 + frow;
+      af[i] = *(const bf16x8_t*)(As + row * 64 + ((fchk ^ swz64(row)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    stage = (stage == 2) ? 0 : stage + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epilogue4(p, m, n0 + wave * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Experimental knobs on the 128x128 kernel (A/B-tested in tools/gemm_bench.py): K-step 64 or 32
+// (32 -> 32 KiB LDS per block -> more co-resident blocks) and s_setprio around the MFMA cluster.
+// ------------------------------------------------------------------------------------------
+template <int BKX, bool PRIO, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = BKX * 2, CPR = BKX / 8, RPP = 1024 / ROWB, PIECES = 128 / RPP, PPW = PIECES / 4;
+  constexpr int TB = 128 * ROWB, SB = 2 * TB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nt1 = p.K1 / BKX, nt2 = p.K2 / BKX, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  const int srow = lane / CPR, spos = lane % CPR;
+  auto fsw = [](int r) { return BKX == 64 ? ((r >> 1) & 7) : swz64(r); };
+
+  auto issue = [&](int buf, int t) {
+    const bf16_t *Ab, *Bb;
+    int lda, ldb, k0;
+    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * BKX; }
+    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * BKX; }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave * PPW + i;
+      const int r = piece * RPP + srow;
+      const int c = spos ^ fsw(r);
+      const int gr = min(m0 + r, p.M - 1);
+      char* dA = smem + buf * SB + piece * 1024;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, dA), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8), LDS_PTR(void, dA + TB), 16, 0, 0);
+    }
+  };
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   const int frow = lane & 15, fchk = lane >> 4;
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
-    const char* As = smem + cur * STAGE_BYTES;
-    const char* Bs = As + TILE_BYTES;
+    if (t + 1 < nt) issue(cur ^ 1, t + 1);
+    const char* As = smem + cur * SB;
+    const char* Bs = As + TB;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BKX / 32; ++kk) {
       bf16x8_t af[4], bfr[4];
       const int c = kk * 4 + fchk;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wm * 64 + i * 16 + frow;
-        af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        af[i] = *(const bf16x8_t*)(As + row * ROWB + ((c ^ fsw(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = wn * 64 + j * 16 + frow;
-        bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        bfr[j] = *(const bf16x8_t*)(Bs + row * ROWB + ((c ^ fsw(row)) << 4));
       }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          // operands swapped (B-tile rows as the MFMA "A" side): the lane ends up holding 4
-          // consecutive output columns of one output row -> 8/16-byte stores.
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
-    if (t + 1 < nt) stage_commit(cur ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
-
-  // epilogue: lane holds C[m][n..n+3], m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + frow;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fchk * 4;
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * p.alpha;
-      if (p.bias) {
-        const uint2 b = *(const uint2*)(p.bias + n);
-        v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
-        v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
-      }
-      if (p.act) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], p.act);
-      }
-      if (p.R) {
-        if (p.r_f32) {
-          const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        } else {
-          const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
-          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-        }
-      }
-      if (p.out_f32) {
-        *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-      }
-    }
+    for (int j = 0; j < 4; ++j)
+      epilogue4(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
   }
 }
 
@@ -183,6 +442,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
 // TN (wgrad) GEMM
 // ------------------------------------------------------------------------------------------
 constexpr int TK = 64;  // rows (m) per LDS stage
+
+// [TK][128] bf16 tiles (256-byte rows) with the 16-byte-chunk swizzle chunk ^= (row & 7) << 1, which is
+// conflict-free for ds_read_b64_tr_b16 (the 32 lanes of a half-wave touch 8 rows x 32 B = all 64 banks).
+__device__ __forceinline__ const char* tn_at(const char* tile, int row, int col) {
+  const int b = col * 2;
+  return tile + row * 256 + ((((b >> 4) ^ ((row & 7) << 1))) << 4) + (b & 15);
+}
+template <bool TR>
+__device__ __forceinline__ bf16x8_t tn_frag(const char* tile, int k0, int c0, int lane) {
+  union { bf16x8_t v; s16x4_t h[2]; uint16_t s[8]; } u;
+  const int g = lane >> 4, c = lane & 15;
+  if constexpr (TR) {
+    const int col = c0 + (c & 3) * 4;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn_at(tile, k0 + g * 8 + (c >> 2), col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn_at(tile, k0 + g * 8 + 4 + (c >> 2), col)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.s[j] = *(const uint16_t*)tn_at(tile, k0 + g * 8 + j, c0 + c);
+  }
+  return u.v;
+}
 
 template <bool TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
@@ -209,29 +489,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int mb = m_begin; mb < m_end; mb += TK) {
-    // stage [TK][128] of P and Q through registers (zero rows past m_end)
+  uint4 pv[4], qv[4];
+  auto fetch = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256;          // 1024 x 16 B per tile
       const int row = idx >> 4, c16 = idx & 15;
       const int m = mb + row;
-      uint4 pv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
+      pv[i] = make_uint4(0, 0, 0, 0);
+      qv[i] = make_uint4(0, 0, 0, 0);
       if (m < m_end) {
-        pv = *(const uint4*)(p.P + (size_t)m * p.ldp + n1_0 + c16 * 8);
-        qv = *(const uint4*)(Q + (size_t)m * p.ldq + n2_0 + c16 * 8);
+        pv[i] = *(const uint4*)(p.P + (size_t)m * p.ldp + n1_0 + c16 * 8);
+        qv[i] = *(const uint4*)(Q + (size_t)m * p.ldq + n2_0 + c16 * 8);
       }
-      *(uint4*)(Ps + row * 256 + c16 * 16) = pv;
-      *(uint4*)(Qs + row * 256 + c16 * 16) = qv;
+    }
+  };
+  fetch(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += TK) {
+    // commit the prefetched rows to LDS (zero rows past m_end), then prefetch the next stage
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 4, c16 = idx & 15;
+      const int off = row * 256 + ((c16 ^ ((row & 7) << 1)) << 4);
+      *(uint4*)(Ps + off) = pv[i];
+      *(uint4*)(Qs + off) = qv[i];
     }
     __syncthreads();
+    if (mb + TK < m_end) fetch(mb + TK);
 #pragma unroll
     for (int kk = 0; kk < TK / 32; ++kk) {
       bf16x8_t pf[4], qf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pf[i] = lds_frag_rows<TR>(Ps, 256, kk * 32, wm * 64 + i * 16, lane);
+      for (int i = 0; i < 4; ++i) pf[i] = tn_frag<TR>(Ps, kk * 32, wm * 64 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) qf[j] = lds_frag_rows<TR>(Qs, 256, kk * 32, wn * 64 + j * 16, lane);
+      for (int j = 0; j < 4; ++j) qf[j] = tn_frag<TR>(Qs, kk * 32, wn * 64 + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -256,10 +548,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 
 }  // namespace
 
-static bool g_use_glds = true;
+static int g_gemm_variant = 1;   // 0: register staging + 16x16x32, 1: LDS-DMA + 16x16x32, 2: LDS-DMA + 32x32x16, 3: 3-stage ring 128x256
 static bool g_use_tr = true;
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
-  g_use_glds = use_glds != 0;
+  g_gemm_variant = use_glds;
   g_use_tr = use_tr != 0;
 }
 bool opadpo_flag_tr() { return g_use_tr; }
@@ -269,15 +561,33 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
   if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
   }
+  if (g_gemm_variant >= 4) {
+    const int tiles_x = ((a.M + BM - 1) / BM) * (a.N / BN);
+    if (g_gemm_variant == 4) hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
+    else if (g_gemm_variant == 5) hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
+    else if (g_gemm_variant == 6) hipLaunchKernelGGL((gemm_nt_kernel_x<32, true, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 4>), dim3(tiles_x), dim3(256), 32768, st, a);
+    return hipGetLastError();
+  }
+  if (g_gemm_variant == 3 && a.N % R_BN == 0) {
+    const int rt = ((a.M + R_BM - 1) / R_BM) * (a.N / R_BN);
+    hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3(rt), dim3(256), R_STAGES * R_ST_BYTES, st, a);
+    return hipGetLastError();
+  }
   const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  if (g_use_glds)
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+  if (g_gemm_variant == 2)
+    hipLaunchKernelGGL((gemm_nt_kernel<true, true>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+  else if (g_gemm_variant == 1)
+    hipLaunchKernelGGL((gemm_nt_kernel<true, false>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
   else
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<false, false>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
   return hipGetLastError();
 }
 

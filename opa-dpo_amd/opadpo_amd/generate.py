@@ -1,0 +1,156 @@
+"""On-policy rollout: prefill + KV-cache sampling decode on the HIP kernels.
+
+Replaces `policy.generate(inputs=queries, images=, attention_mask=, do_sample=True, max_new_tokens=response_len,
+top_p, top_k, temperature, pad_token_id)` + `truncate_after_eos_with_padding(.., eos, pad, [1577, 29973])` of
+opadpo/generator_models/online_generator.py:292-323 (HF generate: temperature -> top-k -> top-p -> multinomial;
+finished rows emit pad; stop when every row hit EOS or max_new_tokens).  Replicas only: prompts are sharded by rank,
+no collective (the reference's synced_gpus flag is only needed for ZeRO-3).
+
+Queries are left-padded (utils/data_utils_online_gpt4v.py:100-107) so every row of a batch has the same length and
+the new token of every row sits at the same position: one RoPE position and one cache slot per step.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib as L
+from .dims import EOS_ID, IMAGE_TOKEN_INDEX, PAD_ID
+from .model import BF, LlavaEngine, LoraAdapter, Saved
+
+
+def truncate_after_eos_with_padding(completions: torch.Tensor, eos_token_id: int, pad_token_id: int,
+                                    additional_tokens: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """generator_models/generator.py:244-273: cut after the first EOS; every additional stop id present in the row
+    overrides the cut position (later list entries win, even when they occur after EOS); the tail becomes pad."""
+    rows = completions.tolist()
+    for r, row in enumerate(rows):
+        end = row.index(eos_token_id) if eos_token_id in row else None
+        for tok in (additional_tokens or ()):
+            if tok in row:
+                end = row.index(tok)
+        if end is not None:
+            rows[r] = row[: end + 1] + [pad_token_id] * (len(row) - end - 1)
+    return torch.tensor(rows, dtype=torch.long, device=completions.device)
+
+
+class Generator:
+    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None):
+        self.engine, self.adapter = engine, adapter
+
+    @torch.no_grad()
+    def generate(self, queries: torch.Tensor, query_attn_masks: torch.Tensor, images: Optional[torch.Tensor] = None, *,
+                 image_feats: Optional[torch.Tensor] = None, max_new_tokens: int, temperature: float = 1.0, top_k: int = 0,
+                 top_p: float = 1.0, seed: int = 0, eos_token_id: int = EOS_ID, pad_token_id: int = PAD_ID,
+                 suppress_eos: bool = False) -> torch.Tensor:
+        """-> responses [B, max_new_tokens] int64 (pad after a row finished)."""
+        eng, d, b = self.engine, self.engine.d, self.engine.base
+        dev = eng.dev
+        st = L.stream()
+        B, Q = queries.shape
+        P, H, F, r, nh, hd, V = d.n_patches, d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim, d.vocab
+        Lp = Q + P - 1
+        max_ctx = Lp + max_new_tokens
+        if image_feats is None:
+            image_feats = eng.encode_images(images)
+        ids = queries.to(dev).to(torch.int32).contiguous()
+        tmask = query_attn_masks.to(dev).to(torch.uint8).contiguous()
+        feat_row = torch.arange(B, device=dev, dtype=torch.int32)
+        e = lambda shape, dtype=BF: torch.empty(*shape, dtype=dtype, device=dev)
+        # ---- prefill: full-sequence kernels, K/V of every layer copied into the cache -----------------------
+        sv = Saved()
+        M = B * Lp
+        sv.x = e((2, M, H), torch.float32)
+        sv.n1, sv.qkv, sv.t_qkv, sv.attn = e((1, M, H)), e((1, M, 3 * H)), e((1, M, 3 * r)), e((1, M, H))
+        sv.lse, sv.t_o, sv.h, sv.n2 = e((1, B, nh, Lp), torch.float32), e((1, M, r)), e((1, M, H), torch.float32), e((1, M, H))
+        sv.t_gu, sv.gu, sv.act, sv.t_d = e((1, M, 2 * r)), e((1, M, 2 * F)), e((1, M, F)), e((1, M, r))
+        sv.rstd1, sv.rstd2 = e((1, M), torch.float32), e((1, M), torch.float32)
+        key_mask = torch.zeros(B, max_ctx, dtype=torch.uint8, device=dev)
+        km_prefill = e((B, Lp), torch.uint8)
+        L.call("opadpo_embed_splice", L.ptr(ids), L.ptr(tmask), L.ptr(b.embed), L.ptr(image_feats.contiguous()), L.ptr(feat_row),
+               None, L.ptr(sv.x[0]), 1, L.ptr(km_prefill), B, Q, P, H, IMAGE_TOKEN_INDEX, st)
+        key_mask[:, :Lp] = km_prefill
+        kc = e((d.n_layers, B, max_ctx, H))
+        vc = e((d.n_layers, B, max_ctx, H))
+
+        def kv_hook(i, qkv):      # cache fill = strided device copy (plumbing)
+            q3 = qkv.view(B, Lp, 3 * H)
+            kc[i, :, :Lp].copy_(q3[:, :, H:2 * H])
+            vc[i, :, :Lp].copy_(q3[:, :, 2 * H:])
+
+        cos, sin = b.rope_tables(max_ctx)
+        for i in range(d.n_layers):
+            eng.layer_fwd(i, self.adapter, sv.x[i & 1], sv.x[(i + 1) & 1], sv, 0, B, Lp, km_prefill, cos, sin, kv_hook)
+        xf = sv.x[d.n_layers & 1]
+        last = (torch.arange(B, device=dev, dtype=torch.int32) * Lp + (Lp - 1)).contiguous()
+        # ---- decode buffers (M = B rows) --------------------------------------------------------------------
+        x = e((B, H), torch.float32)
+        x2 = e((B, H), torch.float32)
+        hs, hn = e((B, H), torch.float32), e((B, H))
+        n1, qkv, t_qkv, att, t_o = e((B, H)), e((B, 3 * H)), e((B, 3 * r)), e((B, H)), e((B, r))
+        hb, n2, t_gu, gu, act, t_d = e((B, H), torch.float32), e((B, H)), e((B, 2 * r)), e((B, 2 * F)), e((B, F)), e((B, r))
+        rstd = e((B,), torch.float32)
+        kv_tmp = e((B, H))
+        emb = e((B, H))
+        logits = e((B, V), torch.float32)
+        nxt = torch.empty(B, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+        out = torch.full((B, max_new_tokens), pad_token_id, dtype=torch.int64, device=dev)
+        rows_b = torch.arange(B, device=dev, dtype=torch.int32)
+        half = hd // 2
+        s = d.lora_scale
+        ad = self.adapter
+
+        def head(src_f32):
+            L.call("opadpo_rmsnorm_fwd", L.ptr(src_f32), 1, L.ptr(b.norm), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, st)
+            L.gemm_nt(hn, b.lm_head, logits)
+            if suppress_eos:
+                logits[:, eos_token_id] = float("-inf")
+            L.call("opadpo_sample", L.ptr(logits), V, B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step),
+                   L.ptr(finished), pad_token_id, L.ptr(nxt), st)
+
+        step = 0
+        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
+        head(hs)
+        for step in range(1, max_new_tokens + 1):
+            out[:, step - 1] = nxt
+            finished |= (nxt == eos_token_id).to(torch.uint8)
+            if step == max_new_tokens or (step % 16 == 0 and bool(finished.all())):
+                break
+            pos = Lp + step - 1                      # cache slot / RoPE position of the token just sampled
+            key_mask[:, pos] = 1
+            L.call("opadpo_gather_rows", L.ptr(b.embed), H, L.ptr(nxt), L.ptr(emb), B, H, st)
+            cur, nx = emb, x
+            slot = (rows_b * max_ctx + pos).contiguous()
+            for i in range(d.n_layers):
+                w = b.layers[i]
+                L.call("opadpo_rmsnorm_fwd", L.ptr(cur), int(cur.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(rstd), B, H, d.rms_eps, st)
+                if ad is not None:
+                    L.gemm_nt(n1, ad.w(i, "a_qkv"), t_qkv, alpha=s)
+                    L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=ad.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
+                else:
+                    L.gemm_nt(n1, w["wqkv"], qkv)
+                L.call("opadpo_rope", L.ptr(qkv), 3 * H, cos.data_ptr() + pos * half * 4, sin.data_ptr() + pos * half * 4, B, 1,
+                       2 * nh, hd, 0, st)
+                for src_off, cache in ((H, kc[i]), (2 * H, vc[i])):
+                    L.call("opadpo_gather_rows", qkv.data_ptr() + 2 * src_off, 3 * H, L.ptr(rows_b), L.ptr(kv_tmp), B, H, st)
+                    L.call("opadpo_scatter_rows", L.ptr(kv_tmp), L.ptr(slot), L.ptr(cache), H, B, H, st)
+                L.call("opadpo_attn_decode", L.ptr(qkv), 3 * H, L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(att), L.ptr(key_mask), B, nh, hd,
+                       pos + 1, max_ctx, hd ** -0.5, st)
+                if ad is not None:
+                    L.gemm_nt(att, ad.w(i, "a_o"), t_o, alpha=s)
+                    L.gemm_nt(att, w["wo"], hb, a2=t_o, b2=ad.w(i, "b_o"), residual=cur)
+                else:
+                    L.gemm_nt(att, w["wo"], hb, residual=cur)
+                eng.mlp_fwd(i, ad, hb, nx, n2, t_gu, gu, act, t_d, rstd, B)
+                cur, nx = nx, (x2 if nx is x else x)
+            head(cur)
+        return out
+
+    def rollout(self, queries, query_attn_masks, images, *, response_len: int, temperature: float = 1.0, top_k: int = 30,
+                top_p: float = 0.95, seed: int = 0, additional_stop_ids: Sequence[int] = (1577, 29973)) -> torch.Tensor:
+        """Online_Generator.rollout's tensor part (online_generator.py:292-323): sample, then cut at EOS / '?'."""
+        resp = self.generate(queries, query_attn_masks, images, max_new_tokens=response_len, temperature=temperature,
+                             top_k=top_k, top_p=top_p, seed=seed)
+        return truncate_after_eos_with_padding(resp, EOS_ID, PAD_ID, list(additional_stop_ids))

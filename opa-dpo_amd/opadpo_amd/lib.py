@@ -85,7 +85,8 @@ def load() -> C.CDLL:
     return lib
 
 
-def set_flags(use_glds: bool = True, use_tr: bool = True) -> None:
+def set_flags(use_glds=True, use_tr: bool = True) -> None:
+    """use_glds: 0 register staging, 1 LDS-DMA + 16x16x32 MFMA, 2 LDS-DMA + 32x32x16 MFMA."""
     load().opadpo_set_flags(int(use_glds), int(use_tr))
 
 

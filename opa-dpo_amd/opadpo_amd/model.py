@@ -353,6 +353,53 @@ class LlavaEngine:
         sv.lse_head = e((R,), torch.float32)
         return sv
 
+    def layer_fwd(self, i: int, adapter: Optional[LoraAdapter], x, xo, sv, k: int, S: int, Lp: int, key_mask, cos, sin,
+                  kv_hook=None) -> None:
+        """One Llama decoder layer over M = S*Lp rows: x (fp32 residual stream) -> xo.  `adapter=None` runs the
+        bare base model (the shipped rollout config has no LoRA: run/online_generate.sh POLICY_LORA_DIR=none).
+        sv.<buf>[k] are the activation buffers; kv_hook(i, qkv) sees the post-RoPE q|k|v (KV-cache fill)."""
+        d, w = self.d, self.base.layers[i]
+        st = L.stream()
+        H, F, r, nh, hd = d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim
+        M = S * Lp
+        s = d.lora_scale
+        n1, qkv, t_qkv, attn, t_o, h, n2, t_gu, gu, act, t_d = (sv.n1[k], sv.qkv[k], sv.t_qkv[k], sv.attn[k], sv.t_o[k],
+                                                                 sv.h[k], sv.n2[k], sv.t_gu[k], sv.gu[k], sv.act[k], sv.t_d[k])
+        L.call("opadpo_rmsnorm_fwd", L.ptr(x), int(x.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
+        if adapter is not None:
+            L.gemm_nt(n1, adapter.w(i, "a_qkv"), t_qkv, alpha=s)
+            L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
+        else:
+            L.gemm_nt(n1, w["wqkv"], qkv)
+        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, st)
+        if kv_hook is not None:
+            kv_hook(i, qkv)
+        L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,
+               L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, 1, hd ** -0.5, st)
+        if adapter is not None:
+            L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
+            L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
+        else:
+            L.gemm_nt(attn, w["wo"], h, residual=x)
+        self.mlp_fwd(i, adapter, h, xo, n2, t_gu, gu, act, t_d, sv.rstd2[k], M)
+
+    def mlp_fwd(self, i: int, adapter: Optional[LoraAdapter], h, xo, n2, t_gu, gu, act, t_d, rstd2, M: int) -> None:
+        d, w = self.d, self.base.layers[i]
+        st = L.stream()
+        H, F, r, s = d.hidden, d.ffn, d.lora_r, d.lora_scale
+        L.call("opadpo_rmsnorm_fwd", L.ptr(h), int(h.dtype == torch.float32), L.ptr(w["ln2"]), L.ptr(n2), L.ptr(rstd2), M, H, d.rms_eps, st)
+        if adapter is not None:
+            L.gemm_nt(n2, adapter.w(i, "a_gu"), t_gu, alpha=s)
+            L.gemm_nt(n2, w["wgu"], gu, a2=t_gu, b2=adapter.w(i, "b_gu"), a2_group_n=F, a2_group_stride=r)
+        else:
+            L.gemm_nt(n2, w["wgu"], gu)
+        L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
+        if adapter is not None:
+            L.gemm_nt(act, adapter.w(i, "a_d"), t_d, alpha=s)
+            L.gemm_nt(act, w["wd"], xo, a2=t_d, b2=adapter.w(i, "b_d"), residual=h)
+        else:
+            L.gemm_nt(act, w["wd"], xo, residual=h)
+
     def seq_logprobs_fwd(self, adapter: LoraAdapter, batch: SeqBatch, feats: torch.Tensor, temperature: float,
                          train: bool):
         """S stacked sequences -> (logp [S,T] fp32, entropy [S,T] fp32, Saved).  Mirrors
@@ -374,26 +421,11 @@ class LlavaEngine:
                L.ptr(batch.feat_row), L.ptr(batch.image_mask), L.ptr(x0), 1, L.ptr(sv.key_mask), S, n_txt, P, H,
                IMAGE_TOKEN_INDEX, st)
         cos, sin = b.rope_tables(Lp)
-        for i, w in enumerate(b.layers):
+        for i in range(d.n_layers):
             k = i if train else 0
             x = sv.x[i if train else (i & 1)]
             xo = sv.x[i + 1 if train else ((i + 1) & 1)]
-            n1, qkv, t_qkv, attn, t_o, h, n2, t_gu, gu, act, t_d = (sv.n1[k], sv.qkv[k], sv.t_qkv[k], sv.attn[k], sv.t_o[k],
-                                                                     sv.h[k], sv.n2[k], sv.t_gu[k], sv.gu[k], sv.act[k], sv.t_d[k])
-            L.call("opadpo_rmsnorm_fwd", L.ptr(x), 1, L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
-            L.gemm_nt(n1, adapter.w(i, "a_qkv"), t_qkv, alpha=s)
-            L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
-            L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, st)
-            L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,
-                   L.ptr(sv.lse[k]), L.ptr(sv.key_mask), S, Lp, nh, hd, 1, hd ** -0.5, st)
-            L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
-            L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
-            L.call("opadpo_rmsnorm_fwd", L.ptr(h), 1, L.ptr(w["ln2"]), L.ptr(n2), L.ptr(sv.rstd2[k]), M, H, d.rms_eps, st)
-            L.gemm_nt(n2, adapter.w(i, "a_gu"), t_gu, alpha=s)
-            L.gemm_nt(n2, w["wgu"], gu, a2=t_gu, b2=adapter.w(i, "b_gu"), a2_group_n=F, a2_group_stride=r)
-            L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
-            L.gemm_nt(act, adapter.w(i, "a_d"), t_d, alpha=s)
-            L.gemm_nt(act, w["wd"], xo, a2=t_d, b2=adapter.w(i, "b_d"), residual=h)
+            self.layer_fwd(i, adapter, x, xo, sv, k, S, Lp, sv.key_mask, cos, sin)
         xf = sv.x[d.n_layers if train else (d.n_layers & 1)]
         # response rows: positions L-T-1 .. L-2 predict tokens L-T .. L-1 (rl_models.py:121-123)
         R = S * T

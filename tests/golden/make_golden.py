@@ -333,3 +333,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- G7: collator (utils/data_utils_dpo.py) with a toy HF-style tokenizer ---------------------------------------
+def make_collator_golden():
+    import json as _json
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, REF)
+    from toy_tokenizer import ToyTokenizer, collator_instances
+    import utils.data_utils_dpo as ref_dd
+    out = {}
+    for detailed in (False, True):
+        coll = ref_dd.DataCollatorForCausalLM(tokenizer=ToyTokenizer(), query_len=24, response_len=40, detailed_report=detailed)
+        batch = coll(collator_instances())
+        for k, v in batch.items():
+            out[f"d{int(detailed)}_{k}"] = v
+    # helper functions on their own
+    out["h_complete"] = np.array(ref_dd.complete_copied_content("a b c. d e f. g", ["a b", "d e f.", ""]))
+    out["h_complete_fail"] = np.array(ref_dd.complete_copied_content("a b c", ["zzz", "a"]))
+    save("ref_collator.npz", **out)
+
+
+if __name__ == "__main__":
+    make_collator_golden()

@@ -151,3 +151,61 @@ def test_lora_flat_layout_roundtrip():
     r, H = d.lora_r, d.hidden
     assert torch.equal(ad.w(1, "a_qkv")[r:2 * r], st["base_model.model.model.layers.1.self_attn.k_proj.lora_A.weight"])
     assert torch.equal(ad.w(0, "b_gu")[d.ffn:], st["base_model.model.model.layers.0.mlp.up_proj.lora_B.weight"])
+
+
+def test_collator_matches_reference(golden_dir):
+    """DataCollatorForCausalLM against the reference's own collator (golden, toy HF-style tokenizer)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from toy_tokenizer import ToyTokenizer, collator_instances
+    from opadpo_amd import data as DT
+    g = load(golden_dir, "ref_collator.npz")
+    for detailed in (False, True):
+        coll = DT.DataCollatorForCausalLM(tokenizer=ToyTokenizer(), query_len=24, response_len=40, detailed_report=detailed)
+        batch = coll(collator_instances())
+        keys = {k[3:] for k in g if k.startswith(f"d{int(detailed)}_")}
+        assert set(batch) == keys, set(batch) ^ keys
+        for k in keys:
+            got = batch[k]
+            got = got.to(torch.uint8).numpy() if got.dtype == torch.bool else got.numpy()
+            np.testing.assert_array_equal(got, g[f"d{int(detailed)}_{k}"], err_msg=f"detailed={detailed} {k}")
+    assert (batch["queries"] == -200).sum() == 2            # one image token per row
+    assert list(DT.complete_copied_content("a b c. d e f. g", ["a b", "d e f.", ""])) == list(g["h_complete"])
+    assert list(DT.complete_copied_content("a b c", ["zzz", "a"])) == list(g["h_complete_fail"])
+    # malformed report -> plain tokenisation with all-zero weights (data_utils_dpo.py:259-278)
+    inst = collator_instances()
+    inst[0]["AI_json_report"] = '{"Sentence 1": {"score": 4}}'
+    b2 = DT.DataCollatorForCausalLM(tokenizer=ToyTokenizer(), query_len=24, response_len=40, detailed_report=True)(inst)
+    assert float(b2["AI_pseudo_response_scores"].abs().sum()) == 0.0
+
+
+def test_dataset_and_image_preprocessing():
+    import base64
+    import io
+    from PIL import Image
+    from opadpo_amd import data as DT
+    img = Image.new("RGB", (50, 30), (200, 10, 10))
+    buf = io.BytesIO()
+    img.save(buf, format="PNG")
+    rows = [{"queries": "<image>\nWhat is this?", "image_bytes": base64.b64encode(buf.getvalue()).decode(), "standard_response": "s",
+             "original_generate_response": "o", "AI_pseudo_response": "a", "AI_json_report": "{}"}]
+    item = DT.DPODataset(rows, image_size=28)[0]
+    assert item["images"].shape == (3, 28, 28)
+    assert item["queries"].startswith("<s> A chat between a curious user") and "图 \nWhat is this? ASSISTANT: " in item["queries"]
+    px = item["images"]
+    # centre = the red image, top/bottom bands = CLIP-mean padding (normalises to ~0)
+    assert abs(float(px[:, 0, 14].abs().max())) < 0.05 and float(px[0, 14, 14]) > 1.0
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor(size={"shortest_edge": 28}, crop_size={"height": 28, "width": 28})
+    sq = Image.new("RGB", (50, 50), tuple(int(x * 255) for x in DT.CLIP_MEAN))
+    sq.paste(img, (0, 10))
+    want = torch.from_numpy(proc.preprocess(sq, return_tensors="np")["pixel_values"][0])
+    assert float((px - want).abs().max()) < 2e-2
+
+
+def test_truncate_and_generate_helpers(golden_dir):
+    from opadpo_amd.generate import truncate_after_eos_with_padding
+    g = load(golden_dir, "ref_truncate.npz")
+    comp = t(g["completions"])
+    np.testing.assert_array_equal(truncate_after_eos_with_padding(comp, 2, 0).numpy(), g["plain"])
+    np.testing.assert_array_equal(truncate_after_eos_with_padding(comp, 2, 0, [1577, 29973]).numpy(), g["with_stops"])

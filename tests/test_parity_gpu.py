@@ -240,3 +240,36 @@ def test_trainer_step_against_oracle(setup):
     REPORT["grad_norm_post_clip"] = tr.optimizer.grad_norm_post_clip()
     assert cos > 0.9, cos    # first Adam step is sign-like: near-zero gradient entries may flip
     assert abs(tr.optimizer.grad_norm_post_clip() - min(1.0, float(flat_g.norm()))) < 5e-2
+
+
+def test_generation_kv_cache_against_oracle(setup):
+    """Prefill + KV-cache decode (greedy: top_k = 1) against the oracle re-running the full model every step."""
+    s = setup
+    LR = s["LR"]
+    from opadpo_amd.generate import Generator
+    from oracle import dpo_ref as D
+    B, Q, N = 2, 12, 6
+    images, queries, qmask, _ = make_inputs(s["d"], B, Q, 9, seed=33)
+    for adapter, lora in ((s["ref"], s["lora_ref"]), (None, {k: v for k, v in s["lora_ref"].items() if "vision_tower" in k or "mm_projector" in k})):
+        gen = Generator(s["eng"], adapter)
+        out = gen.generate(queries, qmask, images.to(s["dev"]), max_new_tokens=N, temperature=1.0, top_k=1, top_p=1.0, seed=1)
+        torch.cuda.synchronize()
+        out = out.cpu()
+        feats = LR.image_features(images, s["W"], lora, s["od"])
+        ids, mask = queries.clone(), qmask.clone()
+        done = torch.zeros(B, dtype=torch.bool)
+        for step in range(N):
+            logits = LR.llava_logits(ids, mask, None, s["W"], lora, s["od"], feats=feats)[:, -1]
+            top2 = logits.topk(2, dim=-1)
+            for b in range(B):
+                if done[b]:
+                    assert int(out[b, step]) == 0          # finished rows emit pad
+                    continue
+                if int(out[b, step]) != int(top2.indices[b, 0]):
+                    gap = float(top2.values[b, 0] - top2.values[b, 1])
+                    assert int(out[b, step]) == int(top2.indices[b, 1]) and gap < 2e-2, (step, b, gap)
+            nxt = out[:, step].clone()
+            done |= nxt == 2
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.bool)], 1)
+    REPORT["generation_checked_steps"] = N

@@ -34,8 +34,21 @@ def main():
     shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
               ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
     only = os.environ.get("GB_ONLY", "")
-    for glds in ((1, 0) if not only else ((1,) if only == "gemm" else ())):
-        L.set_flags(bool(glds), True)
+    if only == "pmc":      # few launches of the two big shapes, default variant only (PMC passes serialize kernels)
+        L.set_flags(int(os.environ.get("GB_VARIANT", 1)), True)
+        for name, N, K1, K2, grp in shapes[:2]:
+            a1 = torch.randn(M, K1, device=dev).to(BF)
+            b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            G = N // grp if grp else 1
+            kw = dict(a2=torch.randn(M, G * K2, device=dev).to(BF), b2=(torch.randn(N, K2, device=dev) * 0.02).to(BF),
+                      a2_group_n=grp, a2_group_stride=K2 if grp else 0)
+            for _ in range(3):
+                L.gemm_nt(a1, b1, out, **kw)
+        torch.cuda.synchronize()
+        return
+    for glds in ((3, 2, 1, 0) if not only else ((4, 5, 6, 7, 1) if only == "gemm" else ())):
+        L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
             b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
