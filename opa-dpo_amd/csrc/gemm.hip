@@ -439,6 +439,198 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_nt "ping-pong" kernel: 256x256 block tile, 8 waves (2 x 4, each 128x64), BK = 64, two 64-KiB
+// LDS stages (128 KiB, one block per CU).  The two wave groups G0 = waves 0-3 and G1 = waves 4-7
+// (wave w and w+4 share a SIMD) run the SAME per-K-tile program
+//        LOAD(t): 24 ds_read_b128 (all A/B fragments of K-tile t)    |  MFMA(t): 64 MFMAs from registers
+// offset by one phase, separated by raw s_barriers: while one group streams fragments out of LDS the
+// other keeps the SIMD's matrix pipe busy (s_setprio 1).  LDS-DMA for tile t+1 is issued two phases
+// before its first reader and waited for with s_waitcnt vmcnt(0) one phase later, so it is in flight
+// across a barrier; nothing waits for a load it just issued.
+//   phase 2t   : G0 issue(t+1), LOAD(t)   | G1 issue(t+1), MFMA(t-1)
+//   phase 2t+1 : G0 MFMA(t), vmcnt(0)     | G1 LOAD(t), vmcnt(0)
+// ------------------------------------------------------------------------------------------
+constexpr int P_BM = 256, P_BN = 256, P_BK = 64;
+constexpr int P_TILE = P_BM * P_BK * 2;          // 32 KiB per operand tile
+constexpr int P_STAGE = 2 * P_TILE;              // A + B
+
+template <bool MF32>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * P_BM, n0 = tn * P_BN;
+
+  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  auto issue = [&](int t) {
+    const bf16_t *Ab, *Bb;
+    int lda, ldb, k0;
+    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * P_BK; }
+    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * P_BK; }
+    char* base = smem + (t & 1) * P_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                // 32 pieces (8 rows x 128 B) per operand, 4 per wave
+      const int piece = wave * 4 + i;
+      const int r = piece * 8 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const int gr = min(m0 + r, p.M - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8),
+                                       LDS_PTR(void, base + P_TILE + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  // 16x16x32 path: acc16[8][4] (f32x4), fragments af[2][8], bfr[2][4] of K=32 each;
+  // 32x32x16 path: acc32[4][2] (f32x16), fragments af[4][4], bfr[4][2] of K=16 each.  Same register budget.
+  f32x4_t acc16[MF32 ? 1 : 8][MF32 ? 1 : 4];
+  f32x16_t acc32[MF32 ? 4 : 1][MF32 ? 2 : 1];
+  bf16x8_t af[MF32 ? 4 : 2][MF32 ? 4 : 8], bfr[MF32 ? 4 : 2][MF32 ? 2 : 4];
+  if constexpr (MF32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc32[i][j][q] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const int frow = MF32 ? (lane & 31) : (lane & 15), fchk = MF32 ? (lane >> 5) : (lane >> 4);
+
+  auto load_frags = [&](int t) {
+    const char* As = smem + (t & 1) * P_STAGE;
+    const char* Bs = As + P_TILE;
+    if constexpr (MF32) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int c = kk * 2 + fchk;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = wc * 64 + j * 32 + frow;
+          bfr[kk][j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 128 + i * 32 + frow;
+          af[kk][i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int c = kk * 4 + fchk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = wc * 64 + j * 16 + frow;
+          bfr[kk][j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = wr * 128 + i * 16 + frow;
+          af[kk][i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+    }
+  };
+  auto mfma_all = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (MF32) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc32[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc16[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define PP_BARRIER()                               \
+  do {                                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    __builtin_amdgcn_s_barrier();                  \
+    __builtin_amdgcn_sched_barrier(0);             \
+  } while (0)
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER();
+
+  if (wr == 0) {
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) issue(t + 1);
+      load_frags(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      mfma_all();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+    }
+    PP_BARRIER();
+  } else {
+    if (nt > 1) issue(1);
+    PP_BARRIER();
+    for (int t = 0; t < nt; ++t) {
+      load_frags(t);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      if (t + 2 < nt) issue(t + 2);
+      mfma_all();
+      PP_BARRIER();
+    }
+  }
+#undef PP_BARRIER
+  if constexpr (MF32) {
+    // D[i' = n][j' = m]: lane holds m = .. + (lane&31); n = .. + 8*q + 4*(lane>>5) + (reg&3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 128 + i * 32 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          epilogue4(p, m, n0 + wc * 64 + j * 32 + q * 8 + fchk * 4, acc32[i][j][q * 4 + 0], acc32[i][j][q * 4 + 1],
+                    acc32[i][j][q * 4 + 2], acc32[i][j][q * 4 + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        epilogue4(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN (wgrad) GEMM
 // ------------------------------------------------------------------------------------------
 constexpr int TK = 64;  // rows (m) per LDS stage
@@ -548,7 +740,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 
 }  // namespace
 
-static int g_gemm_variant = 1;   // 0: register staging + 16x16x32, 1: LDS-DMA + 16x16x32, 2: LDS-DMA + 32x32x16, 3: 3-stage ring 128x256
+static int g_gemm_variant = 10;   // 0: register staging, 1: LDS-DMA 16x16x32, 2: LDS-DMA 32x32x16, 3: 3-stage ring 128x256, 4: LDS-DMA 16x16x32 + setprio, <=128 VGPR; 5-7: BK=32 experiments; 8/9: 256x256 ping-pong (16x16x32 / 32x32x16); 10 (default): auto 8|4
 static bool g_use_tr = true;
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
@@ -565,15 +757,28 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
+  }
+  // variant 10 (default, "auto"): the 256x256 ping-pong kernel when it yields at least ~1.5 rounds of blocks on the
+  // 256 CUs, the 128x128 kernel otherwise (skinny LoRA GEMMs, N not a multiple of 256).
+  const int pp_tiles = (a.N % P_BN == 0) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
+  const bool auto_pp = g_gemm_variant == 10 && pp_tiles >= 384;
+  if ((g_gemm_variant == 8 || g_gemm_variant == 9 || auto_pp) && a.N % P_BN == 0) {
+    const int pt = pp_tiles;
+    if (g_gemm_variant != 9) hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
+    else hipLaunchKernelGGL(gemm_nt_pp_kernel<true>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
+    return hipGetLastError();
   }
   if (g_gemm_variant >= 4) {
     const int tiles_x = ((a.M + BM - 1) / BM) * (a.N / BN);
     if (g_gemm_variant == 4) hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
     else if (g_gemm_variant == 5) hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
     else if (g_gemm_variant == 6) hipLaunchKernelGGL((gemm_nt_kernel_x<32, true, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 4>), dim3(tiles_x), dim3(256), 32768, st, a);
+    else if (g_gemm_variant == 7) hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 4>), dim3(tiles_x), dim3(256), 32768, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
     return hipGetLastError();
   }
   if (g_gemm_variant == 3 && a.N % R_BN == 0) {

@@ -81,13 +81,16 @@ def load() -> C.CDLL:
     g = os.environ.get("OPADPO_USE_GLDS")
     t = os.environ.get("OPADPO_USE_TR")
     if g is not None or t is not None:
-        lib.opadpo_set_flags(int(g or 1), int(t or 1))
+        lib.opadpo_set_flags(int(g or 10), int(t or 1))
     return lib
 
 
-def set_flags(use_glds=True, use_tr: bool = True) -> None:
-    """use_glds: 0 register staging, 1 LDS-DMA + 16x16x32 MFMA, 2 LDS-DMA + 32x32x16 MFMA."""
-    load().opadpo_set_flags(int(use_glds), int(use_tr))
+def set_flags(use_glds=10, use_tr: bool = True) -> None:
+    """gemm_nt variant: 0 register staging, 1 LDS-DMA + 16x16x32 MFMA, 2 LDS-DMA + 32x32x16, 3 three-stage ring
+    128x256, 4 LDS-DMA + 16x16x32 + s_setprio at <=128 VGPRs, 5-7 BK=32 experiments, 8/9 256x256 ping-pong,
+    10 (default) auto: ping-pong for large GEMMs, variant 4 otherwise.  True -> default."""
+    v = 10 if use_glds is True else int(use_glds)
+    load().opadpo_set_flags(v, int(use_tr))
 
 
 def ptr(t: Optional[torch.Tensor]):

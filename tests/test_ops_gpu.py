@@ -41,10 +41,10 @@ def maxabs(got, want):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("glds", [7, 6, 5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize("glds", [10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize("M,N,K1,K2,groups", [(300, 256, 128, 0, 0), (1, 128, 64, 0, 0), (129, 384, 192, 128, 3),
                                               (1000, 1024, 512, 128, 2), (257, 128, 64, 64, 1), (515, 768, 64, 64, 3),
-                                              (2, 256, 4096, 0, 0), (131, 512, 64 * 3, 64, 2)])
+                                              (2, 256, 4096, 0, 0), (131, 512, 64 * 3, 64, 2), (700, 512, 64, 0, 0), (513, 256, 128, 128, 1)])
 def test_gemm_nt(L, glds, M, N, K1, K2, groups):
     L.set_flags(glds, True)
     a1 = rnd(M, K1, seed=1)
@@ -69,7 +69,7 @@ def test_gemm_nt(L, glds, M, N, K1, K2, groups):
     assert e < 6e-3, f"gemm_nt rel err {e}"   # bf16 output rounding ~ 2^-9
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):
     L.set_flags(variant, True)

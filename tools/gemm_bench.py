@@ -47,7 +47,7 @@ def main():
                 L.gemm_nt(a1, b1, out, **kw)
         torch.cuda.synchronize()
         return
-    for glds in ((3, 2, 1, 0) if not only else ((4, 5, 6, 7, 1) if only == "gemm" else ())):
+    for glds in ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ())):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
@@ -61,6 +61,13 @@ def main():
             t = timeit(lambda: L.gemm_nt(a1, b1, out, **kw))
             tf = 2.0 * M * N * (K1 + K2) / t / 1e12
             res.append(dict(kernel="gemm_nt", glds=glds, name=name, M=M, N=N, K=K1 + K2, ms=t * 1e3, tflops=tf))
+            print(res[-1], flush=True)
+    if only in ("", "yard"):      # diagnostic yardstick only (never used by the product): vendor GEMM at the same shapes
+        for name, N, K1, K2, grp in shapes:
+            a1 = torch.randn(M, K1 + K2, device=dev).to(BF)
+            b1 = (torch.randn(N, K1 + K2, device=dev) * 0.02).to(BF)
+            t = timeit(lambda: torch.matmul(a1, b1.t()))
+            res.append(dict(kernel="torch.matmul(hipBLASLt)", name=name, M=M, N=N, K=K1 + K2, ms=t * 1e3, tflops=2.0 * M * N * (K1 + K2) / t / 1e12))
             print(res[-1], flush=True)
     L.set_flags(True, True)
     for tr in ((1, 0) if not only else ((1,) if only == "gemm" else ())):
