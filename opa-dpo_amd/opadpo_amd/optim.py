@@ -63,8 +63,11 @@ class FlatAdamW:
         self.sumsq_fn, self.adamw_fn = sumsq_fn, adamw_fn
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # OPADPO_FORCE_COLLECTIVES=1 (diagnostics): run the exchange code path even in a 1-rank group
+        self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                                and __import__("os").environ.get("OPADPO_FORCE_COLLECTIVES") == "1")
         n = master.numel()
-        if mode == "zero1" and self.world > 1:
+        if mode == "zero1" and self._collective:
             self.lo, self.hi, self.per = shard_bounds(n, self.world, self.rank)
         else:
             self.lo, self.hi, self.per = 0, n, n
@@ -74,7 +77,7 @@ class FlatAdamW:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=master.device)
         self.step_count = 0
         self.last_grad_norm = None     # lazily materialised POST-clip norm (Quirk Q15)
-        if mode == "zero1" and self.world > 1:
+        if mode == "zero1" and self._collective:
             pad_n = self.per * self.world
             self._gpad = torch.zeros(pad_n, dtype=torch.float32, device=master.device)
             self._gshard = torch.zeros(self.per, dtype=torch.float32, device=master.device)
@@ -83,7 +86,7 @@ class FlatAdamW:
     # ---- gradient exchange --------------------------------------------------------------------------
     def _exchange(self) -> torch.Tensor:
         """Returns the (summed over ranks) gradient slice this rank updates."""
-        if self.world == 1:
+        if not self._collective:
             return self.grad
         if self.mode == "allreduce":
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
@@ -106,7 +109,7 @@ class FlatAdamW:
         self.sumsq.zero_()
         if self.max_grad_norm is not None:
             self.sumsq_fn(g, self.sumsq)
-            if self.world > 1 and self.mode == "zero1":
+            if self._collective and self.mode == "zero1":
                 dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
         p = self.master[self.lo:self.hi]
         wk = self.work[self.lo:self.hi]
@@ -115,7 +118,7 @@ class FlatAdamW:
                       sumsq=self.sumsq if self.max_grad_norm is not None else None,
                       max_norm=self.max_grad_norm, grad_div=grad_div)
         self._grad_div = grad_div
-        if self.world > 1 and self.mode == "zero1":
+        if self._collective and self.mode == "zero1":
             n = self.work.numel()
             self._wpad[self.lo:self.hi].copy_(wk)
             shard = self._wpad[self.rank * self.per:(self.rank + 1) * self.per]
