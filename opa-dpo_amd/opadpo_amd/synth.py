@@ -104,3 +104,22 @@ def synth_pairs(d: LlavaDims, n_pairs: int, q_len: int, t_len: int, seed: int = 
 
     out = dict(images=pixels, queries=queries, queries_attn_masks=qmask, chosen=resp(), rejected=resp())
     return {k: v.to(device) for k, v in out.items()}
+
+
+def synth_rollout_batches(d: LlavaDims, args, seed: int = 0):
+    """Endless stream of collated batches with the keys DataCollatorForCausalLM produces (detailed_report=True)."""
+    step = 0
+    B, Q, T = args.rollout_per_device_batch_size, args.query_len, args.response_len
+    while True:
+        p = synth_pairs(d, B, Q, T, seed=seed * 100003 + step)
+        g = torch.Generator().manual_seed(seed * 7 + step)
+        third = synth_pairs(d, B, Q, T, seed=seed * 100003 + step + 50021)["chosen"]
+        batch = {"images": p["images"].float(), "queries": p["queries"], "queries_attention_mask": p["queries_attn_masks"],
+                 "standard_response": p["chosen"], "original_generate_response": p["rejected"], "AI_pseudo_response": third}
+        choices = torch.tensor([1.0, 1.5, 2.0, 2.5])
+        for k in ("original_generate_response", "AI_pseudo_response"):
+            m = batch[k] != 0
+            batch[k + "_scores"] = choices[torch.randint(0, 4, (B, T), generator=g)] * m
+            batch[k + "_image_relations"] = torch.tensor([1.0, 3.0])[torch.randint(0, 2, (B, T), generator=g)] * m
+        yield batch
+        step += 1

@@ -209,3 +209,59 @@ def test_truncate_and_generate_helpers(golden_dir):
     comp = t(g["completions"])
     np.testing.assert_array_equal(truncate_after_eos_with_padding(comp, 2, 0).numpy(), g["plain"])
     np.testing.assert_array_equal(truncate_after_eos_with_padding(comp, 2, 0, [1577, 29973]).numpy(), g["with_stops"])
+
+
+def test_cli_surface_and_quirks(tmp_path, monkeypatch):
+    from opadpo_amd import cli
+    p = cli.make_parser()
+    ns = p.parse_args([])
+    # Quirk Q8: store_false flags default to True
+    for f in ("bf16", "tf32", "use_flash_attention", "resume_from_training", "do_train", "clean_tokens_after_eos"):
+        assert getattr(ns, f) is True
+    assert p.parse_args(["--bf16"]).bf16 is False
+    # the shipped script's batch arithmetic at 4 GPUs (opadpo_train.py:383-433)
+    ns = p.parse_args("--rollout_batch_size 64 --step_batch_size 32 --rollout_per_device_batch_size 2 "
+                      "--step_per_device_batch_size 2 --CoPO False --AncPO True".split())
+    a = cli.build_args(ns, world_size=4)
+    assert (a.rollout_accumulation_steps, a.gradient_accumulation_steps) == (8, 4)
+    assert a.CoPO is False and a.AncPO is False          # Quirk Q5: AncPO follows --CoPO
+    with pytest.raises(ValueError):
+        cli.build_args(p.parse_args(["--rollout_batch_size", "30"]), world_size=4)
+    # PPO-era flags are accepted and ignored (Quirk Q9)
+    p.parse_args("--kl_coef 0.2 --cliprange 0.1 --gamma 0.9 --lam 0.9 --mm_vision_select_layer -1 --value_head_mode linear".split())
+    # YAML fills only what the command line left alone
+    y = tmp_path / "c.yaml"
+    y.write_text("training:\n  response_len: 896\n  beta: 0.3\n")
+    argv = ["--cfg", str(y), "--beta", "0.1"]
+    ns = p.parse_args(argv)
+    cli.load_yaml_defaults(ns, argv)
+    assert ns.response_len == 896 and ns.beta == 0.1
+
+
+def test_checkpoint_io_roundtrip(tmp_path):
+    from opadpo_amd import checkpoint_io as CK
+    from opadpo_amd.synth import init_lora, init_weights
+    d = DM.LlavaDims.tiny()
+    W = init_weights(d, seed=0)
+    llm = {k: v for k, v in W.items() if "vision_tower" not in k}
+    vis = {"vision_model." + k[len(DM.VIS_PREFIX):]: v for k, v in W.items() if k.startswith(DM.VIS_PREFIX)}
+    base, clip = tmp_path / "llava", tmp_path / "clip"
+    base.mkdir(); clip.mkdir()
+    keys = sorted(llm)
+    half = len(keys) // 2
+    torch.save({k: llm[k] for k in keys[:half]}, base / "pytorch_model-00001-of-00002.bin")
+    torch.save({k: llm[k] for k in keys[half:]}, base / "pytorch_model-00002-of-00002.bin")
+    wm = {k: ("pytorch_model-00001-of-00002.bin" if i < half else "pytorch_model-00002-of-00002.bin") for i, k in enumerate(keys)}
+    (base / "pytorch_model.bin.index.json").write_text(json.dumps({"weight_map": wm}))
+    (base / "config.json").write_text(json.dumps({"hidden_size": d.hidden, "num_hidden_layers": d.n_layers, "num_attention_heads": d.n_heads,
+                                                   "intermediate_size": d.ffn, "vocab_size": d.vocab, "image_checkpoint": str(clip)}))
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in vis.items()}, str(clip / "model.safetensors"))
+    state = CK.load_llava_state(str(base))
+    assert set(state) == set(W) and all(torch.equal(state[k], W[k]) for k in W)
+    dd = CK.dims_from_config(str(base), lora_r=d.lora_r, lora_alpha=d.lora_alpha)
+    assert (dd.hidden, dd.n_layers, dd.n_heads, dd.head_dim, dd.ffn, dd.vocab) == (d.hidden, d.n_layers, d.n_heads, d.head_dim, d.ffn, d.vocab)
+    ad = init_lora(d, seed=1)
+    torch.save(ad, tmp_path / "adapter_model.bin")
+    back = CK.load_adapter(str(tmp_path))
+    assert set(back) == set(ad)
