@@ -476,22 +476,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
   const int srow = lane >> 3, spos = lane & 7;
 
-  auto issue = [&](int t) {
-    const bf16_t *Ab, *Bb;
-    int lda, ldb, k0;
-    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * P_BK; }
-    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * P_BK; }
+  // one 1-KiB LDS-DMA piece (8 rows x 128 B) of K-tile t: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave
+  auto issue_piece = [&](int t, int q) {
+    const bool second = t >= nt1;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
     char* base = smem + (t & 1) * P_STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                // 32 pieces (8 rows x 128 B) per operand, 4 per wave
-      const int piece = wave * 4 + i;
-      const int r = piece * 8 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
+    const int piece = wave * 4 + (q & 3);
+    const int r = piece * 8 + srow;
+    const int c = spos ^ ((r >> 1) & 7);
+    if (q < 4) {
+      const bf16_t* Ab = second ? a2 : p.A1;
+      const int lda = second ? p.lda2 : p.lda1;
       const int gr = min(m0 + r, p.M - 1);
       __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+    } else {
+      const bf16_t* Bb = second ? p.B2 : p.B1;
+      const int ldb = second ? p.ldb2 : p.ldb1;
       __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8),
                                        LDS_PTR(void, base + P_TILE + piece * 1024), 16, 0, 0);
     }
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue_piece(t, q);
   };
 
   // 16x16x32 path: acc16[8][4] (f32x4), fragments af[2][8], bfr[2][4] of K=32 each;
@@ -549,24 +556,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
       }
     }
   };
-  auto mfma_all = [&]() {
+  // 64 (32) MFMAs in 8 groups; when t_issue >= 0 one LDS-DMA piece of K-tile t_issue is issued after each group so
+  // that the (expensive) global_load_lds issue slots overlap with MFMAs already in the matrix pipe.
+  auto mfma_all = [&](int t_issue) {
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (MF32) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+    for (int g8 = 0; g8 < 8; ++g8) {
+      if constexpr (MF32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 4; ++e) {
+          const int idx = g8 * 4 + e, kk = idx >> 3, i = (idx & 7) >> 1, j = idx & 1;
+          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc32[i][j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc32[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc16[i][j], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+          const int idx = g8 * 8 + e, kk = idx >> 5, i = (idx & 31) >> 2, j = idx & 3;
+          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc16[i][j], 0, 0, 0);
+        }
+      }
+      if (t_issue >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(t_issue, g8);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
       load_frags(t);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BARRIER();
-      mfma_all();
+      mfma_all(-1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PP_BARRIER();
     }
@@ -599,8 +612,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
       load_frags(t);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       PP_BARRIER();
-      if (t + 2 < nt) issue(t + 2);
-      mfma_all();
+      mfma_all(t + 2 < nt ? t + 2 : -1);
       PP_BARRIER();
     }
   }
