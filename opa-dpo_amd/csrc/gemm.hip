@@ -476,24 +476,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
   const int srow = lane >> 3, spos = lane & 7;
 
-  // one 1-KiB LDS-DMA piece (8 rows x 128 B) of K-tile t: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave
+  // one 1-KiB LDS-DMA piece (8 rows x 128 B) of K-tile t: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave.
+  // buffer_load ... lds through wave-uniform buffer descriptors: per issue ONE 32-bit VALU op (row * ld + swizzled
+  // chunk) — the tile / piece / K offsets ride in the scalar soffset; rows >= M fall outside the A descriptor's range
+  // (hardware range check, no clamp needed: those rows are never stored).
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? a2 : p.A1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const unsigned lrow = (unsigned)(wave * 32 + srow);                    // row of piece 0 inside the 256-row tile
+  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16),    // swizzled 16-B chunk, even / odd pieces
+                           (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  const unsigned m_last = (unsigned)(p.M - 1);
   auto issue_piece = [&](int t, int q) {
     const bool second = t >= nt1;
     const int k0 = (second ? (t - nt1) : t) * P_BK;
     char* base = smem + (t & 1) * P_STAGE;
-    const int piece = wave * 4 + (q & 3);
-    const int r = piece * 8 + srow;
-    const int c = spos ^ ((r >> 1) & 7);
+    const int pi = q & 3;
+    const int piece = wave * 4 + pi;
     if (q < 4) {
-      const bf16_t* Ab = second ? a2 : p.A1;
-      const int lda = second ? p.lda2 : p.lda1;
-      const int gr = min(m0 + r, p.M - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
+      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
+      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
+      const unsigned voff = row * ld2 + csw[pi & 1];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff, k0 * 2, 0, 0);
     } else {
-      const bf16_t* Bb = second ? p.B2 : p.B1;
-      const int ldb = second ? p.ldb2 : p.ldb1;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8),
-                                       LDS_PTR(void, base + P_TILE + piece * 1024), 16, 0, 0);
+      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+      const unsigned voff = lrow * ld2 + csw[pi & 1];
+      const unsigned soff = ((unsigned)n0 + pi * 8u) * ld2 + k0 * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff, soff, 0, 0);
     }
   };
   auto issue = [&](int t) {
@@ -776,9 +786,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
   }
   // variant 10 (default, "auto"): the 256x256 ping-pong kernel when it yields at least ~1.5 rounds of blocks on the
   // 256 CUs, the 128x128 kernel otherwise (skinny LoRA GEMMs, N not a multiple of 256).
-  const int pp_tiles = (a.N % P_BN == 0) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
+  const bool off32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
+                     (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
+  const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
   const bool auto_pp = g_gemm_variant == 10 && pp_tiles >= 384;
-  if ((g_gemm_variant == 8 || g_gemm_variant == 9 || auto_pp) && a.N % P_BN == 0) {
+  if ((g_gemm_variant == 8 || g_gemm_variant == 9 || auto_pp) && pp_tiles > 0) {
     const int pt = pp_tiles;
     if (g_gemm_variant != 9) hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
     else hipLaunchKernelGGL(gemm_nt_pp_kernel<true>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
