@@ -40,12 +40,13 @@ void opadpo_set_flags(int use_glds, int use_tr);
  * replaces nn.Linear + peft.tuners.lora.Linear.forward (y = xW^T + (alpha/r)(xA^T)B^T) reached
  * from rl_models.py:120, and their dgrad in backward (rl_trainer.py:162).
  * A2's column offset for output column n0 is (n0 / a2_group_n) * a2_group_stride (fused q|k|v and
- * gate|up projections); pass a2_group_n = 0 for a single group.  N % 128 == 0, K1 % 64 == 0,
+ * gate|up projections); pass a2_group_n = 0 for a single group.  A1 can be grouped the same way
+ * (a1_group_n / a1_group_stride: block-diagonal dT = dY_g . B_g of the fused projections in one launch).  N % 128 == 0, K1 % 64 == 0,
  * K2 % 64 == 0; M arbitrary.  out_f32: C is float32 instead of bf16; res_f32: R is float32 (the LLM
  * residual stream is kept in fp32 so bf16 rounding does not accumulate over 2*n_layers additions). */
 int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
                    const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
-                   int a2_group_n, int a2_group_stride,
+                   int a2_group_n, int a2_group_stride, int a1_group_n, int a1_group_stride,
                    void* C, int ldc, int out_f32, const void* R, int ldr, int res_f32, const uint16_t* bias,
                    int M, int N, float alpha, int act, void* stream);
 

@@ -28,7 +28,7 @@ void opadpo_set_flags(int use_glds, int use_tr) { opadpo_set_flags_impl(use_glds
 
 int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
                    const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2,
-                   int a2_group_n, int a2_group_stride,
+                   int a2_group_n, int a2_group_stride, int a1_group_n, int a1_group_stride,
                    void* C, int ldc, int out_f32, const void* R, int ldr, int res_f32, const uint16_t* bias,
                    int M, int N, float alpha, int act, void* stream) {
   if (M < 0 || N <= 0 || N % 128) return bad("opadpo_gemm_nt", "N must be a positive multiple of 128");
@@ -36,12 +36,14 @@ int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, i
   if ((K1 && (!A1 || !B1)) || (K2 && (!A2 || !B2)) || !C) return bad("opadpo_gemm_nt", "null operand");
   if (lda1 % 8 || ldb1 % 8 || (K2 && (lda2 % 8 || ldb2 % 8)) || ldc % 4 || (R && ldr % 4))
     return bad("opadpo_gemm_nt", "leading dimensions must keep 16-byte operand / 8-byte output alignment");
-  if (a2_group_n && a2_group_n % 128) return bad("opadpo_gemm_nt", "a2_group_n must be a multiple of the 128-column tile");
+  if ((a2_group_n && a2_group_n % 128) || (a1_group_n && a1_group_n % 128))
+    return bad("opadpo_gemm_nt", "group widths must be multiples of the 128-column tile");
   GemmNTArgs a;
   a.A1 = A1; a.B1 = B1; a.A2 = A2; a.B2 = B2; a.C = C; a.R = R; a.bias = bias;
   a.M = M; a.N = N; a.K1 = K1; a.K2 = K2;
   a.lda1 = lda1; a.ldb1 = ldb1; a.lda2 = lda2; a.ldb2 = ldb2; a.ldc = ldc; a.ldr = ldr;
   a.a2_group_n = a2_group_n; a.a2_group_stride = a2_group_stride;
+  a.a1_group_n = a1_group_n; a.a1_group_stride = a1_group_stride;
   a.alpha = alpha; a.act = act; a.out_f32 = out_f32; a.r_f32 = res_f32;
   return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt");
 }

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
 
   // staging coordinates of this lane inside a 1-KiB (8 rows x 128 B) chunk
   const int srow = lane >> 3, spos = lane & 7;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ring_kernel(GemmNTArgs p) {
   const int nt1 = p.K1 / R_BK, nt2 = p.K2 / R_BK, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
 
   const int srow = lane >> 2, spos = lane & 3;   // 16 rows x 4 chunks per DMA piece
 
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
   const int nt1 = p.K1 / BKX, nt2 = p.K2 / BKX, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
   const int srow = lane / CPR, spos = lane % CPR;
   auto fsw = [](int r) { return BKX == 64 ? ((r >> 1) & 7) : swz64(r); };
 
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
   const int srow = lane >> 3, spos = lane & 7;
 
   // one 1-KiB LDS-DMA piece (8 rows x 128 B) of K-tile t: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave.

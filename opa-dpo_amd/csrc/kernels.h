@@ -15,6 +15,7 @@ struct GemmNTArgs {
   int M, N, K1, K2;
   int lda1, ldb1, lda2, ldb2, ldc, ldr;
   int a2_group_n, a2_group_stride;
+  int a1_group_n, a1_group_stride;      // grouped dgrad: A1 column offset = (n0 / a1_group_n) * a1_group_stride
   float alpha;
   int act;
   int out_f32;

@@ -24,7 +24,7 @@ _u64 = C.c_uint64
 
 # name -> argtypes (restype is int unless noted).  Must list EVERY symbol of include/opadpo_hip.h.
 SIGNATURES = {
-    "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
+    "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
@@ -127,12 +127,13 @@ PROFILE = None
 
 def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
             b2: Optional[torch.Tensor] = None, a2_group_n: int = 0, a2_group_stride: int = 0,
-            residual: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+            a1_group_n: int = 0, a1_group_stride: int = 0, k1: Optional[int] = None, residual: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
             act: int = ACT_NONE) -> torch.Tensor:
     """out[M,N] = act(alpha*(a1 @ b1^T + a2[:, group] @ b2^T) + bias) + residual.  2-D row-major views
     with arbitrary row stride (leading dimension)."""
     _chk(a1, torch.bfloat16, "a1"); _chk(b1, torch.bfloat16, "b1")
-    M, K1 = a1.shape
+    M = a1.shape[0]
+    K1 = a1.shape[1] if k1 is None else k1       # k1: per-group K when a1 is the wide [M, G*K1] grouped operand
     N = b1.shape[0]
     assert b1.shape[1] == K1 and out.shape[0] == M and out.shape[1] == N
     K2 = 0
@@ -149,7 +150,7 @@ def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Option
         e0.record()
     call("opadpo_gemm_nt", ptr(a1), a1.stride(0), ptr(b1), b1.stride(0), K1,
          ptr(a2), a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
-         a2_group_n, a2_group_stride, ptr(out), out.stride(0), int(out_f32),
+         a2_group_n, a2_group_stride, a1_group_n, a1_group_stride, ptr(out), out.stride(0), int(out_f32),
          ptr(residual), residual.stride(0) if residual is not None else 0, int(res_f32), ptr(bias), M, N, float(alpha), act,
          stream())
     if PROFILE is not None:

@@ -487,9 +487,7 @@ class LlavaEngine:
             L.gemm_nt(dY, w["wd_t"], d_act, a2=dt_r, b2=adapter.wt(i, "a_d"))
             L.call("opadpo_silu_mul_bwd", L.ptr(d_act), L.ptr(sv.gu[i]), L.ptr(d_gu), M, F, st)
             _dbg(f"L{i} d_act", d_act); _dbg(f"L{i} d_gu", d_gu)
-            bgt = adapter.wt(i, "b_gu")
-            for g in range(2):
-                L.gemm_nt(d_gu[:, g * F:(g + 1) * F], bgt[g], dt_2r[:, g * r:(g + 1) * r], alpha=s)
+            L.gemm_nt(d_gu, adapter.wt(i, "b_gu").view(2 * r, F), dt_2r, alpha=s, k1=F, a1_group_n=r, a1_group_stride=F)
             L.gemm_tn(d_gu, sv.t_gu[i], adapter.g(i, "b_gu"), q_group_n1=F, q_group_stride=r)
             L.gemm_tn(dt_2r, sv.n2[i], adapter.g(i, "a_gu"))
             L.gemm_nt(d_gu, w["wgu_t"], d_n, a2=dt_2r, b2=adapter.wt(i, "a_gu"))
@@ -509,9 +507,7 @@ class LlavaEngine:
             _dbg(f"L{i} dq", dqkv[:, :H]); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
             L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, st)
             _dbg(f"L{i} dqkv(after rope)", dqkv)
-            bqt = adapter.wt(i, "b_qkv")
-            for g in range(3):
-                L.gemm_nt(dqkv[:, g * H:(g + 1) * H], bqt[g], dt_3r[:, g * r:(g + 1) * r], alpha=s)
+            L.gemm_nt(dqkv, adapter.wt(i, "b_qkv").view(3 * r, H), dt_3r, alpha=s, k1=H, a1_group_n=r, a1_group_stride=H)
             L.gemm_tn(dqkv, sv.t_qkv[i], adapter.g(i, "b_qkv"), q_group_n1=H, q_group_stride=r)
             L.gemm_tn(dt_3r, sv.n1[i], adapter.g(i, "a_qkv"))
             if i > 0:   # layer-0 input is the frozen embedding / image features: no further dgrad

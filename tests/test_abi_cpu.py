@@ -76,5 +76,5 @@ def test_host_side_validation_needs_no_gpu(built_lib):
     from opadpo_amd import lib as L
     fn.argtypes = L.SIGNATURES["opadpo_gemm_nt"]
     fn.restype = ctypes.c_int
-    rc = fn(None, 64, None, 64, 64, None, 0, None, 0, 0, 0, 0, None, 100, 0, None, 0, 0, None, 10, 100, 1.0, 0, None)
+    rc = fn(None, 64, None, 64, 64, None, 0, None, 0, 0, 0, 0, 0, 0, None, 100, 0, None, 0, 0, None, 10, 100, 1.0, 0, None)
     assert rc != 0 and b"multiple of 128" in lib.opadpo_last_error()

@@ -100,6 +100,20 @@ def test_gemm_nt_epilogue(L, act, variant):
     assert float(outw[:, :N].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("variant", [4, 8])
+def test_gemm_nt_grouped_a1(L, variant):
+    """block-diagonal dT_g = dY_g . B_g for fused projections in one launch (a1 groups)."""
+    L.set_flags(variant, True)
+    M, G, r, K = 600, 3, 256, 128
+    a = rnd(M, G * K, seed=1)
+    b = rnd(G * r, K, seed=2)
+    out = torch.empty(M, G * r, dtype=BF, device=dev())
+    L.gemm_nt(a, b, out, alpha=2.0, k1=K, a1_group_n=r, a1_group_stride=K)
+    want = torch.cat([2.0 * a[:, g * K:(g + 1) * K].float() @ b[g * r:(g + 1) * r].float().t() for g in range(G)], 1)
+    L.set_flags(True, True)
+    assert relerr(out, want) < 6e-3
+
+
 @pytest.mark.parametrize("tr", [1, 0])
 @pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0)])
 def test_gemm_tn(L, tr, M, N1, N2, groups):
