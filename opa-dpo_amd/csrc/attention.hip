@@ -90,6 +90,34 @@ __device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int ld,
   }
 }
 
+// split staging (issue-early / write-late): global -> registers while the previous tile is being consumed,
+// registers -> swizzled LDS after the barrier that retires it.
+template <int HD>
+struct TileRegs { uint4 v[(64 * (HD / 8)) / 256]; };
+
+template <int HD>
+__device__ __forceinline__ void tile_fetch(TileRegs<HD>& r, const bf16_t* src, int ld, int s, int L, int pos0, int head, int tid) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int i = 0; i < (64 * CPR) / 256; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / CPR, c16 = idx % CPR;
+    const int pos = pos0 + row;
+    r.v[i] = make_uint4(0, 0, 0, 0);
+    if (pos < L) r.v[i] = *(const uint4*)(src + ((size_t)s * L + pos) * ld + head * HD + c16 * 8);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void tile_commit(char* dst, const TileRegs<HD>& r, int tid) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int i = 0; i < (64 * CPR) / 256; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / CPR, c16 = idx % CPR;
+    *(uint4*)(dst + row * (HD * 2) + ((c16 ^ swz_mask<HD>(row)) << 4)) = r.v[i];
+  }
+}
+
 __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, int s, int L, int k0, int tid) {
   if (tid < 64) {
     const int kp = k0 + tid;
@@ -129,12 +157,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   float m_run = NEG_BIG, l_run = 0.f;
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  TileRegs<HD> kreg, vreg;
+  tile_fetch<HD>(kreg, p.k, p.ld, s, L, 0, h, tid);
+  tile_fetch<HD>(vreg, p.v, p.ld, s, L, 0, h, tid);
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kt * 64;
-    stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
-    stage_tile<HD>(Vs, p.v, p.ld, s, L, k0, h, tid);
+    tile_commit<HD>(Ks, kreg, tid);
+    tile_commit<HD>(Vs, vreg, tid);
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
+    if (kt + 1 < n_kt) {      // next tile's global loads fly while this one is consumed
+      tile_fetch<HD>(kreg, p.k, p.ld, s, L, k0 + 64, h, tid);
+      tile_fetch<HD>(vreg, p.v, p.ld, s, L, k0 + 64, h, tid);
+    }
 
     f32x4_t sc[4];
 #pragma unroll
@@ -263,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
   const bool key_ok = Ms[w * 16 + c] != 0;
 
   const int n_qt = (L + 63) / 64;
-  for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {
+  for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {       // (register budget: no prefetch ring here — 248 VGPRs already)
     const int q0 = qt * 64;
     stage_tile<HD>(Qs, p.q, p.ld, s, L, q0, h, tid);
     stage_tile<HD>(dOs, p.dout, p.ldo, s, L, q0, h, tid);
@@ -361,12 +396,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  TileRegs<HD> kreg, vreg;
+  tile_fetch<HD>(kreg, p.k, p.ld, s, L, 0, h, tid);
+  tile_fetch<HD>(vreg, p.v, p.ld, s, L, 0, h, tid);
   for (int kt = 0; kt < n_kt; ++kt) {
     const int k0 = kt * 64;
-    stage_tile<HD>(Ks, p.k, p.ld, s, L, k0, h, tid);
-    stage_tile<HD>(Vs, p.v, p.ld, s, L, k0, h, tid);
+    tile_commit<HD>(Ks, kreg, tid);
+    tile_commit<HD>(Vs, vreg, tid);
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
+    if (kt + 1 < n_kt) {
+      tile_fetch<HD>(kreg, p.k, p.ld, s, L, k0 + 64, h, tid);
+      tile_fetch<HD>(vreg, p.v, p.ld, s, L, k0 + 64, h, tid);
+    }
     f32x4_t sc[4], dp[4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
