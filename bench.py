@@ -28,6 +28,15 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 
 
+def _pmc_traffic():
+    """Average HBM bytes per gemm_nt launch from the committed PMC passes of this same workload (rocprofv3 cannot run
+    inside the timed process): profiles/r01_pmc_traffic.json, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["gemm_nt_avg_hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(dims_kw, q_len, t_len):
     """Reported CPU baseline: the oracle (the parity-checked CPU restatement of the reference's forward, kind
     'port') on the host cores, on a bounded sample: ONE of the 32 decoder layers at 7B width, one pair =
@@ -48,18 +57,18 @@ def cpu_baseline(dims_kw, q_len, t_len):
     W[p + "input_layernorm.weight"] = torch.ones(d.hidden)
     W[p + "post_attention_layernorm.weight"] = torch.ones(d.hidden)
     L = q_len + t_len + d.n_patches - 1
-    x = torch.randn(2, L, d.hidden, generator=g)
-    km = torch.ones(2, L, dtype=torch.bool)
+    x = torch.randn(1, L, d.hidden, generator=g)
+    km = torch.ones(1, L, dtype=torch.bool)
     t0 = time.time()
     with torch.no_grad():
-        LR.llama_decoder(x, km, W, {k: v.detach() for k, v in lora.items()}, d1)      # reference adapter, 2 sequences
-    y = LR.llama_decoder(x, km, W, lora, d1)                                           # policy, 2 sequences
+        LR.llama_decoder(x, km, W, {k: v.detach() for k, v in lora.items()}, d1)      # reference adapter, 1 of the 2 sequences
+    y = LR.llama_decoder(x, km, W, lora, d1)                                           # policy, 1 of the 2 sequences
     y.sum().backward()
-    dt = time.time() - t0
+    dt = 2.0 * (time.time() - t0)                                                      # chosen + rejected
     pair_s = dt * d.n_layers
     return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), 4 seq-forwards + LoRA backward "
-                      f"of 2 at L={L}: {dt:.1f} s, scaled x{d.n_layers}"}
+            "sample": f"1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), one sequence of the pair at L={L}: "
+                      f"reference forward + policy forward + LoRA backward, x2 sequences = {dt:.1f} s per layer-pair, scaled x{d.n_layers}"}
 
 
 def main():
@@ -157,7 +166,7 @@ def main():
             ach = tot_f / (tot_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_nt (256x256 ping-pong / 128x128 bf16 MFMA GEMM, LDS-DMA staged, LoRA tail fused by K-concatenation)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                    "traffic": None, "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "traffic": _pmc_traffic(), "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
         out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": value, "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

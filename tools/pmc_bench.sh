@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel under the bench workload: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE),
+# --kernel-trace only (no sys/hip/hsa trace), one optimizer step of 8 pairs.  Summary -> gpurun_out/pmc_bench.json
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/pmc_bench
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --pairs 8 --accum 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  echo "pass $C rc=$?"
+done
+python - <<PY
+import csv, glob, json, collections
+out = "$OUT"
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        name = "gemm_nt_pp" if "gemm_nt_pp" in k else ("gemm_nt_x" if "gemm_nt_kernel_x" in k else ("gemm_tn" if "gemm_tn" in k else ("attn" if "attn_" in k else None)))
+        if name:
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for k, d in agg.items():
+    f = d.get("FETCH_SIZE", [0]); w = d.get("WRITE_SIZE", [0])
+    # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams -> x2 (MI355X_MICROARCH.md §HBM)
+    res[k] = {"launches": len(f), "fetch_KiB_raw_mean": sum(f) / len(f), "write_KiB_mean": sum(w) / max(1, len(w)),
+              "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / max(1, len(w))) * 1024}
+json.dump(res, open("$R/gpurun_out/pmc_bench.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
