@@ -348,3 +348,81 @@ def _wide_check(variant, lib, eng, ad, d, dev, images, queries, qmask, two, wts,
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     json.dump(REPORT, open(os.path.join(out_dir, "parity_report_wide.json"), "w"), indent=1)
+
+
+def test_edge_cases_against_oracle(setup):
+    """Ragged / degenerate inputs the reference's pipeline can produce: empty response (EOS at slot 0), response with no
+    padding at all, image token in the first and in the last query slot, a query left-padded down to two real tokens,
+    batch of one; plus the CoPO 'attention' variant (image-key mask concatenated before the query mask)."""
+    s = setup
+    LR = s["LR"]
+    d = s["d"]
+    B, Q, T = 3, 10, 7
+    g = torch.Generator().manual_seed(77)
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g).to(BF).float()
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    queries[0, 0] = -200                         # image token first
+    queries[1, :Q - 2] = 0; qmask[1, :Q - 2] = False
+    queries[1, Q - 2] = -200                     # only [image, one token] survive the left padding
+    queries[2, Q - 1] = -200                     # image token last
+    a = torch.randint(3, d.vocab, (B, T), generator=g)
+    a[0, 0] = 2; a[0, 1:] = 0                    # empty response: EOS then pad
+    a[2, T - 1] = 2                              # row 1: no padding at all, row 2: EOS in the last slot
+    b = torch.randint(3, d.vocab, (B, T), generator=g)
+    b[:, 3] = 2; b[:, 4:] = 0
+    resp = {"standard_response": a, "original_generate_response": b}
+    pol = _policy(s, s["ref"], T)
+    out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, **resp)
+    want = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_ref"], s["od"])
+    for k in resp:
+        got, w = out[k + "_logprobs"].cpu(), want[k + "_logprobs"]
+        valid = resp[k] != 0
+        assert bool(torch.isfinite(got).all()) and bool((got[~valid] == 0).all())
+        assert float((got - w).abs()[valid].max()) < 6e-2, (k, float((got - w).abs()[valid].max()))
+        assert float(((got - w).abs()[valid] / w.abs()[valid].clamp_min(1e-3)).mean()) < 3e-3
+    # batch of one
+    o1 = pol(images=images[:1].to(s["dev"]), queries=queries[:1], queries_attn_masks=qmask[:1], standard_response=a[:1])
+    assert float((o1["standard_response_logprobs"].cpu() - out["standard_response_logprobs"][:1].cpu()).abs().max()) < 2e-2
+    # CoPO 'attention': 30 % of the image keys masked (dpo_trainer.py:311-328 / rl_models.py:103-105)
+    P = d.n_patches
+    im = torch.ones(B, P, dtype=torch.bool)
+    im[0, :5] = False; im[1, 3] = False; im[2, P - 4:] = False
+    wide = torch.cat([im, qmask], dim=1)
+    om = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=wide, **resp)
+    wm = LR.policy_forward(images, queries, wide, resp, s["W"], s["lora_ref"], s["od"])
+    moved = 0.0
+    for k in resp:
+        got, w = om[k + "_logprobs"].cpu(), wm[k + "_logprobs"]
+        valid = resp[k] != 0
+        assert float(((got - w).abs()[valid] / w.abs()[valid].clamp_min(1e-3)).mean()) < 3e-3
+        moved += float((got - out[k + "_logprobs"].cpu()).abs().sum())
+    assert moved > 1e-2, "masking image keys must change the log-probs"
+
+
+def test_reference_recipe_length(setup):
+    """Maximum sizes of the shipped recipe: query 128 + response 896 (L = 128 + 896 + P - 1) — size-independent checks:
+    exact zeros on padding, log-probs <= 0, entropy within [0, ln V], stacking order of the response keys."""
+    import math
+    s = setup
+    d = s["d"]
+    B, Q, T = 2, 128, 896
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g).to(BF)
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    queries[0, :40] = 0; qmask[0, :40] = False
+    queries[:, 50] = -200
+    r1 = torch.randint(3, d.vocab, (B, T), generator=g)
+    r1[0, 700] = 2; r1[0, 701:] = 0
+    r2 = r1.flip(0).clone()
+    pol = _policy(s, s["ref"], T)
+    out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, a_response=r1, b_response=r2)
+    for k, r in (("a_response", r1), ("b_response", r2)):
+        lp, en = out[k + "_logprobs"].cpu(), out[k + "_entropies"].cpu()
+        assert lp.shape == (B, T) and bool(torch.isfinite(lp).all())
+        assert bool((lp[r == 0] == 0).all()) and bool((en[r == 0] == 0).all())
+        assert float(lp.max()) <= 0.0 and float(en.min()) >= 0.0 and float(en.max()) <= math.log(d.vocab) + 1e-3
+    # key order on the batch dimension: swapping the kwargs order swaps nothing in the per-key outputs
+    out2 = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, b_response=r2, a_response=r1)
+    assert float((out2["a_response_logprobs"] - out["a_response_logprobs"]).abs().max()) < 2e-2
