@@ -5,7 +5,7 @@ L = 1087 LLM positions), synthetic image+text batches, random-init weights of th
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP = one optimizer step on every rank: `accum` micro-batches of `pairs` (image, chosen, rejected)
+One STEP = one optimizer step on every rank: `accum` (default 1) micro-batches of `pairs` (default 15) (image, chosen, rejected)
 pairs -> vision encode (once per image) -> frozen-reference forward (no grad) -> policy forward (activations
 resident) -> token-level DPO loss -> LoRA backward -> [RCCL exchange of the flat LoRA gradient] -> global-norm
 clip + AdamW -> refresh of the transposed LoRA copies.  Nothing is skipped or cached across steps.
@@ -76,8 +76,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 8)), help="pairs per micro-batch per GPU")
-    ap.add_argument("--accum", type=int, default=int(os.environ.get("OPADPO_BENCH_ACCUM", 2)), help="micro-batches per optimizer step")
+    # 15 pairs = 30 stacked sequences x 1087 positions = 32610 rows = 128 M-tiles of 256: every big GEMM of the step then
+    # covers a whole number of 256-CU rounds (N=4096: 2048 tiles = 8 rounds; 8 pairs -> 1088 tiles = 4.25 rounds, -8 %).
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 15)), help="pairs per micro-batch per GPU")
+    ap.add_argument("--accum", type=int, default=int(os.environ.get("OPADPO_BENCH_ACCUM", 1)), help="micro-batches per optimizer step")
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
