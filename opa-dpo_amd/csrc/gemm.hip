@@ -457,7 +457,7 @@ constexpr int P_BM = 256, P_BN = 256, P_BK = 64;
 constexpr int P_TILE = P_BM * P_BK * 2;          // 32 KiB per operand tile
 constexpr int P_STAGE = 2 * P_TILE;              // A + B
 
-template <bool MF32>
+template <bool MF32, bool PRIO = true, bool ISSUE_FIRST = true, int GM = GROUP_M>
 __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -466,10 +466,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
+  const int width = GM * tiles_n;
   const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int first_m = group_id * GM;
+  const int gsz = min(tiles_m - first_m, GM);
   const int tm = first_m + (swz % width) % gsz;
   const int tn = (swz % width) / gsz;
   const int m0 = tm * P_BM, n0 = tn * P_BN;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
   // 64 (32) MFMAs in 8 groups; when t_issue >= 0 one LDS-DMA piece of K-tile t_issue is issued after each group so
   // that the (expensive) global_load_lds issue slots overlap with MFMAs already in the matrix pipe.
   auto mfma_all = [&](int t_issue) {
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int g8 = 0; g8 < 8; ++g8) {
       if constexpr (MF32) {
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   };
 #define PP_BARRIER()                               \
   do {                                             \
@@ -610,8 +610,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 
   if (wr == 0) {
     for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) issue(t + 1);
+      if constexpr (ISSUE_FIRST) { if (t + 1 < nt) issue(t + 1); }
       load_frags(t);
+      if constexpr (!ISSUE_FIRST) { if (t + 1 < nt) issue(t + 1); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BARRIER();
       mfma_all(-1);
@@ -783,8 +784,9 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+#define PP_ATTR(...) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE)
+    PP_ATTR(false); PP_ATTR(true); PP_ATTR(false, false); PP_ATTR(false, true, false); PP_ATTR(false, true, true, 16); PP_ATTR(false, true, true, 4);
+#undef PP_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
   }
@@ -794,6 +796,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
   const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
   const bool auto_pp = g_gemm_variant == 10 && pp_tiles >= 384;
+  if (g_gemm_variant >= 11 && g_gemm_variant <= 14 && pp_tiles > 0) {      // schedule experiments
+    const dim3 gr(pp_tiles), bl(512);
+    if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false>), gr, bl, 2 * P_STAGE, st, a);
+    else if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, false>), gr, bl, 2 * P_STAGE, st, a);
+    else if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 16>), gr, bl, 2 * P_STAGE, st, a);
+    else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 4>), gr, bl, 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if ((g_gemm_variant == 8 || g_gemm_variant == 9 || auto_pp) && pp_tiles > 0) {
     const int pt = pp_tiles;
     if (g_gemm_variant != 9) hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
