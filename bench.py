@@ -43,7 +43,7 @@ def cpu_baseline(dims_kw, q_len, t_len):
     4 sequence forwards (2 of them under autograd + backward through the LoRA tensors) at L = 1087; scaled by
     n_layers to a full-model pair (head + vision, <2 % of the FLOPs, not included)."""
     from oracle import llava_ref as LR
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 64))     # torch CPU GEMMs at these sizes stop scaling (and slow down) beyond ~64 threads
     d = LR.LlavaDims(**dims_kw)
     d1 = LR.LlavaDims(**{**dims_kw, "n_layers": 1})
     g = torch.Generator().manual_seed(0)
@@ -66,7 +66,7 @@ def cpu_baseline(dims_kw, q_len, t_len):
     y.sum().backward()
     dt = 2.0 * (time.time() - t0)                                                      # chosen + rejected
     pair_s = dt * d.n_layers
-    return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": min(os.cpu_count(), 64), "kind": "port",
             "sample": f"1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), one sequence of the pair at L={L}: "
                       f"reference forward + policy forward + LoRA backward, x2 sequences = {dt:.1f} s per layer-pair, scaled x{d.n_layers}"}
 

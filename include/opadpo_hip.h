@@ -78,10 +78,11 @@ int opadpo_rmsnorm_fwd(const void* x, int x_f32, const uint16_t* w, uint16_t* y,
 int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint16_t* w, const float* rstd,
                        const void* dres, int dres_f32, float* dx_f32, uint16_t* dx_bf16, int rows, int H, void* stream);
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
-/* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position r % L);
- * cos/sin: fp32 [L, hd/2]; inverse=1 applies the transposed rotation (gradient). */
+/* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position
+ * pos_base[0] + r % L; pos_base is a device int32 or NULL = 0 — device-resident so that a captured decode step can be
+ * replayed); cos/sin: fp32 [max_pos, hd/2]; inverse=1 applies the transposed rotation (gradient). */
 int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
-                int inverse, void* stream);
+                int inverse, const int32_t* pos_base, void* stream);
 int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream);   /* gu = [gate | up] */
 int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu, int rows, int F, void* stream);
 
@@ -122,13 +123,18 @@ int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16,
 
 /* ---- on-policy rollout (opadpo/generator_models/online_generator.py:292-309) ----------------------
  * single-token attention over a KV cache: q [B, nh*hd] (ldq), cache [B, max_ctx, nh*hd] bf16,
- * keys 0..ctx-1 valid where key_mask[b*max_ctx + j] != 0. */
+ * keys 0..ctx-1 valid where key_mask[b*max_ctx + j] != 0; ctx_ptr (device int32, nullable) overrides ctx with
+ * ctx_ptr[0] + 1 (position of the newest key) for graph replay. */
 int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
-                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, int max_ctx, float scale, void* stream);
+                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx,
+                       float scale, void* stream);
 /* temperature -> top-k -> top-p -> multinomial (HF logits processors order); one draw per row from
- * a counter-based generator keyed on (seed, step, row).  finished rows emit pad_id. */
+ * a counter-based generator keyed on (seed, step, row).  finished rows emit pad_id; a row that draws eos_id (>= 0) is
+ * marked finished.  step_ptr (device int32, nullable) overrides `step`; history (nullable) [steps, rows] receives the
+ * token at row step. */
 int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
-                  uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, void* stream);
+                  uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                  int32_t* out, int32_t* history, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,9 +99,9 @@ int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b
   return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
 }
 int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
-                int inverse, void* stream) {
+                int inverse, const int32_t* pos_base, void* stream) {
   if (ld % 8) return bad("opadpo_rope", "misaligned leading dimension");
-  return done(launch_rope(qk, ld, cos_tab, sin_tab, rows, L, n_heads, hd, inverse, S(stream)), "opadpo_rope");
+  return done(launch_rope(qk, ld, cos_tab, sin_tab, rows, L, n_heads, hd, inverse, pos_base, S(stream)), "opadpo_rope");
 }
 int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream) {
   return done(launch_silu_mul_fwd(gu, act, rows, F, S(stream)), "opadpo_silu_mul_fwd");
@@ -164,15 +164,18 @@ int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16,
                            (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)grad_div, S(stream)), "opadpo_adamw");
 }
 int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
-                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, int max_ctx, float scale, void* stream) {
+                       const uint8_t* key_mask, int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx,
+                       float scale, void* stream) {
   if (ctx > max_ctx) return bad("opadpo_attn_decode", "ctx > max_ctx");
-  return done(launch_attn_decode(q, k_cache, v_cache, o, key_mask, B, nh, hd, ctx, max_ctx, ldq, scale, S(stream)),
+  return done(launch_attn_decode(q, k_cache, v_cache, o, key_mask, B, nh, hd, ctx, ctx_ptr, max_ctx, ldq, scale, S(stream)),
               "opadpo_attn_decode");
 }
 int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
-                  uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, void* stream) {
+                  uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                  int32_t* out, int32_t* history, void* stream) {
   if (temperature <= 0.f) return bad("opadpo_sample", "temperature must be > 0");
-  return done(launch_sample(logits, ldl, rows, V, temperature, top_k, top_p, seed, step, finished, pad_id, out, S(stream)),
+  return done(launch_sample(logits, ldl, rows, V, temperature, top_k, top_p, seed, step, step_ptr, finished, pad_id, eos_id, out,
+                            history, S(stream)),
               "opadpo_sample");
 }
 

@@ -10,8 +10,9 @@ namespace {
 // Phase 2: softmax over the block.  Phase 3: 4 key groups x 64 lanes (hd/64 dims per lane).
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc,
-                                                           bf16_t* o, const uint8_t* key_mask, int nh, int ctx, int max_ctx,
-                                                           float scale) {
+                                                           bf16_t* o, const uint8_t* key_mask, int nh, int ctx_arg,
+                                                           const int32_t* ctx_ptr, int max_ctx, float scale) {
+  const int ctx = ctx_ptr ? min(ctx_ptr[0] + 1, max_ctx) : ctx_arg;   // device-resident: keys 0..pos (graph replay)
   extern __shared__ float sm[];          // [ctx] probabilities + [4*HD] partial outputs + [4] reduce
   float* prob = sm;
   float* part = sm + max_ctx;
@@ -81,15 +82,21 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// step_ptr (nullable): device-resident step counter (graph replay) used for the RNG stream and, with `history`
+// ([max_steps, rows]), for the slot the token is appended to.  eos_id >= 0: a row that samples EOS is marked finished.
 __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int ldl, int V, float inv_temp, int top_k, float top_p,
-                                                      uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id,
-                                                      int32_t* out) {
+                                                      uint64_t seed, uint64_t step_arg, const int32_t* step_ptr, uint8_t* finished,
+                                                      int pad_id, int eos_id, int32_t* out, int32_t* history) {
+  const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : step_arg;
   __shared__ float red[4];
   __shared__ float scan[256];
   __shared__ uint32_t s_thr;
   const int row = blockIdx.x, tid = threadIdx.x;
   if (finished && finished[row]) {
-    if (tid == 0) out[row] = pad_id;
+    if (tid == 0) {
+      out[row] = pad_id;
+      if (history) history[step * gridDim.x + row] = pad_id;
+    }
     return;
   }
   const float* z = logits + (size_t)row * ldl;
@@ -170,29 +177,33 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int ld
       }
     }
     out[row] = pick;
+    if (history) history[step * gridDim.x + row] = pick;
+    if (finished && eos_id >= 0 && pick == eos_id) finished[row] = 1;
   }
 }
 
 }  // namespace
 
 hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* o, const uint8_t* key_mask,
-                              int B, int nh, int hd, int ctx, int max_ctx, int ldq, float scale, hipStream_t st) {
+                              int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx, int ldq, float scale,
+                              hipStream_t st) {
   if (B <= 0) return hipSuccess;
   const size_t smem = (size_t)(max_ctx + 4 * hd + 4) * sizeof(float);
   if (smem > 64 * 1024) return hipErrorInvalidValue;
   if (hd == 128)
-    hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, max_ctx, scale);
+    hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, scale);
   else if (hd == 64)
-    hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, max_ctx, scale);
+    hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, scale);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
 hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
-                         uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, hipStream_t st) {
+                         uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                         int32_t* out, int32_t* history, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), 0, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed, step,
-                     finished, pad_id, out);
+                     step_ptr, finished, pad_id, eos_id, out, history);
   return hipGetLastError();
 }

@@ -122,14 +122,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
 // (call once for the q section and once for the k section, or with 2*n_heads when contiguous).
 // forward: x' = x*cos + rot(x)*sin ; inverse (gradient): g' = g*cos - rot(g)*sin  with rot(x) = [-x2, x1]
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const float* cosb, const float* sinb,
-                                                    size_t total, int L, int n_heads, int hd, int inverse) {
+                                                    size_t total, int L, int n_heads, int hd, int inverse, const int32_t* pos_base) {
   const int half = hd / 2;
+  const int pos0 = pos_base ? pos_base[0] : 0;     // device-resident position offset (graph-replayed decode step)
   const int per_row = n_heads * (half / 8);     // 8 (x1,x2) pairs per thread
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const size_t row = idx / per_row;
     const int rem = (int)(idx % per_row);
     const int head = rem / (half / 8), i0 = (rem % (half / 8)) * 8;
-    const int pos = (int)(row % L);
+    const int pos = pos0 + (int)(row % L);
     bf16_t* base = qk + row * ld + head * hd;
     float x1[8], x2[8];
     unpack8(*(const uint4*)(base + i0), x1);
@@ -364,11 +365,11 @@ hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* 
   return hipGetLastError();
 }
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, hipStream_t st) {
+                       int inverse, const int32_t* pos_base, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (hd % 16) return hipErrorInvalidValue;
   const size_t total = (size_t)rows * n_heads * (hd / 16);
-  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base);
   return hipGetLastError();
 }
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {

@@ -62,7 +62,7 @@ hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const 
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
 hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, hipStream_t st);
+                       int inverse, const int32_t* pos_base, hipStream_t st);
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
@@ -87,6 +87,8 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_
                         float max_norm, float grad_div, hipStream_t st);
 
 hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
-                         uint64_t seed, uint64_t step, const uint8_t* finished, int pad_id, int32_t* out, hipStream_t st);
+                         uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
+                         int32_t* out, int32_t* history, hipStream_t st);
 hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* o, const uint8_t* key_mask,
-                              int B, int nh, int hd, int ctx, int max_ctx, int ldq, float scale, hipStream_t st);
+                              int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx, int ldq, float scale,
+                              hipStream_t st);

@@ -36,8 +36,8 @@ def truncate_after_eos_with_padding(completions: torch.Tensor, eos_token_id: int
 
 
 class Generator:
-    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None):
-        self.engine, self.adapter = engine, adapter
+    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True):
+        self.engine, self.adapter, self.use_graph = engine, adapter, use_graph
 
     @torch.no_grad()
     def generate(self, queries: torch.Tensor, query_attn_masks: torch.Tensor, images: Optional[torch.Tensor] = None, *,
@@ -84,7 +84,11 @@ class Generator:
             eng.layer_fwd(i, self.adapter, sv.x[i & 1], sv.x[(i + 1) & 1], sv, 0, B, Lp, km_prefill, cos, sin, kv_hook)
         xf = sv.x[d.n_layers & 1]
         last = (torch.arange(B, device=dev, dtype=torch.int32) * Lp + (Lp - 1)).contiguous()
-        # ---- decode buffers (M = B rows) --------------------------------------------------------------------
+        # ---- decode: ONE step captured in a HIP graph and replayed per token -----------------------------------
+        # Everything that changes from step to step lives in device memory (position / step counter, cache slot
+        # indices, current tokens, finished flags), so the ~15 launches x n_layers of a step are recorded once and
+        # replayed with a single hipGraphLaunch (the eager loop was host-launch-bound: ~480 Python->C calls per token).
+        key_mask[:, Lp:] = 1                       # future slots: valid as soon as ctx (device counter) reaches them
         x = e((B, H), torch.float32)
         x2 = e((B, H), torch.float32)
         hs, hn = e((B, H), torch.float32), e((B, H))
@@ -94,35 +98,32 @@ class Generator:
         kv_tmp = e((B, H))
         emb = e((B, H))
         logits = e((B, V), torch.float32)
-        nxt = torch.empty(B, dtype=torch.int32, device=dev)
+        cur_tok = torch.zeros(B, dtype=torch.int32, device=dev)
         finished = torch.zeros(B, dtype=torch.uint8, device=dev)
-        out = torch.full((B, max_new_tokens), pad_token_id, dtype=torch.int64, device=dev)
+        history = torch.full((max_new_tokens, B), pad_token_id, dtype=torch.int32, device=dev)
         rows_b = torch.arange(B, device=dev, dtype=torch.int32)
-        half = hd // 2
+        step_d = torch.zeros(1, dtype=torch.int32, device=dev)                     # tokens sampled so far
+        pos_d = torch.full((1,), Lp - 1, dtype=torch.int32, device=dev)            # position of the newest cached key
+        slot = (rows_b * max_ctx + (Lp - 1)).contiguous()                          # its cache row per sequence
         s = d.lora_scale
         ad = self.adapter
+        eos_arg = -1 if suppress_eos else eos_token_id
 
         def head(src_f32):
-            L.call("opadpo_rmsnorm_fwd", L.ptr(src_f32), 1, L.ptr(b.norm), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, st)
+            L.call("opadpo_rmsnorm_fwd", L.ptr(src_f32), 1, L.ptr(b.norm), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, L.stream())
             L.gemm_nt(hn, b.lm_head, logits)
             if suppress_eos:
                 logits[:, eos_token_id] = float("-inf")
-            L.call("opadpo_sample", L.ptr(logits), V, B, V, float(temperature), int(top_k), float(top_p), int(seed), int(step),
-                   L.ptr(finished), pad_token_id, L.ptr(nxt), st)
+            L.call("opadpo_sample", L.ptr(logits), V, B, V, float(temperature), int(top_k), float(top_p), int(seed), 0,
+                   L.ptr(step_d), L.ptr(finished), pad_token_id, eos_arg, L.ptr(cur_tok), L.ptr(history), L.stream())
+            step_d.add_(1)
 
-        step = 0
-        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
-        head(hs)
-        for step in range(1, max_new_tokens + 1):
-            out[:, step - 1] = nxt
-            finished |= (nxt == eos_token_id).to(torch.uint8)
-            if step == max_new_tokens or (step % 16 == 0 and bool(finished.all())):
-                break
-            pos = Lp + step - 1                      # cache slot / RoPE position of the token just sampled
-            key_mask[:, pos] = 1
-            L.call("opadpo_gather_rows", L.ptr(b.embed), H, L.ptr(nxt), L.ptr(emb), B, H, st)
+        def decode_step():
+            st = L.stream()
+            pos_d.add_(1)
+            slot.add_(1)
+            L.call("opadpo_gather_rows", L.ptr(b.embed), H, L.ptr(cur_tok), L.ptr(emb), B, H, st)
             cur, nx = emb, x
-            slot = (rows_b * max_ctx + pos).contiguous()
             for i in range(d.n_layers):
                 w = b.layers[i]
                 L.call("opadpo_rmsnorm_fwd", L.ptr(cur), int(cur.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(rstd), B, H, d.rms_eps, st)
@@ -131,13 +132,12 @@ class Generator:
                     L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=ad.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
                 else:
                     L.gemm_nt(n1, w["wqkv"], qkv)
-                L.call("opadpo_rope", L.ptr(qkv), 3 * H, cos.data_ptr() + pos * half * 4, sin.data_ptr() + pos * half * 4, B, 1,
-                       2 * nh, hd, 0, st)
+                L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), B, 1, 2 * nh, hd, 0, L.ptr(pos_d), st)
                 for src_off, cache in ((H, kc[i]), (2 * H, vc[i])):
                     L.call("opadpo_gather_rows", qkv.data_ptr() + 2 * src_off, 3 * H, L.ptr(rows_b), L.ptr(kv_tmp), B, H, st)
                     L.call("opadpo_scatter_rows", L.ptr(kv_tmp), L.ptr(slot), L.ptr(cache), H, B, H, st)
                 L.call("opadpo_attn_decode", L.ptr(qkv), 3 * H, L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(att), L.ptr(key_mask), B, nh, hd,
-                       pos + 1, max_ctx, hd ** -0.5, st)
+                       0, L.ptr(pos_d), max_ctx, hd ** -0.5, st)
                 if ad is not None:
                     L.gemm_nt(att, ad.w(i, "a_o"), t_o, alpha=s)
                     L.gemm_nt(att, w["wo"], hb, a2=t_o, b2=ad.w(i, "b_o"), residual=cur)
@@ -146,7 +146,23 @@ class Generator:
                 eng.mlp_fwd(i, ad, hb, nx, n2, t_gu, gu, act, t_d, rstd, B)
                 cur, nx = nx, (x2 if nx is x else x)
             head(cur)
-        return out
+
+        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
+        head(hs)                                   # token 0 from the prefill logits
+        graph = None
+        for step in range(1, max_new_tokens):
+            if step == 2 and self.use_graph and max_new_tokens > 3:
+                torch.cuda.synchronize()           # step 1 ran eagerly (warm-up of every kernel of the step)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    decode_step()                  # recorded, not executed
+            if graph is not None:
+                graph.replay()
+            else:
+                decode_step()
+            if step % 32 == 0 and bool(finished.all()):
+                break
+        return history.t().contiguous().to(torch.int64)
 
     def rollout(self, queries, query_attn_masks, images, *, response_len: int, temperature: float = 1.0, top_k: int = 30,
                 top_p: float = 0.95, seed: int = 0, additional_stop_ids: Sequence[int] = (1577, 29973)) -> torch.Tensor:

@@ -31,7 +31,7 @@ SIGNATURES = {
     "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_rmsnorm_bwd": [_p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
-    "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "opadpo_silu_mul_fwd": [_p, _p, _i, _i, _p],
     "opadpo_silu_mul_bwd": [_p, _p, _p, _i, _i, _p],
     "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
@@ -46,8 +46,8 @@ SIGNATURES = {
     "opadpo_head_bwd": [_p, _i, _p, _p, _p, _f, _p, _i, _i, _i, _p],
     "opadpo_sumsq": [_p, _sz, _p, _p],
     "opadpo_adamw": [_p, _p, _p, _p, _p, _sz, _d, _d, _d, _d, _d, _i, _p, _d, _d, _p],
-    "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _i, _p, _p],
+    "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _f, _p],
+    "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _p, _i, _i, _p, _p, _p],
 }
 OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags"]
 

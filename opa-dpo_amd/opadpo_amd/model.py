@@ -371,7 +371,7 @@ class LlavaEngine:
             L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
         else:
             L.gemm_nt(n1, w["wqkv"], qkv)
-        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, st)
+        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, st)
         if kv_hook is not None:
             kv_hook(i, qkv)
         L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,
@@ -505,7 +505,7 @@ class LlavaEngine:
                    dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, st)
             _dbg(f"L{i} d_attn", d_attn); _dbg(f"L{i} attn", sv.attn[i]); _dbg(f"L{i} lse", sv.lse[i]); _dbg(f"L{i} delta", delta)
             _dbg(f"L{i} dq", dqkv[:, :H]); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
-            L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, st)
+            L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, None, st)
             _dbg(f"L{i} dqkv(after rope)", dqkv)
             L.gemm_nt(dqkv, adapter.wt(i, "b_qkv").view(3 * r, H), dt_3r, alpha=s, k1=H, a1_group_n=r, a1_group_stride=H)
             L.gemm_tn(dqkv, sv.t_qkv[i], adapter.g(i, "b_qkv"), q_group_n1=H, q_group_stride=r)

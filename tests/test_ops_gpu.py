@@ -257,7 +257,7 @@ def test_rope(L):
     f = torch.outer(torch.arange(Ln).float(), inv)
     cos, sin = f.cos().to(dev()).contiguous(), f.sin().to(dev()).contiguous()
     x = qkv.clone()
-    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, L.stream())
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, None, L.stream())
     ref = qkv.float().view(S, Ln, 3 * nh, hd)
     c = torch.cat([f, f], -1).cos().to(dev())[None, :, None, :]
     s = torch.cat([f, f], -1).sin().to(dev())[None, :, None, :]
@@ -266,8 +266,17 @@ def test_rope(L):
     want[:, :, : 2 * nh] = (ref * c + rot * s)[:, :, : 2 * nh]
     assert relerr(x, want.reshape(S * Ln, 3 * H)) < 4e-3
     assert torch.equal(x[:, 2 * H:], qkv[:, 2 * H:])          # v untouched
-    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, L.stream())
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, None, L.stream())
     assert relerr(x, qkv) < 8e-3                               # inverse rotation restores the input
+    # device-resident position offset (decode step replayed from a graph): one row per sequence at position 7
+    one = qkv[:S].clone()
+    pos = torch.tensor([7], dtype=torch.int32, device=dev())
+    L.call("opadpo_rope", one.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S, 1, 2 * nh, hd, 0, pos.data_ptr(), L.stream())
+    r1 = qkv[:S].float().view(S, 3 * nh, hd)
+    c7, s7 = torch.cat([f[7], f[7]]).cos().to(dev()), torch.cat([f[7], f[7]]).sin().to(dev())
+    w1 = r1.clone()
+    w1[:, : 2 * nh] = (r1 * c7 + torch.cat([-r1[..., hd // 2:], r1[..., : hd // 2]], -1) * s7)[:, : 2 * nh]
+    assert relerr(one, w1.reshape(S, 3 * H)) < 4e-3
 
 
 def test_silu_mul(L):
@@ -418,7 +427,12 @@ def test_attn_decode(L):
     km[0, :4] = 0
     o = torch.empty(B, H, dtype=BF, device=dev())
     L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o.data_ptr(), km.data_ptr(), B, nh, hd, ctx,
-           max_ctx, hd ** -0.5, L.stream())
+           None, max_ctx, hd ** -0.5, L.stream())
+    o2 = torch.empty_like(o)
+    posd = torch.tensor([ctx - 1], dtype=torch.int32, device=dev())        # device-resident newest-key position
+    L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o2.data_ptr(), km.data_ptr(), B, nh, hd, 0,
+           posd.data_ptr(), max_ctx, hd ** -0.5, L.stream())
+    assert torch.equal(o, o2)
     qf = q.float().view(B, nh, hd)
     kf = kc.float().view(B, max_ctx, nh, hd)[:, :ctx]
     vf = vc.float().view(B, max_ctx, nh, hd)[:, :ctx]
@@ -436,7 +450,7 @@ def test_sampler_distribution(L):
     out = torch.empty(rows, dtype=torch.int32, device=dev())
     fin = torch.zeros(rows, dtype=torch.uint8, device=dev())
     fin[7] = 1
-    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 5, fin.data_ptr(), 0, out.data_ptr(), L.stream())
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 5, None, fin.data_ptr(), 0, -1, out.data_ptr(), None, L.stream())
     torch.cuda.synchronize()
     assert int(out[7]) == 0
     z = base / 0.8
@@ -453,9 +467,15 @@ def test_sampler_distribution(L):
     assert float((emp - p).abs().max()) < 0.03
     # determinism for (seed, step, row) and pure multinomial path
     out2 = torch.empty_like(out)
-    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 5, fin.data_ptr(), 0, out2.data_ptr(), L.stream())
-    assert torch.equal(out, out2)
-    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 1.0, 0, 1.0, 99, 0, None, 0, out2.data_ptr(), L.stream())
+    stepd = torch.tensor([5], dtype=torch.int32, device=dev())
+    hist = torch.full((8, rows), -7, dtype=torch.int32, device=dev())
+    fin2 = fin.clone()
+    eos = int(out[0])
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 0.8, 30, 0.95, 1234, 0, stepd.data_ptr(), fin2.data_ptr(), 0, eos,
+           out2.data_ptr(), hist.data_ptr(), L.stream())
+    assert torch.equal(out, out2) and torch.equal(hist[5], out) and int((hist[4] != -7).sum()) == 0
+    assert torch.equal(fin2.bool(), fin.bool() | (out == eos))              # rows that drew EOS are marked finished
+    L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 1.0, 0, 1.0, 99, 0, None, None, 0, -1, out2.data_ptr(), None, L.stream())
     emp = torch.bincount(out2.long(), minlength=V).float() / rows
     assert float((emp - torch.softmax(base, -1)).abs().max()) < 0.03
 

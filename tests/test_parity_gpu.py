@@ -248,10 +248,11 @@ def test_generation_kv_cache_against_oracle(setup):
     LR = s["LR"]
     from opadpo_amd.generate import Generator
     from oracle import dpo_ref as D
-    B, Q, N = 2, 12, 6
+    B, Q, N = 2, 12, 8
     images, queries, qmask, _ = make_inputs(s["d"], B, Q, 9, seed=33)
-    for adapter, lora in ((s["ref"], s["lora_ref"]), (None, {k: v for k, v in s["lora_ref"].items() if "vision_tower" in k or "mm_projector" in k})):
-        gen = Generator(s["eng"], adapter)
+    vis_only = {k: v for k, v in s["lora_ref"].items() if "vision_tower" in k or "mm_projector" in k}
+    for adapter, lora, use_graph in ((s["ref"], s["lora_ref"], True), (None, vis_only, True), (s["ref"], s["lora_ref"], False)):
+        gen = Generator(s["eng"], adapter, use_graph=use_graph)
         out = gen.generate(queries, qmask, images.to(s["dev"]), max_new_tokens=N, temperature=1.0, top_k=1, top_p=1.0, seed=1)
         torch.cuda.synchronize()
         out = out.cpu()

@@ -47,7 +47,7 @@ def main():
                 L.gemm_nt(a1, b1, out, **kw)
         torch.cuda.synchronize()
         return
-    for glds in ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ((8, 11, 12, 13, 14, 8) if only == "pp" else ()))):
+    for glds in ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ((8, 9, 8, 9) if only == "pp" else ()))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
