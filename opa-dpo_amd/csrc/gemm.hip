@@ -662,6 +662,94 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 // ------------------------------------------------------------------------------------------
 constexpr int TK = 64;  // rows (m) per LDS stage
 
+// ---------------------------------------------------------------------------------------------------
+// gemm_nt "skinny" kernel (M <= 64: KV-cache decode, one token per sequence).  HBM-bound: the job is to stream
+// the [N,K] weight exactly once at full bandwidth with enough bytes in flight, not to feed the MFMA pipe.
+//   * one workgroup (8 waves) = NR*16 weight rows x the WHOLE K, so no cross-workgroup reduction / atomics and the
+//     full epilogue (alpha, bias, act, residual, fp32 out) stays fused; N = 4096 -> 256 workgroups = one per CU;
+//   * inside the workgroup the K range is split over the 8 waves (contiguous slices, so every weight row is read as
+//     8 sequential streams); each lane loads its MFMA fragment (row = lane&15, 8 bf16 at k-chunk lane>>4) straight
+//     from global memory with 16-byte non-temporal loads, U k-steps issued back to back before the MFMAs;
+//   * the weight fragment is the first MFMA operand, so a lane ends up with 4 consecutive output columns of one
+//     activation row -> vector stores; activations (a few hundred KB, L2-resident) are the second operand, MF
+//     fragments of 16 rows, rows >= M are zero and never loaded;
+//   * the 8 partial accumulators meet in LDS (NR*MF KiB per wave), one barrier.
+// The LoRA tail ([x|t].[W|B]^T) is a second K segment, split over the waves the same way.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+template <int MF, int NR, int U>
+__global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
+  __shared__ __attribute__((aligned(16))) float red[8][NR * MF][64][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * (16 * NR);
+  const int r = lane & 15, c = lane >> 4;
+
+  const bf16_t* a1 = p.A1;
+  const bf16_t* a2 = p.A2;
+  if (p.a1_group_n > 0) a1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+
+  f32x4_t acc[NR][MF];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto segment = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int K) {
+    const int ns = K >> 5;                       // 32-element k-steps
+    const int per = (ns + 7) >> 3;
+    const int sb = wave * per, se = min(ns, sb + per);
+    const bf16_t* wp[NR];
+    const bf16_t* xp[MF];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) wp[i] = B + (size_t)(n0 + i * 16 + r) * ldb + c * 8;
+#pragma unroll
+    for (int f = 0; f < MF; ++f) xp[f] = A + (size_t)min(f * 16 + r, p.M - 1) * lda + c * 8;
+    for (int s = sb; s < se; s += U) {
+      u32x4_t w[U][NR], x[U][MF];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = s + u < se;
+        const int k = (s + u) << 5;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          w[u][i] = u32x4_t{0, 0, 0, 0};
+          if (live) w[u][i] = __builtin_nontemporal_load((const u32x4_t*)(wp[i] + k));
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+          x[u][f] = u32x4_t{0, 0, 0, 0};
+          if (live && f * 16 + r < p.M) x[u][f] = *(const u32x4_t*)(xp[f] + k);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+          for (int f = 0; f < MF; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&w[u][i], *(const bf16x8_t*)&x[u][f], acc[i][f], 0, 0, 0);
+    }
+  };
+  segment(a1, p.lda1, p.B1, p.ldb1, p.K1);
+  if (p.K2 > 0) segment(a2, p.lda2, p.B2, p.ldb2, p.K2);
+
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) *(f32x4_t*)red[wave][i * MF + f][lane] = acc[i][f];
+  __syncthreads();
+  for (int idx = wave; idx < NR * MF; idx += 8) {
+    f32x4_t v = *(const f32x4_t*)red[0][idx][lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) v += *(const f32x4_t*)red[w2][idx][lane];
+    const int i = idx / MF, f = idx % MF;
+    const int m = f * 16 + r;
+    if (m < p.M) epilogue4(p, m, n0 + i * 16 + c * 4, v[0], v[1], v[2], v[3]);
+  }
+}
+
+
 // [TK][128] bf16 tiles (256-byte rows) with the 16-byte-chunk swizzle chunk ^= (row & 7) << 1, which is
 // conflict-free for ds_read_b64_tr_b16 (the 32 lanes of a half-wave touch 8 rows x 32 B = all 64 banks).
 __device__ __forceinline__ const char* tn_at(const char* tile, int row, int col) {
@@ -789,6 +877,18 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
 #undef PP_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
+  }
+  // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
+  if (a.M <= 64 && (g_gemm_variant == 10 || g_gemm_variant == 15)) {
+    const bool wide = a.N % 32 == 0 && a.N / 32 >= 512 && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) &&
+                      (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
+    const int mf = (a.M + 15) / 16;
+    const dim3 bl(512), gr(wide ? a.N / 32 : a.N / 16);
+#define SK(MF_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<MF_, NR_, U_>), gr, bl, 0, st, a)
+    if (wide) { if (mf == 1) SK(1, 2, 8); else if (mf == 2) SK(2, 2, 4); else if (mf == 3) SK(3, 2, 2); else SK(4, 2, 2); }
+    else      { if (mf == 1) SK(1, 1, 8); else if (mf == 2) SK(2, 1, 4); else if (mf == 3) SK(3, 1, 4); else SK(4, 1, 4); }
+#undef SK
+    return hipGetLastError();
   }
   // variant 10 (default, "auto"): the 256x256 ping-pong kernel when it yields at least ~1.5 rounds of blocks on the
   // 256 CUs, the 128x128 kernel otherwise (skinny LoRA GEMMs, N not a multiple of 256).

@@ -69,6 +69,43 @@ def test_gemm_nt(L, glds, M, N, K1, K2, groups):
     assert e < 6e-3, f"gemm_nt rel err {e}"   # bf16 output rounding ~ 2^-9
 
 
+@pytest.mark.parametrize("M", [1, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K1,K2,groups", [(256, 4096, 0, 0), (384, 192, 128, 3), (16384, 128, 64, 2), (128, 2752, 256, 1),
+                                            (22016, 64, 128, 2)])
+def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
+    """decode-sized GEMMs (M <= 64) take the weight-streaming kernel: in-workgroup split-K, LoRA tail as a second K
+    segment, grouped tail columns, fused epilogue (alpha / bias / residual, bf16 and fp32 outputs)."""
+    L.set_flags(10, True)
+    a1, b1 = rnd(M, K1, scale=0.5, seed=1), rnd(N, K1, scale=0.5, seed=2)
+    want = a1.float() @ b1.float().t()
+    kw = {}
+    if K2:
+        G = max(groups, 1)
+        a2, b2 = rnd(M, G * K2, scale=0.5, seed=3), rnd(N, K2, scale=0.5, seed=4)
+        kw = dict(a2=a2, b2=b2, a2_group_n=(N // G if groups > 1 else 0), a2_group_stride=(K2 if groups > 1 else 0))
+        ng = N // G
+        for g in range(G):
+            want[:, g * ng:(g + 1) * ng] += a2[:, g * K2:(g + 1) * K2].float() @ b2[g * ng:(g + 1) * ng].float().t()
+    out = torch.full((M + 1, N), 7.0, dtype=BF, device=dev())
+    L.gemm_nt(a1, b1, out[:M], **kw)
+    assert relerr(out[:M], want) < 6e-3
+    assert float((out[M:].float() - 7.0).abs().max()) == 0.0          # rows >= M untouched
+    bias, res32 = rnd(N, seed=5), torch.randn(M, N, device=dev())
+    o32 = torch.empty(M, N, device=dev())
+    L.gemm_nt(a1, b1, o32, bias=bias, residual=res32, alpha=0.25, **kw)
+    assert relerr(o32, 0.25 * want + bias.float() + res32) < 1e-5
+    resb = rnd(M, N, seed=6)
+    ob = torch.empty(M, N, dtype=BF, device=dev())
+    L.gemm_nt(a1, b1, ob, residual=resb, act=2, **kw)
+    assert relerr(ob, torch.nn.functional.gelu(want) + resb.float()) < 6e-3
+    # the general tile kernel on the same problem agrees
+    L.set_flags(4, True)
+    o4 = torch.empty(M, N, device=dev())
+    L.gemm_nt(a1, b1, o4, bias=bias, residual=res32, alpha=0.25, **kw)
+    L.set_flags(10, True)
+    assert relerr(o32, o4) < 1e-5
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):

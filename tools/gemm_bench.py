@@ -34,6 +34,34 @@ def main():
     shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
               ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
     only = os.environ.get("GB_ONLY", "")
+    if only == "skinny":   # decode-sized GEMMs: weight streaming rate; weights rotated over > 512 MB so MALL cannot hold them
+        for M_ in (8, 16, 32, 64):
+            for name, N, K1, K2, grp in shapes:
+                if name == "lora_t":
+                    continue
+                copies = max(2, int(6.0e8 // (N * K1 * 2)) + 1)
+                ws = [(torch.randn(N, K1, device=dev) * 0.02).to(BF) for _ in range(copies)]
+                a1 = torch.randn(M_, K1, device=dev).to(BF)
+                out = torch.empty(M_, N, dtype=BF, device=dev)
+                for label, variant in (("skinny", 10), ("tile128", 4), ("hipBLASLt", -1)):
+                    if variant >= 0:
+                        L.set_flags(variant, True)
+                    it = [0]
+
+                    def fn():
+                        w = ws[it[0] % copies]
+                        it[0] += 1
+                        if variant >= 0:
+                            L.gemm_nt(a1, w, out)
+                        else:
+                            torch.matmul(a1, w.t(), out=out)
+                    t = timeit(fn, iters=3 * copies, warm=copies)
+                    res.append(dict(kernel=label, name=name, M=M_, N=N, K=K1, us=t * 1e6, GBps=N * K1 * 2 / t / 1e9))
+                    print(res[-1], flush=True)
+                del ws
+        L.set_flags(10, True)
+        json.dump(res, open(os.path.join(REPO, "gpurun_out", "gemm_skinny.json"), "w"), indent=1)
+        return
     if only == "pmc":      # few launches of the two big shapes, default variant only (PMC passes serialize kernels)
         L.set_flags(int(os.environ.get("GB_VARIANT", 1)), True)
         for name, N, K1, K2, grp in shapes[:2]:
