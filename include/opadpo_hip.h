@@ -27,6 +27,8 @@ extern "C" {
 #define OPADPO_ACT_NONE 0
 #define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
+#define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
+                                  * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
 
 int opadpo_abi_version(void);
 const char* opadpo_last_error(void);
@@ -121,13 +123,21 @@ int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16,
                  double beta2, double eps, double weight_decay, int step, const float* sumsq, double max_norm,
                  double grad_div, void* stream);
 
-/* ---- on-policy rollout (opadpo/generator_models/online_generator.py:292-309) ----------------------
- * single-token attention over a KV cache: q [B, nh*hd] (ldq), cache [B, max_ctx, nh*hd] bf16,
+/* ---- rollout (online_generator.py:292-323: policy.generate(do_sample=True, top_k, top_p, temperature)) ----
+ * KV cache layout is head-major: k_cache / v_cache [B, nh, max_ctx, hd] (one (sequence, head) = one contiguous stream).
+ * attn_decode: one query token per sequence, q row b at q + b*ldq ([nh*hd] used), o [B, nh*hd];
  * keys 0..ctx-1 valid where key_mask[b*max_ctx + j] != 0; ctx_ptr (device int32, nullable) overrides ctx with
- * ctx_ptr[0] + 1 (position of the newest key) for graph replay. */
+ * ctx_ptr[0] + 1 (position of the newest key) for graph replay.  workspace (nullable): device scratch of at least
+ * opadpo_attn_decode_workspace_bytes(B, nh, hd, max_ctx) bytes; with it the key range is split over several blocks
+ * (+ one merge launch) when B*nh alone cannot fill the 256 CUs.  Cache slots >= ctx are never read. */
 int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
                        const uint8_t* key_mask, int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx,
-                       float scale, void* stream);
+                       float scale, void* workspace, size_t workspace_bytes, void* stream);
+size_t opadpo_attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx);
+/* decode step: RoPE at position pos_ptr[0] (device int32) on the q and k thirds of qkv rows [q|k|v] (ld elements apart);
+ * q is rotated in place, the rotated k and the v are appended to the caches at [b, h, pos, :]. */
+int opadpo_rope_kv_append(uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
+                          int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, void* stream);
 /* temperature -> top-k -> top-p -> multinomial (HF logits processors order); one draw per row from
  * a counter-based generator keyed on (seed, step, row).  finished rows emit pad_id; a row that draws eos_id (>= 0) is
  * marked finished.  step_ptr (device int32, nullable) overrides `step`; history (nullable) [steps, rows] receives the

@@ -165,10 +165,20 @@ int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16,
 }
 int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
                        const uint8_t* key_mask, int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx,
-                       float scale, void* stream) {
+                       float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (ctx > max_ctx) return bad("opadpo_attn_decode", "ctx > max_ctx");
-  return done(launch_attn_decode(q, k_cache, v_cache, o, key_mask, B, nh, hd, ctx, ctx_ptr, max_ctx, ldq, scale, S(stream)),
+  if (ldq % 8) return bad("opadpo_attn_decode", "misaligned leading dimension");
+  return done(launch_attn_decode(q, k_cache, v_cache, o, key_mask, B, nh, hd, ctx, ctx_ptr, max_ctx, ldq, scale, workspace,
+                                 workspace_bytes, S(stream)),
               "opadpo_attn_decode");
+}
+size_t opadpo_attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx) {
+  return (B > 0 && nh > 0) ? attn_decode_workspace_bytes(B, nh, hd, max_ctx) : 0;
+}
+int opadpo_rope_kv_append(uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
+                          int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, void* stream) {
+  return done(launch_rope_kv_append(qkv, ld, cos_tab, sin_tab, k_cache, v_cache, B, nh, hd, pos_ptr, max_ctx, S(stream)),
+              "opadpo_rope_kv_append");
 }
 int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
                   uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,

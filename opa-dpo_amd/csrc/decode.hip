@@ -3,71 +3,167 @@
 // calls policy.generate(do_sample=True, top_k=30, top_p=0.95): online_generator.py:292-309).
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
-// block = (head, batch row); 256 threads.  Phase 1: thread t scores keys t, t+256, ...
-// Phase 2: softmax over the block.  Phase 3: 4 key groups x 64 lanes (hd/64 dims per lane).
-template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc,
-                                                           bf16_t* o, const uint8_t* key_mask, int nh, int ctx_arg,
-                                                           const int32_t* ctx_ptr, int max_ctx, float scale) {
+// ---- single-token attention over the KV cache ("flash decoding") ----------------------------------------------------
+// Cache layout is head-major: k_cache / v_cache [B, nh, max_ctx, HD], so one (sequence, head) is a contiguous stream
+// of HD*2-byte rows -> every wave load instruction covers 1 KiB of consecutive bytes.  HBM-bound: 2*HD*2 bytes per key.
+// grid = (nh, B, splits), NW waves.  HD/8 lanes share one key (16 B of K and of V each), so a wave covers 64/(HD/8)
+// keys per step and the block NW x that; U steps are issued back to back (U K-loads + U V-loads in flight per lane).
+// Each lane group keeps an online softmax (running max / sum / 8 output dims per lane); groups merge through LDS.
+// NW = 4 when B*nh alone oversubscribes the 256 CUs, 16 (one fat block per CU, 128 KiB of loads in flight) otherwise.
+// splits > 1 (B*nh < 256): the key range is cut into pieces, every block writes (max, sum, out[HD]) to the workspace
+// and attn_decode_merge_kernel combines them (a kernel boundary is the cheapest device-wide release/acquire here: a
+// per-block agent-scope fence costs an L2 write-back per block on a multi-XCD part).
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc,
+                                                               bf16_t* o, const uint8_t* key_mask, int nh, int ctx_arg,
+                                                               const int32_t* ctx_ptr, int max_ctx, float scale_log2e, float* ws_part) {
+  constexpr int LPK = HD / 8;            // lanes per key
+  constexpr int KPW = 64 / LPK;          // keys per wave step
+  constexpr int NG = NW * KPW;           // lane groups (= keys per block step)
+  constexpr int U = 4;
+  __shared__ float sm_m[NG], sm_l[NG];
+  __shared__ __attribute__((aligned(16))) float sm_acc[NG][HD];
   const int ctx = ctx_ptr ? min(ctx_ptr[0] + 1, max_ctx) : ctx_arg;   // device-resident: keys 0..pos (graph replay)
-  extern __shared__ float sm[];          // [ctx] probabilities + [4*HD] partial outputs + [4] reduce
-  float* prob = sm;
-  float* part = sm + max_ctx;
-  float* red = part + 4 * HD;
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const size_t row_stride = (size_t)nh * HD;
-  const bf16_t* qp = q + (size_t)b * ldq + h * HD;
-  float qf[HD];
+  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z, splits = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane / LPK, d = lane % LPK;
+  const int per = (((ctx + splits - 1) / splits) + NG - 1) / NG * NG;
+  const int s0 = split * per, s1 = min(ctx, s0 + per);
+
+  float qf[8];
+  unpack8(*(const uint4*)(q + (size_t)b * ldq + h * HD + d * 8), qf);
 #pragma unroll
-  for (int i = 0; i < HD / 8; ++i) unpack8(*(const uint4*)(qp + i * 8), qf + i * 8);
-  float mx = -1.0e30f;
-  for (int j = tid; j < ctx; j += 256) {
-    float s = -1.0e30f;
-    if (!key_mask || key_mask[(size_t)b * max_ctx + j]) {
-      const bf16_t* kp = kc + ((size_t)b * max_ctx + j) * row_stride + h * HD;
-      float acc = 0.f;
+  for (int e = 0; e < 8; ++e) qf[e] *= scale_log2e;
+  const size_t seq = ((size_t)b * nh + h) * max_ctx;
+  const bf16_t* kb = kc + seq * HD + d * 8;
+  const bf16_t* vb = vc + seq * HD + d * 8;
+  const uint8_t* km = key_mask ? key_mask + (size_t)b * max_ctx : nullptr;
+
+  float m = -1.0e30f, l = 0.f, acc[8];
 #pragma unroll
-      for (int i = 0; i < HD / 8; ++i) {
-        float kf[8];
-        unpack8(*(const uint4*)(kp + i * 8), kf);
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int jb = s0 + wave * KPW; jb < s1; jb += NG * U) {
+    uint4 kk[U], vv[U];
+    bool ok[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += kf[e] * qf[i * 8 + e];
+    for (int u = 0; u < U; ++u) {
+      const int j = jb + u * NG + g;
+      ok[u] = j < s1 && (!km || km[j]);
+      kk[u] = make_uint4(0, 0, 0, 0);
+      vv[u] = make_uint4(0, 0, 0, 0);
+      if (j < s1) {                      // slots >= ctx are never read (uninitialised memory may hold NaN bit patterns)
+        kk[u] = *(const uint4*)(kb + (size_t)j * HD);
+        vv[u] = *(const uint4*)(vb + (size_t)j * HD);
       }
-      s = acc * scale;
     }
-    prob[j] = s;
-    mx = fmaxf(mx, s);
-  }
-  mx = block_max_256(mx, red);
-  float se = 0.f;
-  for (int j = tid; j < ctx; j += 256) {
-    const float s = prob[j];
-    const float e = (s > -1.0e29f) ? __expf(s - mx) : 0.f;
-    prob[j] = e;
-    se += e;
-  }
-  se = block_sum_256(se, red);
-  __syncthreads();
-  const int grp = tid >> 6, lane = tid & 63;
-  constexpr int DPL = HD / 64;           // dims per lane
-  float acc[DPL];
+    float sc[U];
+    float mn = m;
 #pragma unroll
-  for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
-  for (int j = grp; j < ctx; j += 4) {
-    const float pj = prob[j];
-    const bf16_t* vp = vc + ((size_t)b * max_ctx + j) * row_stride + h * HD + lane * DPL;
+    for (int u = 0; u < U; ++u) {
+      float kf[8];
+      unpack8(kk[u], kf);
+      float a = 0.f;
 #pragma unroll
-    for (int e = 0; e < DPL; ++e) acc[e] += pj * bf2f(vp[e]);
+      for (int e = 0; e < 8; ++e) a += kf[e] * qf[e];
+#pragma unroll
+      for (int off = 1; off < LPK; off <<= 1) a += __shfl_xor(a, off, 64);
+      sc[u] = ok[u] ? a : -1.0e30f;
+      mn = fmaxf(mn, sc[u]);
+    }
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pj = ok[u] ? exp2f(sc[u] - m) : 0.f;
+      float vf[8];
+      unpack8(vv[u], vf);
+      l += pj;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pj * vf[e];
+    }
   }
-#pragma unroll
-  for (int e = 0; e < DPL; ++e) part[grp * HD + lane * DPL + e] = acc[e];
+  const int grp = wave * KPW + g;
+  if (d == 0) { sm_m[grp] = m; sm_l[grp] = l; }
+  *(float4*)&sm_acc[grp][d * 8] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *(float4*)&sm_acc[grp][d * 8 + 4] = make_float4(acc[4], acc[5], acc[6], acc[7]);
   __syncthreads();
   if (tid < HD) {
-    const float v = (part[tid] + part[HD + tid] + part[2 * HD + tid] + part[3 * HD + tid]) / (se > 0.f ? se : 1.f);
-    o[(size_t)b * row_stride + h * HD + tid] = f2bf(v);
+    float M = -1.0e30f, Lsum = 0.f, O = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < NG; ++i) M = fmaxf(M, sm_m[i]);
+#pragma unroll 4
+    for (int i = 0; i < NG; ++i) {
+      const float w = exp2f(sm_m[i] - M);
+      Lsum += sm_l[i] * w;
+      O += sm_acc[i][tid] * w;
+    }
+    const int bh = b * nh + h;
+    if (splits == 1) {
+      o[(size_t)bh * HD + tid] = f2bf(Lsum > 0.f ? O / Lsum : 0.f);
+    } else {
+      float* part = ws_part + ((size_t)bh * splits + split) * (HD + 2);
+      part[2 + tid] = O;
+      if (tid == 0) { part[0] = M; part[1] = Lsum; }
+    }
+  }
+}
+
+// one block per (sequence, head): out = sum_s w_s O_s / sum_s w_s L_s, w_s = 2^(M_s - max M)
+__global__ void attn_decode_merge_kernel(const float* ws_part, bf16_t* o, int splits, int HD) {
+  const int bh = blockIdx.x, tid = threadIdx.x;
+  const float* p0 = ws_part + (size_t)bh * splits * (HD + 2);
+  float MM = -1.0e30f;
+  for (int i = 0; i < splits; ++i) MM = fmaxf(MM, p0[(size_t)i * (HD + 2)]);
+  float LL = 0.f, OO = 0.f;
+  for (int i = 0; i < splits; ++i) {
+    const float* pi = p0 + (size_t)i * (HD + 2);
+    const float w = exp2f(pi[0] - MM);
+    LL += pi[1] * w;
+    OO += pi[2 + tid] * w;
+  }
+  o[(size_t)bh * HD + tid] = f2bf(LL > 0.f ? OO / LL : 0.f);
+}
+
+// ---- decode-step RoPE + KV-cache append: q rotated in place, k rotated into k_cache[b,h,pos,:], v copied into
+// v_cache[b,h,pos,:] (pos = pos_ptr[0], device-resident).  qkv rows are [q(H) | k(H) | v(H)].  One launch replaces
+// rope + 2x(gather, scatter).
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(bf16_t* qkv, int ld, const float* cosb, const float* sinb, bf16_t* kc,
+                                                              bf16_t* vc, int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx) {
+  const int half = hd / 2, cpr = half / 8;        // chunks (8 pairs) per head
+  const int total = B * nh * cpr;
+  const int pos = pos_ptr[0];
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int b = idx / (nh * cpr), rem = idx % (nh * cpr);
+    const int h = rem / cpr, i0 = (rem % cpr) * 8;
+    const float* cp = cosb + (size_t)pos * half + i0;
+    const float* sp = sinb + (size_t)pos * half + i0;
+    const size_t H = (size_t)nh * hd;
+    bf16_t* qp = qkv + (size_t)b * ld + h * hd;
+    const bf16_t* kp = qp + H;
+    const bf16_t* vp = qp + 2 * H;
+    const size_t crow = (((size_t)b * nh + h) * max_ctx + pos) * hd;
+    float x1[8], x2[8], o1[8], o2[8];
+    unpack8(*(const uint4*)(qp + i0), x1);
+    unpack8(*(const uint4*)(qp + half + i0), x2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o1[j] = x1[j] * cp[j] - x2[j] * sp[j]; o2[j] = x2[j] * cp[j] + x1[j] * sp[j]; }
+    *(uint4*)(qp + i0) = pack8(o1);
+    *(uint4*)(qp + half + i0) = pack8(o2);
+    unpack8(*(const uint4*)(kp + i0), x1);
+    unpack8(*(const uint4*)(kp + half + i0), x2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o1[j] = x1[j] * cp[j] - x2[j] * sp[j]; o2[j] = x2[j] * cp[j] + x1[j] * sp[j]; }
+    *(uint4*)(kc + crow + i0) = pack8(o1);
+    *(uint4*)(kc + crow + half + i0) = pack8(o2);
+    *(uint4*)(vc + crow + i0) = *(const uint4*)(vp + i0);
+    *(uint4*)(vc + crow + half + i0) = *(const uint4*)(vp + half + i0);
   }
 }
 
@@ -84,7 +180,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 
 // step_ptr (nullable): device-resident step counter (graph replay) used for the RNG stream and, with `history`
 // ([max_steps, rows]), for the slot the token is appended to.  eos_id >= 0: a row that samples EOS is marked finished.
-__global__ __launch_bounds__(256) void sample_kernel(const float* logits, int ldl, int V, float inv_temp, int top_k, float top_p,
+__global__ __launch_bounds__(256) void sample_kernel_generic(const float* logits, int ldl, int V, float inv_temp, int top_k, float top_p,
                                                       uint64_t seed, uint64_t step_arg, const int32_t* step_ptr, uint8_t* finished,
                                                       int pad_id, int eos_id, int32_t* out, int32_t* history) {
   const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : step_arg;
@@ -182,20 +278,260 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* logits, int ld
   }
 }
 
+
+// ---- fast sampler: the whole row lives in LDS ------------------------------------------------------------------------
+// 1024 threads per row; the temperature-scaled row (V <= 32768 floats = 128 KiB of the CU's 160 KiB LDS) is read from
+// memory ONCE, every later pass is a conflict-free stride-1 LDS sweep (the generic kernel makes ~66 passes over memory).
+// Same filter semantics as the generic kernel:
+//   top-k : 4-level radix select (8-bit digits of the monotone key) with an LDS histogram of counts ->
+//           thr = key of the k-th largest logit (ties kept);
+//   top-p : the same descent over a histogram of probability MASS -> largest t2 with mass(thr <= key < t2) <= (1-p)*Z.
+//           Mass is fixed-point (2^-40 of the row maximum) in uint64, so LDS atomics are exact and order-independent:
+//           the draw is deterministic for (seed, step, row);
+//   draw  : block-wide exclusive scan of the per-thread kept mass, the owner thread walks its <= 32 values.
+constexpr int SAMP_T = 1024, SAMP_W = SAMP_T / 64, SAMP_MAXV = 32768;
+constexpr float SAMP_FIX = 1099511627776.0f;   // 2^40
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((long long)v, o, 64);
+  return v;
+}
+
+// digit choice for one radix level, executed by wave 0: hist[256] (uint64) -> LDS result {digit, carried sum}.
+//   DESC (top-k):  largest digit d with base + sum(hist[d..255]) >= need;   carry = base + sum(hist[d+1..255])
+//   !DESC (top-p): largest digit d with base + sum(hist[0..d-1]) <= need;   carry = base + sum(hist[0..d-1])
+template <bool DESC>
+__device__ __forceinline__ void pick_digit(const uint64_t* hist, uint64_t base, uint64_t need, int lane, uint32_t* out_digit,
+                                           uint64_t* out_carry) {
+  uint64_t c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = hist[lane * 4 + i];
+  const uint64_t s = c[0] + c[1] + c[2] + c[3];
+  uint64_t incl = s;                       // DESC: sum over lanes >= lane ; else: sum over lanes <= lane
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t t = (uint64_t)(DESC ? __shfl_down((long long)incl, off, 64) : __shfl_up((long long)incl, off, 64));
+    if (DESC ? (lane + off < 64) : (lane >= off)) incl += t;
+  }
+  const uint64_t outside = base + incl - s;   // DESC: bins above this lane's 4 ; else: bins below this lane's 4
+  uint64_t S[4];                              // DESC: base + sum(hist[bin..255]) ; else: base + sum(hist[0..bin-1])
+  if (DESC) {
+    S[3] = outside + c[3]; S[2] = S[3] + c[2]; S[1] = S[2] + c[1]; S[0] = S[1] + c[0];
+  } else {
+    S[0] = outside; S[1] = S[0] + c[0]; S[2] = S[1] + c[1]; S[3] = S[2] + c[2];
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cnt += DESC ? (S[i] >= need) : (S[i] <= need);
+  int total = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  const int dsel = max(total - 1, 0);          // satisfying bins form the prefix [0..dsel]
+  if (lane == (dsel >> 2)) {
+    const int i = dsel & 3;
+    *out_digit = (uint32_t)dsel;
+    *out_carry = DESC ? (S[i] - c[i]) : S[i];
+  }
+}
+
+__global__ __launch_bounds__(SAMP_T) void sample_kernel_fast(const float* logits, int ldl, int V, float inv_temp, int top_k, float top_p,
+                                                             uint64_t seed, uint64_t step_arg, const int32_t* step_ptr, uint8_t* finished,
+                                                             int pad_id, int eos_id, int32_t* out, int32_t* history) {
+  extern __shared__ __attribute__((aligned(16))) float zs[];     // [V] scaled logits
+  const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : step_arg;
+  __shared__ uint64_t hist[256];
+  __shared__ uint64_t wsum[SAMP_W];
+  __shared__ float wmax[SAMP_W];
+  __shared__ uint32_t s_digit;
+  __shared__ uint64_t s_carry;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (finished && finished[row]) {
+    if (tid == 0) {
+      out[row] = pad_id;
+      if (history) history[step * gridDim.x + row] = pad_id;
+    }
+    return;
+  }
+  const float4* z4 = (const float4*)(logits + (size_t)row * ldl);
+  float mx = -3.0e38f;
+  for (int gi = tid; gi < (V >> 2); gi += SAMP_T) {
+    float4 t = z4[gi];
+    t.x *= inv_temp; t.y *= inv_temp; t.z *= inv_temp; t.w *= inv_temp;
+    *(float4*)&zs[gi * 4] = t;
+    mx = fmaxf(fmaxf(mx, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  mx = wmax[0];
+#pragma unroll
+  for (int i = 1; i < SAMP_W; ++i) mx = fmaxf(mx, wmax[i]);
+  auto qmass = [&](float x) -> uint64_t { return (uint64_t)(__expf(x - mx) * SAMP_FIX); };   // exp(-inf) = 0
+  auto block_sum = [&](uint64_t x) -> uint64_t {
+    x = wave_sum_u64(x);
+    __syncthreads();
+    if (lane == 0) wsum[wave] = x;
+    __syncthreads();
+    uint64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < SAMP_W; ++i) t += wsum[i];
+    return t;
+  };
+
+  uint32_t thr = 0;   // keep tokens with key >= thr
+  if (top_k > 0 && top_k < V) {
+    uint32_t prefix = 0, pmask = 0;
+    uint64_t above = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int base = 0; base < V; base += SAMP_T) {
+        const int i = base + tid;
+        const uint32_t k = i < V ? fkey(zs[i]) : 0u;
+        bool mine = i < V && (k & pmask) == prefix;
+        const uint32_t dg = (k >> shift) & 255u;
+        // wave-aggregated counting for crowded bins (the top byte of a float key takes only a few values)
+#pragma unroll 1
+        for (int it = 0; it < 3; ++it) {
+          const uint64_t act = __ballot(mine);
+          if (!act) break;
+          const int lead = __ffsll((long long)act) - 1;
+          const uint32_t ldg = __shfl(dg, lead, 64);
+          const uint64_t same = __ballot(mine && dg == ldg);
+          if (lane == lead) atomicAdd((unsigned long long*)&hist[ldg], (unsigned long long)__popcll(same));
+          if (dg == ldg) mine = false;
+        }
+        if (mine) atomicAdd((unsigned long long*)&hist[dg], 1ull);
+      }
+      __syncthreads();
+      if (wave == 0) pick_digit<true>(hist, above, (uint64_t)top_k, lane, &s_digit, &s_carry);
+      __syncthreads();
+      prefix |= s_digit << shift;
+      pmask |= 255u << shift;
+      above = s_carry;
+      __syncthreads();
+    }
+    thr = prefix;
+  }
+  if (top_p < 1.0f) {
+    uint64_t zk = 0;
+    for (int i = tid; i < V; i += SAMP_T) {
+      const float x = zs[i];
+      if (fkey(x) >= thr) zk += qmass(x);
+    }
+    zk = block_sum(zk);
+    const uint64_t budget = (uint64_t)((1.0 - (double)top_p) * (double)zk);
+    uint32_t prefix = 0, pmask = 0;
+    uint64_t below = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += SAMP_T) {
+        const float x = zs[i];
+        const uint32_t k = fkey(x);
+        if (k >= thr && (k & pmask) == prefix) {
+          const uint64_t qm = qmass(x);
+          if (qm) atomicAdd((unsigned long long*)&hist[(k >> shift) & 255u], (unsigned long long)qm);
+        }
+      }
+      __syncthreads();
+      if (wave == 0) pick_digit<false>(hist, below, budget, lane, &s_digit, &s_carry);
+      __syncthreads();
+      prefix |= s_digit << shift;
+      pmask |= 255u << shift;
+      below = s_carry;
+      __syncthreads();
+    }
+    thr = max(thr, prefix);
+  }
+  // multinomial over the kept set; cumulative order = (thread, then index) — any fixed order is a valid draw
+  uint64_t local = 0;
+  for (int i = tid; i < V; i += SAMP_T) {
+    const float x = zs[i];
+    if (fkey(x) >= thr) local += qmass(x);
+  }
+  uint64_t incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t t = (uint64_t)__shfl_up((long long)incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint64_t wave_base = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < SAMP_W; ++i) {
+    if (i < wave) wave_base += wsum[i];
+    total += wsum[i];
+  }
+  const uint64_t r = mix64(mix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (uint64_t)row);
+  const uint64_t r24 = r >> 40;                                   // u = r24 / 2^24 in [0, 1)
+  const uint64_t target = (total >> 24) * r24 + (((total & 0xffffffull) * r24) >> 24);   // floor(u * total) < total
+  const uint64_t start = wave_base + incl - local;
+  if (total == 0) {
+    if (tid == 0) {
+      out[row] = pad_id;
+      if (history) history[step * gridDim.x + row] = pad_id;
+    }
+    return;
+  }
+  if (local > 0 && start <= target && target < start + local) {
+    uint64_t run = start;
+    int pick = pad_id;
+    for (int i = tid; i < V && run <= target; i += SAMP_T) {
+      const float x = zs[i];
+      if (fkey(x) >= thr) {
+        const uint64_t qm = qmass(x);
+        if (qm) pick = i;
+        run += qm;
+      }
+    }
+    out[row] = pick;
+    if (history) history[step * gridDim.x + row] = pick;
+    if (finished && eos_id >= 0 && pick == eos_id) finished[row] = 1;
+  }
+}
+
 }  // namespace
+
+static int attn_decode_splits(int B, int nh, int max_ctx) {
+  if (B * nh >= 256) return 1;
+  int splits = (256 + B * nh - 1) / (B * nh);
+  splits = std::min(splits, std::max(1, max_ctx / 256));
+  return std::max(1, std::min(splits, 16));
+}
+size_t attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx) {
+  const int splits = attn_decode_splits(B, nh, max_ctx);
+  return splits == 1 ? 0 : (size_t)B * nh * splits * (hd + 2) * 4;
+}
 
 hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* o, const uint8_t* key_mask,
                               int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx, int ldq, float scale,
-                              hipStream_t st) {
+                              void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  const size_t smem = (size_t)(max_ctx + 4 * hd + 4) * sizeof(float);
-  if (smem > 64 * 1024) return hipErrorInvalidValue;
-  if (hd == 128)
-    hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, scale);
-  else if (hd == 64)
-    hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(nh, B), dim3(256), smem, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, scale);
-  else
-    return hipErrorInvalidValue;
+  if (hd != 64 && hd != 128) return hipErrorInvalidValue;
+  int splits = attn_decode_splits(B, nh, max_ctx);
+  if (splits > 1 && (!workspace || workspace_bytes < attn_decode_workspace_bytes(B, nh, hd, max_ctx))) splits = 1;
+  float* part = (float*)workspace;
+  const float sl2 = scale * 1.4426950408889634f;
+  const bool fat = B * nh * splits < 1024;       // few blocks: 16 waves each
+  const dim3 gr(nh, B, splits);
+#define AD(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), gr, dim3(NW_ * 64), 0, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, sl2, part)
+  if (hd == 128) { if (fat) AD(128, 16); else AD(128, 4); }
+  else           { if (fat) AD(64, 16); else AD(64, 4); }
+#undef AD
+  if (splits > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(B * nh), dim3(hd), 0, st, part, o, splits, hd);
+  return hipGetLastError();
+}
+
+hipError_t launch_rope_kv_append(bf16_t* qkv, int ld, const float* cosb, const float* sinb, bf16_t* kc, bf16_t* vc, int B, int nh,
+                                 int hd, const int32_t* pos_ptr, int max_ctx, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  if (hd % 16 || ld % 8 || !pos_ptr) return hipErrorInvalidValue;
+  const int total = B * nh * (hd / 16);
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3((total + 255) / 256), dim3(256), 0, st, qkv, ld, cosb, sinb, kc, vc, B, nh, hd, pos_ptr, max_ctx);
   return hipGetLastError();
 }
 
@@ -203,7 +539,17 @@ hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float te
                          uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
                          int32_t* out, int32_t* history, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_kernel, dim3(rows), dim3(256), 0, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed, step,
-                     step_ptr, finished, pad_id, eos_id, out, history);
+  const bool fast = V % 4 == 0 && ldl % 4 == 0 && V <= SAMP_MAXV && ((uintptr_t)logits & 15) == 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)sample_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, SAMP_MAXV * 4);
+    attr_set = true;
+  }
+  if (fast)
+    hipLaunchKernelGGL(sample_kernel_fast, dim3(rows), dim3(SAMP_T), (size_t)V * 4, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed,
+                       step, step_ptr, finished, pad_id, eos_id, out, history);
+  else
+    hipLaunchKernelGGL(sample_kernel_generic, dim3(rows), dim3(256), 0, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed,
+                       step, step_ptr, finished, pad_id, eos_id, out, history);
   return hipGetLastError();
 }

@@ -863,8 +863,11 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
-hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
-  if (a.M <= 0) return hipSuccess;
+hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
+  if (a_in.M <= 0) return hipSuccess;
+  GemmNTArgs a = a_in;
+  const bool stream_hint = (a.act & OPADPO_GEMM_STREAM) != 0;
+  a.act &= 0xff;
   if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
@@ -879,7 +882,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st) {
     attr_set = true;
   }
   // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
-  if (a.M <= 64 && (g_gemm_variant == 10 || g_gemm_variant == 15)) {
+  if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15)) {
     const bool wide = a.N % 32 == 0 && a.N / 32 >= 512 && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) &&
                       (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
     const int mf = (a.M + 15) / 16;

@@ -71,13 +71,13 @@ class Generator:
         L.call("opadpo_embed_splice", L.ptr(ids), L.ptr(tmask), L.ptr(b.embed), L.ptr(image_feats.contiguous()), L.ptr(feat_row),
                None, L.ptr(sv.x[0]), 1, L.ptr(km_prefill), B, Q, P, H, IMAGE_TOKEN_INDEX, st)
         key_mask[:, :Lp] = km_prefill
-        kc = e((d.n_layers, B, max_ctx, H))
-        vc = e((d.n_layers, B, max_ctx, H))
+        kc = e((d.n_layers, B, nh, max_ctx, hd))      # head-major: one (sequence, head) is one contiguous key stream
+        vc = e((d.n_layers, B, nh, max_ctx, hd))
 
         def kv_hook(i, qkv):      # cache fill = strided device copy (plumbing)
-            q3 = qkv.view(B, Lp, 3 * H)
-            kc[i, :, :Lp].copy_(q3[:, :, H:2 * H])
-            vc[i, :, :Lp].copy_(q3[:, :, 2 * H:])
+            q5 = qkv.view(B, Lp, 3, nh, hd)
+            kc[i, :, :, :Lp].copy_(q5[:, :, 1].transpose(1, 2))
+            vc[i, :, :, :Lp].copy_(q5[:, :, 2].transpose(1, 2))
 
         cos, sin = b.rope_tables(max_ctx)
         for i in range(d.n_layers):
@@ -85,8 +85,8 @@ class Generator:
         xf = sv.x[d.n_layers & 1]
         last = (torch.arange(B, device=dev, dtype=torch.int32) * Lp + (Lp - 1)).contiguous()
         # ---- decode: ONE step captured in a HIP graph and replayed per token -----------------------------------
-        # Everything that changes from step to step lives in device memory (position / step counter, cache slot
-        # indices, current tokens, finished flags), so the ~15 launches x n_layers of a step are recorded once and
+        # Everything that changes from step to step lives in device memory (position / step counter,
+        # current tokens, finished flags), so the ~10 launches x n_layers of a step are recorded once and
         # replayed with a single hipGraphLaunch (the eager loop was host-launch-bound: ~480 Python->C calls per token).
         key_mask[:, Lp:] = 1                       # future slots: valid as soon as ctx (device counter) reaches them
         x = e((B, H), torch.float32)
@@ -95,16 +95,15 @@ class Generator:
         n1, qkv, t_qkv, att, t_o = e((B, H)), e((B, 3 * H)), e((B, 3 * r)), e((B, H)), e((B, r))
         hb, n2, t_gu, gu, act, t_d = e((B, H), torch.float32), e((B, H)), e((B, 2 * r)), e((B, 2 * F)), e((B, F)), e((B, r))
         rstd = e((B,), torch.float32)
-        kv_tmp = e((B, H))
         emb = e((B, H))
+        ws_bytes = int(L.load().opadpo_attn_decode_workspace_bytes(B, nh, hd, max_ctx))
+        ws = torch.zeros(max(ws_bytes, 4), dtype=torch.uint8, device=dev)         # split-KV scratch
         logits = e((B, V), torch.float32)
         cur_tok = torch.zeros(B, dtype=torch.int32, device=dev)
         finished = torch.zeros(B, dtype=torch.uint8, device=dev)
         history = torch.full((max_new_tokens, B), pad_token_id, dtype=torch.int32, device=dev)
-        rows_b = torch.arange(B, device=dev, dtype=torch.int32)
         step_d = torch.zeros(1, dtype=torch.int32, device=dev)                     # tokens sampled so far
         pos_d = torch.full((1,), Lp - 1, dtype=torch.int32, device=dev)            # position of the newest cached key
-        slot = (rows_b * max_ctx + (Lp - 1)).contiguous()                          # its cache row per sequence
         s = d.lora_scale
         ad = self.adapter
         eos_arg = -1 if suppress_eos else eos_token_id
@@ -121,7 +120,6 @@ class Generator:
         def decode_step():
             st = L.stream()
             pos_d.add_(1)
-            slot.add_(1)
             L.call("opadpo_gather_rows", L.ptr(b.embed), H, L.ptr(cur_tok), L.ptr(emb), B, H, st)
             cur, nx = emb, x
             for i in range(d.n_layers):
@@ -132,12 +130,10 @@ class Generator:
                     L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=ad.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
                 else:
                     L.gemm_nt(n1, w["wqkv"], qkv)
-                L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), B, 1, 2 * nh, hd, 0, L.ptr(pos_d), st)
-                for src_off, cache in ((H, kc[i]), (2 * H, vc[i])):
-                    L.call("opadpo_gather_rows", qkv.data_ptr() + 2 * src_off, 3 * H, L.ptr(rows_b), L.ptr(kv_tmp), B, H, st)
-                    L.call("opadpo_scatter_rows", L.ptr(kv_tmp), L.ptr(slot), L.ptr(cache), H, B, H, st)
+                L.call("opadpo_rope_kv_append", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), L.ptr(kc[i]), L.ptr(vc[i]), B, nh, hd,
+                       L.ptr(pos_d), max_ctx, st)
                 L.call("opadpo_attn_decode", L.ptr(qkv), 3 * H, L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(att), L.ptr(key_mask), B, nh, hd,
-                       0, L.ptr(pos_d), max_ctx, hd ** -0.5, st)
+                       0, L.ptr(pos_d), max_ctx, hd ** -0.5, L.ptr(ws), ws_bytes, st)
                 if ad is not None:
                     L.gemm_nt(att, ad.w(i, "a_o"), t_o, alpha=s)
                     L.gemm_nt(att, w["wo"], hb, a2=t_o, b2=ad.w(i, "b_o"), residual=cur)
@@ -148,20 +144,21 @@ class Generator:
             head(cur)
 
         L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
-        head(hs)                                   # token 0 from the prefill logits
-        graph = None
-        for step in range(1, max_new_tokens):
-            if step == 2 and self.use_graph and max_new_tokens > 3:
-                torch.cuda.synchronize()           # step 1 ran eagerly (warm-up of every kernel of the step)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    decode_step()                  # recorded, not executed
-            if graph is not None:
-                graph.replay()
-            else:
-                decode_step()
-            if step % 32 == 0 and bool(finished.all()):
-                break
+        with L.decode_schedule():                  # M = B <= 64 GEMMs: weight-streaming kernel
+            head(hs)                               # token 0 from the prefill logits
+            graph = None
+            for step in range(1, max_new_tokens):
+                if step == 2 and self.use_graph and max_new_tokens > 3:
+                    torch.cuda.synchronize()       # step 1 ran eagerly (warm-up of every kernel of the step)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        decode_step()              # recorded, not executed
+                if graph is not None:
+                    graph.replay()
+                else:
+                    decode_step()
+                if step % 32 == 0 and bool(finished.all()):
+                    break
         return history.t().contiguous().to(torch.int64)
 
     def rollout(self, queries, query_attn_masks, images, *, response_len: int, temperature: float = 1.0, top_k: int = 30,

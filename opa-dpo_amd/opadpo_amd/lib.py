@@ -46,10 +46,11 @@ SIGNATURES = {
     "opadpo_head_bwd": [_p, _i, _p, _p, _p, _f, _p, _i, _i, _i, _p],
     "opadpo_sumsq": [_p, _sz, _p, _p],
     "opadpo_adamw": [_p, _p, _p, _p, _p, _sz, _d, _d, _d, _d, _d, _i, _p, _d, _d, _p],
-    "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _f, _p],
+    "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _f, _p, _sz, _p],
+    "opadpo_rope_kv_append": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
     "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _p, _i, _i, _p, _p, _p],
 }
-OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags"]
+OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes"]
 
 _lib: Optional[C.CDLL] = None
 
@@ -75,6 +76,8 @@ def load() -> C.CDLL:
     lib.opadpo_last_error.restype = C.c_char_p
     lib.opadpo_set_flags.argtypes = [_i, _i]
     lib.opadpo_set_flags.restype = None
+    lib.opadpo_attn_decode_workspace_bytes.argtypes = [_i, _i, _i, _i]
+    lib.opadpo_attn_decode_workspace_bytes.restype = _sz
     if lib.opadpo_abi_version() != 1:
         raise OpadpoError("ABI version mismatch")
     _lib = lib
@@ -125,6 +128,22 @@ def _chk(t: torch.Tensor, dtype, name: str):
 PROFILE = None
 
 
+GEMM_STREAM = 0x100
+_stream_weights = False
+
+
+class decode_schedule:
+    """with decode_schedule(): every gemm_nt with M <= 64 takes the weight-streaming kernel (OPADPO_GEMM_STREAM)."""
+
+    def __enter__(self):
+        global _stream_weights
+        self._prev, _stream_weights = _stream_weights, True
+
+    def __exit__(self, *exc):
+        global _stream_weights
+        _stream_weights = self._prev
+
+
 def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
             b2: Optional[torch.Tensor] = None, a2_group_n: int = 0, a2_group_stride: int = 0,
             a1_group_n: int = 0, a1_group_stride: int = 0, k1: Optional[int] = None, residual: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
@@ -151,8 +170,8 @@ def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Option
     call("opadpo_gemm_nt", ptr(a1), a1.stride(0), ptr(b1), b1.stride(0), K1,
          ptr(a2), a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
          a2_group_n, a2_group_stride, a1_group_n, a1_group_stride, ptr(out), out.stride(0), int(out_f32),
-         ptr(residual), residual.stride(0) if residual is not None else 0, int(res_f32), ptr(bias), M, N, float(alpha), act,
-         stream())
+         ptr(residual), residual.stride(0) if residual is not None else 0, int(res_f32), ptr(bias), M, N, float(alpha),
+         act | (GEMM_STREAM if _stream_weights else 0), stream())
     if PROFILE is not None:
         e1.record()
         PROFILE.append((2.0 * M * N * (K1 + K2), e0, e1))

@@ -17,7 +17,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(int|void|const char\*)\s+(opadpo_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(int|void|size_t|const char\*)\s+(opadpo_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         types = []
         if args and args != "void":
@@ -42,9 +42,9 @@ def built_lib():
 
 def test_header_declares_the_path():
     protos = parse_header()
-    assert len(protos) >= 27
+    assert len(protos) >= 29
     for need in ("opadpo_gemm_nt", "opadpo_gemm_tn", "opadpo_attn_fwd", "opadpo_attn_bwd", "opadpo_head_fwd",
-                 "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_embed_splice"):
+                 "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_rope_kv_append", "opadpo_embed_splice"):
         assert need in protos
 
 

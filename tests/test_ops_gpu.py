@@ -75,7 +75,7 @@ def test_gemm_nt(L, glds, M, N, K1, K2, groups):
 def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
     """decode-sized GEMMs (M <= 64) take the weight-streaming kernel: in-workgroup split-K, LoRA tail as a second K
     segment, grouped tail columns, fused epilogue (alpha / bias / residual, bf16 and fp32 outputs)."""
-    L.set_flags(10, True)
+    L.set_flags(15, True)          # 15 = force the streaming kernel (product: OPADPO_GEMM_STREAM hint per call)
     a1, b1 = rnd(M, K1, scale=0.5, seed=1), rnd(N, K1, scale=0.5, seed=2)
     want = a1.float() @ b1.float().t()
     kw = {}
@@ -104,6 +104,10 @@ def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
     L.gemm_nt(a1, b1, o4, bias=bias, residual=res32, alpha=0.25, **kw)
     L.set_flags(10, True)
     assert relerr(o32, o4) < 1e-5
+    with L.decode_schedule():      # the per-call hint selects the same kernel: identical bits
+        o5 = torch.empty(M, N, device=dev())
+        L.gemm_nt(a1, b1, o5, bias=bias, residual=res32, alpha=0.25, **kw)
+    assert torch.equal(o5, o32)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9])
@@ -455,28 +459,68 @@ def test_adamw_and_sumsq(L):
         assert torch.equal(pb, p.to(BF))
 
 
-def test_attn_decode(L):
-    B, nh, hd, ctx, max_ctx = 3, 2, 128, 70, 96
+@pytest.mark.parametrize("B,nh,hd,ctx,max_ctx", [(3, 2, 128, 70, 96), (1, 4, 128, 900, 1024), (2, 2, 64, 333, 512), (40, 32, 128, 130, 160),
+                                                 (2, 3, 128, 1, 64), (8, 32, 128, 750, 768), (1, 1, 64, 2000, 2048)])
+def test_attn_decode(L, B, nh, hd, ctx, max_ctx):
+    """single-token attention over the head-major KV cache; split-KV path (few sequences -> workspace + merge launch)
+    and single-block path agree with torch fp32; the device-resident ctx pointer gives the same bits."""
     H = nh * hd
     q = rnd(B, H, seed=1)
-    kc, vc = rnd(B, max_ctx, H, seed=2), rnd(B, max_ctx, H, seed=3)
+    kc, vc = rnd(B, nh, max_ctx, hd, seed=2), rnd(B, nh, max_ctx, hd, seed=3)
+    kc[:, :, ctx:] = float("nan")          # slots beyond ctx are uninitialised memory in the product: must never be read
+    vc[:, :, ctx:] = float("nan")
     km = torch.ones(B, max_ctx, dtype=torch.uint8, device=dev())
-    km[0, :4] = 0
-    o = torch.empty(B, H, dtype=BF, device=dev())
-    L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o.data_ptr(), km.data_ptr(), B, nh, hd, ctx,
-           None, max_ctx, hd ** -0.5, L.stream())
-    o2 = torch.empty_like(o)
+    km[0, : min(4, ctx - 1)] = 0
+    if ctx > 40:
+        km[B - 1, 17:33] = 0
+    ws_bytes = int(L.load().opadpo_attn_decode_workspace_bytes(B, nh, hd, max_ctx))
+    ws = torch.zeros(max(ws_bytes, 4), dtype=torch.uint8, device=dev())
+    outs = []
+    for wsp, wsb in ((ws.data_ptr(), ws_bytes), (None, 0)):
+        o = torch.empty(B, H, dtype=BF, device=dev())
+        for _ in range(2):
+            L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o.data_ptr(), km.data_ptr(), B, nh, hd, ctx,
+                   None, max_ctx, hd ** -0.5, wsp, wsb, L.stream())
+        outs.append(o)
+    o2 = torch.empty_like(outs[0])
     posd = torch.tensor([ctx - 1], dtype=torch.int32, device=dev())        # device-resident newest-key position
     L.call("opadpo_attn_decode", q.data_ptr(), H, kc.data_ptr(), vc.data_ptr(), o2.data_ptr(), km.data_ptr(), B, nh, hd, 0,
-           posd.data_ptr(), max_ctx, hd ** -0.5, L.stream())
-    assert torch.equal(o, o2)
+           posd.data_ptr(), max_ctx, hd ** -0.5, ws.data_ptr(), ws_bytes, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], o2)
     qf = q.float().view(B, nh, hd)
-    kf = kc.float().view(B, max_ctx, nh, hd)[:, :ctx]
-    vf = vc.float().view(B, max_ctx, nh, hd)[:, :ctx]
-    sc = torch.einsum("bhd,bkhd->bhk", qf, kf) * hd ** -0.5
+    kf, vf = kc.float()[:, :, :ctx], vc.float()[:, :, :ctx]
+    sc = torch.einsum("bhd,bhkd->bhk", qf, kf) * hd ** -0.5
     sc = sc.masked_fill(~km[:, None, :ctx].bool(), float("-inf"))
-    want = torch.einsum("bhk,bkhd->bhd", torch.softmax(sc, -1), vf).reshape(B, H)
-    assert relerr(o, want) < 6e-3
+    want = torch.einsum("bhk,bhkd->bhd", torch.softmax(sc, -1), vf).reshape(B, H)
+    for o in outs:
+        assert relerr(o, want) < 6e-3
+
+
+def test_rope_kv_append(L):
+    """decode-step RoPE + cache append in one launch == rope kernel on q|k + copies into [b, h, pos, :]."""
+    B, nh, hd, max_ctx, pos = 5, 4, 128, 48, 29
+    H = nh * hd
+    qkv = rnd(B, 3 * H, seed=1)
+    half = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, device=dev()).float() / half))
+    ang = torch.arange(max_ctx, device=dev()).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    posd = torch.tensor([pos], dtype=torch.int32, device=dev())
+    ref = qkv.clone()
+    L.call("opadpo_rope", ref.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), B, 1, 2 * nh, hd, 0, posd.data_ptr(), L.stream())
+    kc = torch.zeros(B, nh, max_ctx, hd, dtype=BF, device=dev())
+    vc = torch.zeros_like(kc)
+    got = qkv.clone()
+    L.call("opadpo_rope_kv_append", got.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(), B, nh, hd,
+           posd.data_ptr(), max_ctx, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :H], ref[:, :H])                               # q rotated in place, same bits
+    assert torch.equal(kc[:, :, pos].reshape(B, H), ref[:, H:2 * H])         # rotated k appended
+    assert torch.equal(vc[:, :, pos].reshape(B, H), qkv[:, 2 * H:])          # v appended
+    kc[:, :, pos] = 0
+    vc[:, :, pos] = 0
+    assert float(kc.abs().max()) == 0.0 and float(vc.abs().max()) == 0.0     # nothing else touched
 
 
 def test_sampler_distribution(L):
@@ -515,6 +559,43 @@ def test_sampler_distribution(L):
     L.call("opadpo_sample", logits.data_ptr(), V, rows, V, 1.0, 0, 1.0, 99, 0, None, None, 0, -1, out2.data_ptr(), None, L.stream())
     emp = torch.bincount(out2.long(), minlength=V).float() / rows
     assert float((emp - torch.softmax(base, -1)).abs().max()) < 0.03
+
+
+@pytest.mark.parametrize("V", [32000, 32768, 40000, 1001])
+def test_sampler_filters_large_vocab(L, V):
+    """top-k / top-p thresholds at LLaVA's vocabulary size (register-resident radix select; V > 32768 or V % 4 != 0 take the
+    generic kernel): every draw lies inside the HF-filtered set, every member of that set is reachable."""
+    rows = 256
+    g = torch.Generator(device="cpu").manual_seed(V)
+    base = (torch.randn(V, generator=g) * 3).to(dev())
+    logits = base[None].repeat(rows, 1).contiguous()
+    for top_k, top_p, temp in ((30, 0.95, 1.0), (5, 1.0, 0.7), (0, 0.6, 1.0), (1, 1.0, 1.0)):
+        out = torch.empty(rows, dtype=torch.int32, device=dev())
+        picks = []
+        for step in range(8):
+            L.call("opadpo_sample", logits.data_ptr(), V, rows, V, temp, top_k, top_p, 77, step, None, None, 0, -1, out.data_ptr(), None, L.stream())
+            picks.append(out.clone())
+        picks = torch.cat(picks).long()
+        z = base.double() / temp
+        if top_k:
+            kth = torch.topk(z, top_k).values[-1]
+            z = z.masked_fill(z < kth, float("-inf"))
+        edge = torch.zeros(V, dtype=torch.bool, device=dev())
+        if top_p < 1.0:
+            sv, idx = torch.sort(z)
+            cum = torch.softmax(sv, -1).cumsum(-1)
+            rem = cum <= (1 - top_p)
+            rem[-1] = False
+            # a token whose removal hinges on the last bits of the cumulative mass may go either way (fp32 exp there, fp64 here)
+            edge[idx[(cum - (1 - top_p)).abs() < 1e-4]] = True
+            z[idx[rem]] = float("-inf")
+        p = torch.softmax(z, -1)
+        ok = (p > 0) | edge
+        assert bool(ok[picks].all()), f"V={V} k={top_k} p={top_p}: sampled a filtered token"
+        if top_k == 1:
+            assert bool((picks == int(base.argmax())).all())
+        emp = torch.bincount(picks, minlength=V).double() / picks.numel()
+        assert float((emp - p).abs().max()) < 0.06
 
 
 def test_errors_are_loud(L):
