@@ -1,13 +1,13 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel under the bench workload: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE),
-# --kernel-trace only (no sys/hip/hsa trace), one optimizer step of 8 pairs.  Summary -> gpurun_out/pmc_bench.json
+# --kernel-trace only (no sys/hip/hsa trace), one optimizer step of the default 15-pair micro-batch (PAIRS=...).  Summary -> gpurun_out/pmc_bench.json
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_bench
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --pairs 8 --accum 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-15} --accum 1 --no-cpu-baseline > $OUT/$C.log 2>&1
   echo "pass $C rc=$?"
 done
 python - <<PY
@@ -26,6 +26,12 @@ for k, d in agg.items():
     # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams -> x2 (MI355X_MICROARCH.md §HBM)
     res[k] = {"launches": len(f), "fetch_KiB_raw_mean": sum(f) / len(f), "write_KiB_mean": sum(w) / max(1, len(w)),
               "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / max(1, len(w))) * 1024}
-json.dump(res, open("$R/gpurun_out/pmc_bench.json", "w"), indent=1)
-print(json.dumps(res, indent=1))
+nt = [res[k] for k in ("gemm_nt_pp", "gemm_nt_x") if k in res]
+tot_l = sum(r["launches"] for r in nt)
+full = {"command": "tools/pmc_bench.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes; python bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-15} --accum 1)",
+        "correction": "FETCH_SIZE x2 on gfx950 for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section); values are KiB in the raw counters; the memory-side counters include Infinity-Cache hits",
+        "kernels": res,
+        "gemm_nt_avg_hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in nt) / max(1, tot_l)}
+json.dump(full, open("$R/gpurun_out/pmc_bench.json", "w"), indent=1)
+print(json.dumps(full, indent=1))
 PY
