@@ -76,14 +76,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    # 15 pairs = 30 stacked sequences x 1087 positions = 32610 rows = 128 M-tiles of 256: every big GEMM of the step then
-    # covers a whole number of 256-CU rounds (N=4096: 2048 tiles = 8 rounds; 8 pairs -> 1088 tiles = 4.25 rounds, -8 %).
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 15)), help="pairs per micro-batch per GPU")
+    # chosen + rejected of a pair are packed on their shared image + query prefix: one row of 703 + 2*384 = 1471 positions per
+    # pair and pass (the reference stacks 2 x 1087).  22 pairs = 32362 rows = 127 M-tiles of 256: every big GEMM of the step
+    # then covers (almost) a whole number of 256-CU rounds (N=4096: 2032 tiles = 7.94 rounds).  --no-pack: the reference's
+    # layout, 15 pairs = 30 x 1087 = 32610 rows = 128 M-tiles.
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 0)), help="pairs per micro-batch per GPU (0: 22 packed / 15 stacked)")
+    ap.add_argument("--no-pack", action="store_true", help="stack chosen / rejected as separate sequences (reference layout)")
     ap.add_argument("--accum", type=int, default=int(os.environ.get("OPADPO_BENCH_ACCUM", 1)), help="micro-batches per optimizer step")
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    pack = not args.no_pack
+    if args.pairs <= 0:
+        args.pairs = 22 if pack else 15
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -99,7 +105,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from opadpo_amd import lib as L
-    from opadpo_amd.dims import LlavaDims, pair_flops
+    from opadpo_amd.dims import LlavaDims, pair_flops, pair_flops_packed
     from opadpo_amd.losses import DPOArgs, pair_loss
     from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
     from opadpo_amd.optim import FlatAdamW
@@ -116,8 +122,8 @@ def main():
     pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
     torch.cuda.empty_cache()
-    policy = AutoregressivePolicy(eng, pol_ad, t_len)
-    ref_policy = AutoregressivePolicy(eng, ref_ad, t_len)
+    policy = AutoregressivePolicy(eng, pol_ad, t_len, pack_responses=pack)
+    ref_policy = AutoregressivePolicy(eng, ref_ad, t_len, pack_responses=pack)
     opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode)
     largs = DPOArgs()
     batches = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(args.accum)]
@@ -160,7 +166,8 @@ def main():
     pairs_per_step = args.pairs * args.accum * world
     value = pairs_per_step * args.steps / dt
     if rank == 0:
-        fl = pair_flops(d, q_len, t_len)
+        fl_ref = pair_flops(d, q_len, t_len)                      # reference formulation: 4 full sequences per pair
+        fl = pair_flops_packed(d, q_len, t_len, 2) if pack else fl_ref     # what this run executes
         roof = None
         if prof:
             tot_f = sum(p[0] for p in prof)
@@ -175,11 +182,14 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"LLaVA-1.5-{args.model.upper()} LoRA(r={d.lora_r}) DPO, 1xMI355X per rank, query {q_len} + response {t_len} "
                                       f"(L={q_len + t_len + d.n_patches - 1}), random-init weights, synthetic pairs",
+                          "response_layout": ("packed: chosen+rejected share one pass over the image+query prefix (segment-masked attention), "
+                                              f"{q_len + d.n_patches - 1}+2x{t_len} positions per pair and pass" if pack else
+                                              f"stacked: 2 x {q_len + t_len + d.n_patches - 1} positions per pair and pass (reference layout)"),
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
                           "global_pairs_per_step": pairs_per_step, "seq_len": q_len + t_len,
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
                           "loss": float(loss)},
-               "model_flops_per_pair_TF": fl / 1e12,
+               "executed_flops_per_pair_TF": fl / 1e12, "reference_layout_flops_per_pair_TF": fl_ref / 1e12,
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "roofline": roof}
         if args.model == "7b" and world == 1 and not args.no_cpu_baseline:

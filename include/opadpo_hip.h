@@ -62,16 +62,19 @@ int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float
 /* ---- attention (flash-attn 2.5.3 LlamaFlashAttention2 / CLIP eager attention) -------------------
  * q,k,v: element (s,pos,head,d) at ptr[(s*L+pos)*ld + head*hd + d]; o/dout with ldo.
  * key_mask [S,L] bytes (NULL = all keys valid); causal: key pos <= query pos.  hd in {64,128}.
- * lse [S,nh,L] fp32 (may be NULL in forward when no backward follows). */
+ * lse [S,nh,L] fp32 (may be NULL in forward when no backward follows).
+ * seg_len > 0 (needs causal): every row is [prefix of seg_prefix positions | response 0 | response 1 | ...], each response
+ * seg_len long; a response attends the prefix and itself only — the K responses of a DPO sample (rl_models.py:95-112 stacks
+ * them as K separate sequences) share ONE pass over the image + query prefix.  seg_len = 0: plain sequences. */
 int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
                     float* lse, const uint8_t* key_mask, int S, int L, int nh, int hd, int causal, float scale,
-                    void* stream);
+                    int seg_prefix, int seg_len, void* stream);
 /* dq/dk/dv: bf16 with the q/k/v addressing (ld); dq_f32: optional fp32 copy of dQ [S*L, nh*hd]
  * (NULL in the product path); delta: fp32 scratch [S,nh,L].  Atomic-free (two passes: dK/dV, dQ). */
 int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
                     const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
                     uint16_t* dq, uint16_t* dk, uint16_t* dv, float* dq_f32, float* delta,
-                    int S, int L, int nh, int hd, int causal, float scale, void* stream);
+                    int S, int L, int nh, int hd, int causal, float scale, int seg_prefix, int seg_len, void* stream);
 
 /* ---- norms / rotary / SwiGLU (transformers modeling_llama.py / modeling_clip.py) -------------- */
 /* x: bf16 or (x_f32) float32 rows; y bf16; rstd fp32 [rows] (nullable). */
@@ -82,9 +85,10 @@ int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint1
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
 /* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position
  * pos_base[0] + r % L; pos_base is a device int32 or NULL = 0 — device-resident so that a captured decode step can be
- * replayed); cos/sin: fp32 [max_pos, hd/2]; inverse=1 applies the transposed rotation (gradient). */
+ * replayed); cos/sin: fp32 [max_pos, hd/2]; inverse=1 applies the transposed rotation (gradient).  seg_len > 0: packed
+ * responses (see opadpo_attn_fwd) — positions >= seg_prefix + seg_len wrap back so every response starts at seg_prefix. */
 int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
-                int inverse, const int32_t* pos_base, void* stream);
+                int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, void* stream);
 int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream);   /* gu = [gate | up] */
 int opadpo_silu_mul_bwd(const uint16_t* dact, const uint16_t* gu, uint16_t* dgu, int rows, int F, void* stream);
 
@@ -103,6 +107,8 @@ int opadpo_vision_embed(const uint16_t* patches, const uint16_t* cls, const uint
 /* ---- data movement helpers ---------------------------------------------------------------------- */
 int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx, uint16_t* dst, int n, int H, void* stream);
 int opadpo_scatter_rows(const uint16_t* src, const int32_t* rows_idx, uint16_t* dst, int ld_dst, int n, int H, void* stream);
+/* dst[rows_idx[r], :H] += src[r, :H] (fp32; duplicate indices accumulate) */
+int opadpo_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, void* stream);
 int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream);
 int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream);
 int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream);

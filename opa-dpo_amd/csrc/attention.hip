@@ -125,6 +125,30 @@ __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask,
   }
 }
 
+// ---- packed responses with a shared prefix (seg_len > 0) ------------------------------------------------------------
+// A row holds [prefix (seg_prefix positions: image + query) | response 0 | response 1 | ...], every response seg_len long.
+// Response a attends the prefix and itself, never another response: for a query in segment a >= 1 the keys in
+// [seg_prefix, start of segment a) are excluded on top of the causal / key masks.  Causality makes the prefix states
+// independent of the responses, so this equals running prefix+response_a as separate sequences (what the reference does,
+// rl_models.py:95-112) while computing the prefix ONCE.  K/V tiles that lie wholly inside the excluded range are skipped.
+__device__ __forceinline__ int seg_xlo(const AttnArgs& p) { return p.seg_len > 0 ? p.seg_prefix : 0x7fffffff; }
+__device__ __forceinline__ int seg_qstart(const AttnArgs& p, int qpos) {     // first key of the query's own segment
+  if (p.seg_len <= 0) return 0x7fffffff;
+  return qpos >= p.seg_prefix + p.seg_len ? p.seg_prefix + ((qpos - p.seg_prefix) / p.seg_len) * p.seg_len : p.seg_prefix;
+}
+struct SegSkip {       // block-uniform: K/V tiles [lo, hi) are excluded for every row of the q tile starting at q0
+  int lo, hi;
+  __device__ __forceinline__ SegSkip(const AttnArgs& p, int q0, int n_kt) : lo(n_kt), hi(n_kt) {
+    if (p.seg_len > 0 && q0 >= p.seg_prefix + p.seg_len) {
+      const int qs = p.seg_prefix + ((q0 - p.seg_prefix) / p.seg_len) * p.seg_len;
+      const int l = (p.seg_prefix + 63) / 64, h = qs / 64;
+      if (h > l) { lo = l; hi = h; }
+    }
+  }
+  __device__ __forceinline__ int first() const { return lo == 0 ? hi : 0; }
+  __device__ __forceinline__ int next(int kt) const { const int n = kt + 1; return (n >= lo && n < hi) ? hi : n; }
+};
+
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
@@ -157,18 +181,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   float m_run = NEG_BIG, l_run = 0.f;
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  const SegSkip sk(p, q0, n_kt);
+  const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
   TileRegs<HD> kreg, vreg;
-  tile_fetch<HD>(kreg, p.k, p.ld, s, L, 0, h, tid);
-  tile_fetch<HD>(vreg, p.v, p.ld, s, L, 0, h, tid);
-  for (int kt = 0; kt < n_kt; ++kt) {
+  tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
+  tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
+  for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
+    nxt = sk.next(kt);
     const int k0 = kt * 64;
     tile_commit<HD>(Ks, kreg, tid);
     tile_commit<HD>(Vs, vreg, tid);
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
-    if (kt + 1 < n_kt) {      // next tile's global loads fly while this one is consumed
-      tile_fetch<HD>(kreg, p.k, p.ld, s, L, k0 + 64, h, tid);
-      tile_fetch<HD>(vreg, p.v, p.ld, s, L, k0 + 64, h, tid);
+    if (nxt < n_kt) {      // next tile's global loads fly while this one is consumed
+      tile_fetch<HD>(kreg, p.k, p.ld, s, L, nxt * 64, h, tid);
+      tile_fetch<HD>(vreg, p.v, p.ld, s, L, nxt * 64, h, tid);
     }
 
     f32x4_t sc[4];
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = kf * 16 + g * 4 + r;
-        ok[kf][r] = Ms[kl] && (!p.causal || (k0 + kl) <= qpos);
+        ok[kf][r] = Ms[kl] && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
         sc[kf][r] = ok[kf][r] ? sc[kf][r] * p.scale : NEG_BIG;
         mx = fmaxf(mx, sc[kf][r]);
       }
@@ -297,7 +324,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
   __syncthreads();
   const bool key_ok = Ms[w * 16 + c] != 0;
 
-  const int n_qt = (L + 63) / 64;
+  int n_qt = (L + 63) / 64;
+  int kend = 0x7fffffff;                     // packed responses: a key in segment a is visible to queries < end of segment a
+  if (p.seg_len > 0) {
+    if (kpos >= p.seg_prefix) kend = p.seg_prefix + ((kpos - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
+    if (k0 >= p.seg_prefix) {                // whole tile inside the response area: later segments never see it
+      const int q_cut = p.seg_prefix + ((min(k0 + 63, L - 1) - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
+      n_qt = min(n_qt, (q_cut + 63) / 64);
+    }
+  }
   for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {       // (register budget: no prefetch ring here — 248 VGPRs already)
     const int q0 = qt * 64;
     stage_tile<HD>(Qs, p.q, p.ld, s, L, q0, h, tid);
@@ -327,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int ql = qf * 16 + g * 4 + r;
         const int qp = q0 + ql;
-        const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp);
+        const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend;
         const float pv = ok ? __expf(sc[qf][r] * p.scale - lse_s[ql]) : 0.f;
         sc[qf][r] = pv;
         dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
@@ -396,18 +431,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
+  const SegSkip sk(p, q0, n_kt);
+  const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
   TileRegs<HD> kreg, vreg;
-  tile_fetch<HD>(kreg, p.k, p.ld, s, L, 0, h, tid);
-  tile_fetch<HD>(vreg, p.v, p.ld, s, L, 0, h, tid);
-  for (int kt = 0; kt < n_kt; ++kt) {
+  tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
+  tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
+  for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
+    nxt = sk.next(kt);
     const int k0 = kt * 64;
     tile_commit<HD>(Ks, kreg, tid);
     tile_commit<HD>(Vs, vreg, tid);
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
-    if (kt + 1 < n_kt) {
-      tile_fetch<HD>(kreg, p.k, p.ld, s, L, k0 + 64, h, tid);
-      tile_fetch<HD>(vreg, p.v, p.ld, s, L, k0 + 64, h, tid);
+    if (nxt < n_kt) {
+      tile_fetch<HD>(kreg, p.k, p.ld, s, L, nxt * 64, h, tid);
+      tile_fetch<HD>(vreg, p.v, p.ld, s, L, nxt * 64, h, tid);
     }
     f32x4_t sc[4], dp[4];
 #pragma unroll
@@ -426,7 +464,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kl = kf * 16 + g * 4 + r;
-        const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos);
+        const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
         const float pv = ok ? __expf(sc[kf][r] * p.scale - lse) : 0.f;
         dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
       }

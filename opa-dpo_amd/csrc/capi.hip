@@ -62,21 +62,24 @@ int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float
 
 int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
                     float* lse, const uint8_t* key_mask, int S_, int L, int nh, int hd, int causal, float scale,
-                    void* stream) {
+                    int seg_prefix, int seg_len, void* stream) {
   if (hd != 64 && hd != 128) return bad("opadpo_attn_fwd", "head_dim must be 64 or 128");
   if (!q || !k || !v || !o || ld % 8 || ldo % 4) return bad("opadpo_attn_fwd", "null operand or misaligned leading dimension");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.key_mask = key_mask;
   a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
+  if (seg_len < 0 || seg_prefix < 0 || (seg_len > 0 && !causal)) return bad("opadpo_attn_fwd", "packed responses need causal attention and seg_prefix, seg_len >= 0");
+  a.seg_prefix = seg_prefix; a.seg_len = seg_len;
   return done(launch_attn_fwd(a, S(stream)), "opadpo_attn_fwd");
 }
 
 int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, const uint16_t* o,
                     const uint16_t* dout, int ldo, const float* lse, const uint8_t* key_mask,
                     uint16_t* dq, uint16_t* dk, uint16_t* dv, float* dq_f32, float* delta,
-                    int S_, int L, int nh, int hd, int causal, float scale, void* stream) {
+                    int S_, int L, int nh, int hd, int causal, float scale, int seg_prefix, int seg_len, void* stream) {
   if (hd != 64 && hd != 128) return bad("opadpo_attn_bwd", "head_dim must be 64 or 128");
+  if (seg_len < 0 || seg_prefix < 0 || (seg_len > 0 && !causal)) return bad("opadpo_attn_bwd", "packed responses need causal attention and seg_prefix, seg_len >= 0");
   if (!q || !k || !v || !o || !dout || !lse || (!dq && !dq_f32) || !dk || !dv || !delta || ld % 8 || ldo % 8)
     return bad("opadpo_attn_bwd", "null operand or misaligned leading dimension");
   AttnArgs a;
@@ -84,6 +87,7 @@ int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
   a.q = q; a.k = k; a.v = v; a.o = (uint16_t*)o; a.lse = (float*)lse; a.key_mask = key_mask;
   a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
   a.dout = dout; a.dq_acc = dq_f32; a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta;
+  a.seg_prefix = seg_prefix; a.seg_len = seg_len;
   return done(launch_attn_bwd(a, S(stream)), "opadpo_attn_bwd");
 }
 
@@ -99,9 +103,9 @@ int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b
   return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
 }
 int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
-                int inverse, const int32_t* pos_base, void* stream) {
+                int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, void* stream) {
   if (ld % 8) return bad("opadpo_rope", "misaligned leading dimension");
-  return done(launch_rope(qk, ld, cos_tab, sin_tab, rows, L, n_heads, hd, inverse, pos_base, S(stream)), "opadpo_rope");
+  return done(launch_rope(qk, ld, cos_tab, sin_tab, rows, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len, S(stream)), "opadpo_rope");
 }
 int opadpo_silu_mul_fwd(const uint16_t* gu, uint16_t* act, int rows, int F, void* stream) {
   return done(launch_silu_mul_fwd(gu, act, rows, F, S(stream)), "opadpo_silu_mul_fwd");
@@ -130,6 +134,9 @@ int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx,
 int opadpo_scatter_rows(const uint16_t* src, const int32_t* rows_idx, uint16_t* dst, int ld_dst, int n, int H, void* stream) {
   if (ld_dst % 8) return bad("opadpo_scatter_rows", "misaligned leading dimension");
   return done(launch_scatter_rows(src, rows_idx, dst, ld_dst, n, H, S(stream)), "opadpo_scatter_rows");
+}
+int opadpo_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, void* stream) {
+  return done(launch_scatter_add_rows_f32(src, rows_idx, dst, ld_dst, n, H, S(stream)), "opadpo_scatter_add_rows_f32");
 }
 int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream) {
   return done(launch_transpose(in, out, R, C, S(stream)), "opadpo_transpose");

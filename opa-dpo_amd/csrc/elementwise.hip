@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
 // (call once for the q section and once for the k section, or with 2*n_heads when contiguous).
 // forward: x' = x*cos + rot(x)*sin ; inverse (gradient): g' = g*cos - rot(g)*sin  with rot(x) = [-x2, x1]
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const float* cosb, const float* sinb,
-                                                    size_t total, int L, int n_heads, int hd, int inverse, const int32_t* pos_base) {
+                                                    size_t total, int L, int n_heads, int hd, int inverse, const int32_t* pos_base,
+                                                    int seg_prefix, int seg_len) {
   const int half = hd / 2;
   const int pos0 = pos_base ? pos_base[0] : 0;     // device-resident position offset (graph-replayed decode step)
   const int per_row = n_heads * (half / 8);     // 8 (x1,x2) pairs per thread
@@ -130,7 +131,9 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const flo
     const size_t row = idx / per_row;
     const int rem = (int)(idx % per_row);
     const int head = rem / (half / 8), i0 = (rem % (half / 8)) * 8;
-    const int pos = pos0 + (int)(row % L);
+    int pos = pos0 + (int)(row % L);
+    // packed responses sharing a prefix: every response restarts at position seg_prefix
+    if (seg_len > 0 && pos >= seg_prefix + seg_len) pos -= ((pos - seg_prefix) / seg_len) * seg_len;
     bf16_t* base = qk + row * ld + head * hd;
     float x1[8], x2[8];
     unpack8(*(const uint4*)(base + i0), x1);
@@ -279,6 +282,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* src, int
   const bf16_t* s = src + (size_t)rows_idx[r] * ld_src;
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) *(uint4*)(dst + r * H + i) = *(const uint4*)(s + i);
 }
+// dst[rows_idx[r]] += src[r] (fp32, hardware float atomics: duplicate row indices accumulate)
+__global__ __launch_bounds__(256) void scatter_add_rows_f32_kernel(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int H) {
+  const size_t r = blockIdx.x;
+  float* d = dst + (size_t)rows_idx[r] * ld_dst;
+  for (int i = threadIdx.x; i < H; i += 256) atomicAdd(d + i, src[r * H + i]);
+}
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst,
                                                             int ld_dst, int H) {
   const size_t r = blockIdx.x;
@@ -365,11 +374,11 @@ hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* 
   return hipGetLastError();
 }
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, hipStream_t st) {
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (hd % 16) return hipErrorInvalidValue;
   const size_t total = (size_t)rows * n_heads * (hd / 16);
-  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len);
   return hipGetLastError();
 }
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {
@@ -415,6 +424,11 @@ hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_
   if (n <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, st, src, rows_idx, dst, ld_dst, H);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_add_rows_f32_kernel, dim3(n), dim3(256), 0, st, src, rows_idx, dst, ld_dst, H);
   return hipGetLastError();
 }
 hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st) {

@@ -41,6 +41,7 @@ struct AttnArgs {
   int ld, ldo;
   int causal;
   float scale;
+  int seg_prefix, seg_len;                              // packed responses sharing a prefix (seg_len = 0: off)
   // backward only
   const bf16_t* dout;                                   // ldo addressing
   float* dq_acc;                                        // optional fp32 copy of dQ [S*L, nh*hd] (nullable)
@@ -62,7 +63,7 @@ hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const 
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
 hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, hipStream_t st);
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st);
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
@@ -71,6 +72,7 @@ hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, con
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st);
 hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st);
 hipError_t launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* rows_idx, bf16_t* dst, int n, int H, hipStream_t st);
+hipError_t launch_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, hipStream_t st);
 hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst, int ld_dst, int n, int H, hipStream_t st);
 hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);

@@ -118,3 +118,22 @@ def pair_flops(d: LlavaDims, q_len: int, t_len: int) -> float:
     dgrad = 2 * (p_lin + p_lora) * L + 2 * nl * 2 * L * L * H
     wgrad = 4 * p_lora * L
     return 4 * f_seq + 2 * dgrad + 2 * wgrad + f_img
+
+
+def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2) -> float:
+    """FLOPs EXECUTED for one preference pair when the K responses of a sample are packed on a shared image + query
+    prefix (policy.pack_responses): one row of pfx + K*t_len positions per policy / reference pass instead of K rows of
+    pfx + t_len.  Same conventions as pair_flops (attention counted on the causal/segment-masked (q, k) pairs)."""
+    H, F, V, nl, r = d.hidden, d.ffn, d.vocab, d.n_layers, d.lora_r
+    pfx = q_len + d.n_patches - 1
+    Lp = pfx + K * t_len
+    p_lin = nl * (4 * H * H + 3 * H * F)
+    p_lora = lora_param_count(d)
+    pairs = pfx * pfx / 2 + K * (t_len * pfx + t_len * t_len / 2)          # attended (query, key) pairs
+    f_row = 2 * (p_lin + p_lora) * Lp + nl * 4 * H * pairs + 2 * V * H * t_len * K
+    vh, vf, P1 = d.v_hidden, d.v_ffn, d.n_patches + 1
+    f_img = d.v_used_layers * (2 * (4 * vh * vh + 2 * vh * vf) * P1 + 4 * P1 * P1 * vh) \
+        + 2 * d.n_patches * (d.patch_k * vh + vh * H + H * H)
+    dgrad = 2 * (p_lin + p_lora) * Lp + 2 * nl * 4 * H * pairs
+    wgrad = 4 * p_lora * Lp
+    return 2 * f_row + dgrad + wgrad + f_img

@@ -26,12 +26,12 @@ _u64 = C.c_uint64
 SIGNATURES = {
     "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_rmsnorm_bwd": [_p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
-    "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "opadpo_silu_mul_fwd": [_p, _p, _i, _i, _p],
     "opadpo_silu_mul_bwd": [_p, _p, _p, _i, _i, _p],
     "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
@@ -39,6 +39,7 @@ SIGNATURES = {
     "opadpo_vision_embed": [_p, _p, _p, _p, _i, _i, _i, _p],
     "opadpo_gather_rows": [_p, _i, _p, _p, _i, _i, _p],
     "opadpo_scatter_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "opadpo_scatter_add_rows_f32": [_p, _p, _p, _i, _i, _i, _p],
     "opadpo_transpose": [_p, _p, _i, _i, _p],
     "opadpo_f32_to_bf16": [_p, _p, _sz, _p],
     "opadpo_f32_to_bf16_strided": [_p, _p, _sz, _i, _i, _p],

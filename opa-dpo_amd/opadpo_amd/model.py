@@ -244,6 +244,8 @@ class SeqBatch:
     feat_row: torch.Tensor     # [S] int32: which image's features each sequence uses
     image_mask: Optional[torch.Tensor]  # [S, P] uint8 (CoPO 'attention') or None
     T: int                     # response length
+    K: int = 1                 # responses packed per row: ids = [query | response_0 | ... | response_{K-1}] sharing one
+                               # pass over the image + query prefix (K = 1: one response per row, the reference's layout)
 
 
 class Saved:
@@ -301,7 +303,7 @@ class LlavaEngine:
             L.call("opadpo_layernorm_fwd", L.ptr(x), L.ptr(w["layer_norm1_w"]), L.ptr(w["layer_norm1_b"]), L.ptr(n), M, vh, d.v_eps, st)
             L.gemm_nt(n, w["wqkv"], qkv, bias=w["bqkv"])
             L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * vh, qkv.data_ptr() + 4 * vh, 3 * vh, L.ptr(att), vh,
-                   None, None, B, T, d.v_heads, hd, 0, hd ** -0.5, st)
+                   None, None, B, T, d.v_heads, hd, 0, hd ** -0.5, 0, 0, st)
             L.gemm_nt(att, w["wo"], x2, bias=w["bo"], residual=x)
             L.call("opadpo_layernorm_fwd", L.ptr(x2), L.ptr(w["layer_norm2_w"]), L.ptr(w["layer_norm2_b"]), L.ptr(n), M, vh, d.v_eps, st)
             L.gemm_nt(n, w["fc1"], f1, bias=w["b1"], act=L.ACT_QUICK_GELU)
@@ -318,7 +320,7 @@ class LlavaEngine:
         return feats.view(B, P, d.hidden)
 
     # -- LLM ---------------------------------------------------------------------------------------
-    def _alloc_saved(self, S: int, Lp: int, T: int, train: bool) -> Saved:
+    def _alloc_saved(self, S: int, Lp: int, T: int, train: bool, K: int = 1) -> Saved:
         """Activation storage of one forward.  Fresh torch allocations (the caching allocator recycles
         them): a Saved object owns its tensors until backward has consumed it, so several training
         forwards (clean + CoPO-masked) can be alive at once."""
@@ -344,7 +346,7 @@ class LlavaEngine:
         sv.gu = e((nb, M, 2 * F))
         sv.act = e((nb, M, F))
         sv.t_d = e((nb, M, r))
-        R = S * T
+        R = S * T * K
         sv.key_mask = e((S, Lp), torch.uint8)
         sv.hs = e((R, H), torch.float32)
         sv.hn = e((R, H))
@@ -354,7 +356,7 @@ class LlavaEngine:
         return sv
 
     def layer_fwd(self, i: int, adapter: Optional[LoraAdapter], x, xo, sv, k: int, S: int, Lp: int, key_mask, cos, sin,
-                  kv_hook=None) -> None:
+                  kv_hook=None, seg=(0, 0)) -> None:
         """One Llama decoder layer over M = S*Lp rows: x (fp32 residual stream) -> xo.  `adapter=None` runs the
         bare base model (the shipped rollout config has no LoRA: run/online_generate.sh POLICY_LORA_DIR=none).
         sv.<buf>[k] are the activation buffers; kv_hook(i, qkv) sees the post-RoPE q|k|v (KV-cache fill)."""
@@ -371,11 +373,11 @@ class LlavaEngine:
             L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
         else:
             L.gemm_nt(n1, w["wqkv"], qkv)
-        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, st)
+        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, seg[0], seg[1], st)
         if kv_hook is not None:
             kv_hook(i, qkv)
         L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,
-               L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, 1, hd ** -0.5, st)
+               L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, 1, hd ** -0.5, seg[0], seg[1], st)
         if adapter is not None:
             L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
             L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
@@ -410,12 +412,15 @@ class LlavaEngine:
         S, n_txt = batch.ids.shape
         P, H, F, r, nh, hd = d.n_patches, d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim
         Lp = n_txt + P - 1
-        T = batch.T
+        T, K = batch.T, batch.K
         M = S * Lp
         s = d.lora_scale
-        sv = self._alloc_saved(S, Lp, T, train)
+        pfx = Lp - K * T                              # image + query positions shared by the K responses of a row
+        seg = (pfx, T) if K > 1 else (0, 0)
+        sv = self._alloc_saved(S, Lp, T, train, K)
         sv.batch = batch
         sv.temperature = temperature
+        sv.seg, sv.K = seg, K
         x0 = sv.x[0]
         L.call("opadpo_embed_splice", L.ptr(batch.ids), L.ptr(batch.text_mask), L.ptr(b.embed), L.ptr(feats),
                L.ptr(batch.feat_row), L.ptr(batch.image_mask), L.ptr(x0), 1, L.ptr(sv.key_mask), S, n_txt, P, H,
@@ -425,13 +430,17 @@ class LlavaEngine:
             k = i if train else 0
             x = sv.x[i if train else (i & 1)]
             xo = sv.x[i + 1 if train else ((i + 1) & 1)]
-            self.layer_fwd(i, adapter, x, xo, sv, k, S, Lp, sv.key_mask, cos, sin)
+            self.layer_fwd(i, adapter, x, xo, sv, k, S, Lp, sv.key_mask, cos, sin, seg=seg)
         xf = sv.x[d.n_layers if train else (d.n_layers & 1)]
-        # response rows: positions L-T-1 .. L-2 predict tokens L-T .. L-1 (rl_models.py:121-123)
-        R = S * T
-        rows = (torch.arange(S, device=self.dev, dtype=torch.int32)[:, None] * Lp
-                + torch.arange(Lp - T - 1, Lp - 1, device=self.dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
-        labels = batch.ids[:, n_txt - T:].contiguous().view(-1)
+        # response rows: the position before each response token predicts it (rl_models.py:121-123: logits[:, -T-1:-1]).
+        # Packed rows: token 0 of EVERY response is predicted from the last prefix position, token t >= 1 of response k
+        # from position pfx + k*T + t - 1.  Output order is [k][s][t] = the reference's stacking of the response keys.
+        R = K * S * T
+        ar = lambda n: torch.arange(n, device=self.dev, dtype=torch.int32)
+        off = pfx + ar(K)[:, None, None] * T + ar(T)[None, None, :] - 1            # [K,1,T]
+        off = torch.where(ar(T)[None, None, :] == 0, torch.full_like(off, pfx - 1), off)
+        rows = (ar(S)[None, :, None] * Lp + off).reshape(-1).contiguous()            # [K,S,T]
+        labels = batch.ids[:, n_txt - K * T:].reshape(S, K, T).transpose(0, 1).contiguous().view(-1)
         sv.rows, sv.labels = rows, labels
         L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(rows), L.ptr(sv.hs), R, 2 * H, st)   # fp32 rows = 2H bf16 units
         L.call("opadpo_rmsnorm_fwd", L.ptr(sv.hs), 1, L.ptr(b.norm), L.ptr(sv.hn), L.ptr(sv.rstd_f), R, H, d.rms_eps, st)
@@ -440,7 +449,7 @@ class LlavaEngine:
         ent = torch.empty(R, dtype=torch.float32, device=self.dev)
         L.call("opadpo_head_fwd", L.ptr(sv.logits), d.vocab, L.ptr(labels), 1.0 / temperature, L.ptr(logp), L.ptr(ent),
                L.ptr(sv.lse_head), R, d.vocab, st)
-        return logp.view(S, T), ent.view(S, T), sv
+        return logp.view(K * S, T), ent.view(K * S, T), sv
 
     def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor) -> None:
         """Accumulate d(loss)/d(LoRA A,B) into adapter.grad given dlogp [S,T] fp32."""
@@ -450,7 +459,8 @@ class LlavaEngine:
         S, Lp, T, M = sv.S, sv.L, sv.T, sv.M
         H, F, r, nh, hd, V = d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim, d.vocab
         s = d.lora_scale
-        R = S * T
+        R = S * T * sv.K
+        seg = sv.seg
         dlogp = dlogp.to(device=self.dev, dtype=torch.float32).contiguous().view(-1)
         dz = self.buf("bw_dz", (R, V))
         L.call("opadpo_head_bwd", L.ptr(sv.logits), V, L.ptr(sv.labels), L.ptr(sv.lse_head), L.ptr(dlogp),
@@ -462,7 +472,10 @@ class LlavaEngine:
         dX = self.buf("bw_dX", (M, H), torch.float32)      # fp32 gradient residual stream ...
         dXb = self.buf("bw_dXb", (M, H))                    # ... and its bf16 copy (GEMM operand)
         dX.zero_()
-        L.call("opadpo_scatter_rows", L.ptr(d_hs), L.ptr(sv.rows), L.ptr(dX), 2 * H, R, 2 * H, st)
+        if sv.K > 1:      # the last prefix row feeds token 0 of every response: contributions add
+            L.call("opadpo_scatter_add_rows_f32", L.ptr(d_hs), L.ptr(sv.rows), L.ptr(dX), H, R, H, st)
+        else:
+            L.call("opadpo_scatter_rows", L.ptr(d_hs), L.ptr(sv.rows), L.ptr(dX), 2 * H, R, 2 * H, st)
         L.call("opadpo_f32_to_bf16", L.ptr(dX), L.ptr(dXb), M * H, st)
         _dbg("dz", dz); _dbg("d_hn", d_hn); _dbg("d_hs", d_hs); _dbg("dX0", dX)
         d_h = self.buf("bw_dh", (M, H), torch.float32)
@@ -502,10 +515,10 @@ class LlavaEngine:
             qkv = sv.qkv[i]
             L.call("opadpo_attn_bwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(sv.attn[i]),
                    L.ptr(d_attn), H, L.ptr(sv.lse[i]), L.ptr(sv.key_mask), L.ptr(dqkv), dqkv.data_ptr() + 2 * H,
-                   dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, st)
+                   dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, seg[0], seg[1], st)
             _dbg(f"L{i} d_attn", d_attn); _dbg(f"L{i} attn", sv.attn[i]); _dbg(f"L{i} lse", sv.lse[i]); _dbg(f"L{i} delta", delta)
             _dbg(f"L{i} dq", dqkv[:, :H]); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
-            L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, None, st)
+            L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, None, seg[0], seg[1], st)
             _dbg(f"L{i} dqkv(after rope)", dqkv)
             L.gemm_nt(dqkv, adapter.wt(i, "b_qkv").view(3 * r, H), dt_3r, alpha=s, k1=H, a1_group_n=r, a1_group_stride=H)
             L.gemm_tn(dqkv, sv.t_qkv[i], adapter.g(i, "b_qkv"), q_group_n1=H, q_group_stride=r)

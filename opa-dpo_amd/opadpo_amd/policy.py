@@ -43,8 +43,13 @@ class _SeqLogprobs(torch.autograd.Function):
 
 class AutoregressivePolicy(torch.nn.Module):
     def __init__(self, engine: LlavaEngine, adapter: LoraAdapter, response_len: int, temperature: float = 1.0,
-                 adapter_name: Optional[str] = None):
+                 adapter_name: Optional[str] = None, pack_responses: bool = True):
         super().__init__()
+        # pack_responses: the K response keys of a call become ONE row per sample, [image+query | r_0 | ... | r_{K-1}], with
+        # segment-masked attention, so the shared image + query prefix (703 of 1087 positions at seq512) is computed once
+        # instead of K times.  Same log-probs / gradients as the reference's K stacked sequences (causal attention makes the
+        # prefix states independent of the response); False keeps the reference's layout.
+        self.pack_responses = pack_responses
         self.engine = engine
         self.adapter = adapter
         self.adapter_name = adapter_name
@@ -64,22 +69,28 @@ class AutoregressivePolicy(torch.nn.Module):
         qm = queries_attn_masks.to(dev).bool()
         ids, masks = [], []
         image_mask = None
+        P = d.n_patches
+        if qm.size(1) == Q:                                   # rl_models.py:100-102
+            qmask_txt = qm
+        else:                                                 # CoPO 'attention' (:103-105): [image mask | query mask]
+            assert qm.size(1) == P + Q
+            qmask_txt = qm[:, P:]
+            image_mask = qm[:, :P]
         for k in keys:
             r = responses[k].to(dev)
-            i = torch.cat([queries, r], dim=1)
-            if qm.size(1) == Q:                               # rl_models.py:100-102
-                m = i != PAD_ID
-                m[:, :Q] = qm
-            else:                                             # CoPO 'attention' (:103-105): [image mask | query mask]
-                P = d.n_patches
-                assert qm.size(1) == P + Q
-                m = torch.cat([qm[:, P:], r != PAD_ID], dim=1)
-                image_mask = qm[:, :P]
-            ids.append(i)
-            masks.append(m)
+            ids.append(torch.cat([queries, r], dim=1))
+            masks.append(torch.cat([qmask_txt, r != PAD_ID], dim=1))
         K = len(keys)
         T = responses[keys[0]].shape[1]
         assert T == self.response_len, "policy slices with args.response_len (rl_models.py:121-123, Quirk Q7)"
+        if self.pack_responses and K > 1:
+            batch = SeqBatch(
+                ids=torch.cat([queries] + [responses[k].to(dev) for k in keys], 1).to(torch.int32).contiguous(),
+                text_mask=torch.cat([qmask_txt] + [responses[k].to(dev) != PAD_ID for k in keys], 1).to(torch.uint8).contiguous(),
+                feat_row=torch.arange(B, device=dev, dtype=torch.int32),
+                image_mask=None if image_mask is None else image_mask.to(torch.uint8).contiguous(),
+                T=T, K=K)
+            return keys, batch
         batch = SeqBatch(
             ids=torch.cat(ids, 0).to(torch.int32).contiguous(),
             text_mask=torch.cat(masks, 0).to(torch.uint8).contiguous(),

@@ -177,13 +177,19 @@ def test_gemm_tn(L, tr, M, N1, N2, groups):
     assert e < 1e-4, f"gemm_tn rel err {e}"
 
 
-def ref_attention(q, k, v, key_mask, causal, scale):
-    """q,k,v [S,L,nh,hd] fp32 -> o [S,L,nh,hd], fully-masked rows -> 0."""
+def ref_attention(q, k, v, key_mask, causal, scale, seg=(0, 0)):
+    """q,k,v [S,L,nh,hd] fp32 -> o [S,L,nh,hd], fully-masked rows -> 0.  seg = (prefix, seg_len): packed responses, a
+    query attends the prefix and its own response segment only."""
     S, Ln, nh, hd = q.shape
     sc = torch.einsum("sqhd,skhd->shqk", q, k) * scale
     allow = torch.ones(S, 1, Ln, Ln, dtype=torch.bool, device=q.device)
     if causal:
         allow = allow & torch.tril(torch.ones(Ln, Ln, dtype=torch.bool, device=q.device))[None, None]
+    if seg[1] > 0:
+        pos = torch.arange(Ln, device=q.device)
+        sid = torch.where(pos < seg[0], torch.full_like(pos, -1), (pos - seg[0]) // seg[1])
+        same = (sid[None, :] == -1) | (sid[:, None] == sid[None, :])          # key in prefix, or same segment
+        allow = allow & same[None, None]
     if key_mask is not None:
         allow = allow & key_mask.bool()[:, None, None, :]
     sc = sc.masked_fill(~allow, float("-inf"))
@@ -208,7 +214,7 @@ def test_attn_fwd(L, tr, S, Ln, nh, hd, causal, masked):
     lse = torch.zeros(S, nh, Ln, device=dev())
     st = L.stream()
     L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
-           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, causal, hd ** -0.5, st)
+           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, causal, hd ** -0.5, 0, 0, st)
     torch.cuda.synchronize()
     q4 = qkv[:, :H].float().view(S, Ln, nh, hd)
     k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd)
@@ -236,13 +242,13 @@ def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
     st = L.stream()
     scale = hd ** -0.5
     L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
-           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, 1, scale, st)
+           lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, 1, scale, 0, 0, st)
     dq_acc = torch.zeros(S * Ln, H, device=dev())
     dqkv = torch.zeros(S * Ln, 3 * H, dtype=BF, device=dev())
     delta = torch.zeros(S, nh, Ln, device=dev())
     L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
            dout.data_ptr(), H, lse.data_ptr(), L.ptr(km), dqkv.data_ptr(), dqkv.data_ptr() + 2 * H,
-           dqkv.data_ptr() + 4 * H, dq_acc.data_ptr(), delta.data_ptr(), S, Ln, nh, hd, 1, scale, st)
+           dqkv.data_ptr() + 4 * H, dq_acc.data_ptr(), delta.data_ptr(), S, Ln, nh, hd, 1, scale, 0, 0, st)
     torch.cuda.synchronize()
     q4 = qkv[:, :H].float().view(S, Ln, nh, hd).requires_grad_(True)
     k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd).requires_grad_(True)
@@ -254,6 +260,101 @@ def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
                            ("dv", dqkv[:, 2 * H:], v4.grad.reshape(S * Ln, H))):
         e = relerr(got, ref)
         assert e < 2e-2, f"attn_bwd {name} rel err {e}"
+
+
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("S,nh,hd,pfx,T,K", [(2, 2, 128, 70, 37, 2), (1, 1, 128, 130, 100, 3), (2, 2, 64, 64, 64, 2), (1, 2, 128, 5, 150, 2),
+                                             (1, 1, 128, 200, 128, 3)])
+def test_attn_packed_responses(L, tr, S, nh, hd, pfx, T, K):
+    """seg_len > 0: rows are [prefix | response_0 | ... | response_{K-1}]; forward and backward equal (a) torch attention
+    with the explicit segment mask and (b) K separate [prefix | response_k] sequences — what the reference runs."""
+    L.set_flags(True, bool(tr))
+    H = nh * hd
+    Ln = pfx + K * T
+    scale = hd ** -0.5
+    qkv = rnd(S * Ln, 3 * H, scale=0.8, seed=21)
+    dout = rnd(S * Ln, H, seed=22)
+    km = torch.ones(S, Ln, dtype=torch.uint8, device=dev())
+    km[0, :3] = 0
+    km[-1, pfx + T - 5: pfx + T] = 0                   # right padding of response 0
+    st = L.stream()
+
+    def run(x, do, mask, S_, L_, seg):
+        o = torch.zeros(S_ * L_, H, dtype=BF, device=dev())
+        lse = torch.zeros(S_, nh, L_, device=dev())
+        L.call("opadpo_attn_fwd", x.data_ptr(), x.data_ptr() + 2 * H, x.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+               lse.data_ptr(), mask.data_ptr(), S_, L_, nh, hd, 1, scale, seg[0], seg[1], st)
+        dx = torch.zeros(S_ * L_, 3 * H, dtype=BF, device=dev())
+        dq32 = torch.zeros(S_ * L_, H, device=dev())
+        delta = torch.zeros(S_, nh, L_, device=dev())
+        L.call("opadpo_attn_bwd", x.data_ptr(), x.data_ptr() + 2 * H, x.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+               do.data_ptr(), H, lse.data_ptr(), mask.data_ptr(), dx.data_ptr(), dx.data_ptr() + 2 * H, dx.data_ptr() + 4 * H,
+               dq32.data_ptr(), delta.data_ptr(), S_, L_, nh, hd, 1, scale, seg[0], seg[1], st)
+        torch.cuda.synchronize()
+        return o, dx
+
+    o, dx = run(qkv, dout, km, S, Ln, (pfx, T))
+    q4 = qkv[:, :H].float().view(S, Ln, nh, hd).requires_grad_(True)
+    k4 = qkv[:, H:2 * H].float().view(S, Ln, nh, hd).requires_grad_(True)
+    v4 = qkv[:, 2 * H:].float().view(S, Ln, nh, hd).requires_grad_(True)
+    want = ref_attention(q4, k4, v4, km, 1, scale, seg=(pfx, T))
+    want.backward(dout.float().view(S, Ln, nh, hd))
+    assert relerr(o, want.reshape(S * Ln, H)) < 1e-2
+    for name, got, ref in (("dq", dx[:, :H], q4.grad), ("dk", dx[:, H:2 * H], k4.grad), ("dv", dx[:, 2 * H:], v4.grad)):
+        e = relerr(got, ref.reshape(S * Ln, H))
+        assert e < 2e-2, f"packed attn_bwd {name} rel err {e}"
+    # (b) the K separate sequences [prefix | response_k] (kernel without segments): same response outputs; the prefix
+    # gradients of the packed row are the sum over the K sequences
+    x3 = qkv.view(S, Ln, 3 * H)
+    d3 = dout.view(S, Ln, H)
+    dk_pfx = torch.zeros(S, pfx, 2 * H, device=dev())
+    for k in range(K):
+        sl = slice(pfx + k * T, pfx + (k + 1) * T)
+        xs = torch.cat([x3[:, :pfx], x3[:, sl]], 1).reshape(S * (pfx + T), 3 * H).contiguous()
+        ds = torch.cat([torch.zeros_like(d3[:, :pfx]), d3[:, sl]], 1).reshape(S * (pfx + T), H).contiguous()
+        ms = torch.cat([km[:, :pfx], km[:, sl]], 1).contiguous()
+        os_, dxs = run(xs, ds, ms, S, pfx + T, (0, 0))
+        assert relerr(o.view(S, Ln, H)[:, sl], os_.view(S, pfx + T, H)[:, pfx:]) < 4e-3
+        assert relerr(dx.view(S, Ln, 3 * H)[:, sl], dxs.view(S, pfx + T, 3 * H)[:, pfx:]) < 1e-2
+        dk_pfx += dxs.view(S, pfx + T, 3 * H)[:, :pfx, H:].float()
+    # prefix queries get gradient only through dout on prefix rows (zeroed in the split runs), so compare dK/dV of the
+    # prefix against the packed run with the prefix dout removed
+    dout0 = dout.clone().view(S, Ln, H)
+    dout0[:, :pfx] = 0
+    _, dx0 = run(qkv, dout0.reshape(S * Ln, H).contiguous(), km, S, Ln, (pfx, T))
+    assert relerr(dx0.view(S, Ln, 3 * H)[:, :pfx, H:], dk_pfx) < 1.5e-2
+
+
+def test_rope_packed_positions(L):
+    S, nh, hd, pfx, T, K = 2, 2, 128, 11, 7, 3
+    Ln, H = pfx + K * T, nh * hd
+    qkv = rnd(S * Ln, 3 * H, seed=1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    f = torch.outer(torch.arange(Ln).float(), inv)
+    cos, sin = f.cos().to(dev()).contiguous(), f.sin().to(dev()).contiguous()
+    x = qkv.clone()
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, None, pfx, T, L.stream())
+    # reference: the plain kernel on each [prefix | response_k] sequence
+    x3, q3 = x.view(S, Ln, 3 * H), qkv.view(S, Ln, 3 * H)
+    for k in range(K):
+        sl = slice(pfx + k * T, pfx + (k + 1) * T)
+        xs = torch.cat([q3[:, :pfx], q3[:, sl]], 1).reshape(S * (pfx + T), 3 * H).contiguous()
+        L.call("opadpo_rope", xs.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * (pfx + T), pfx + T, 2 * nh, hd, 0, None, 0, 0, L.stream())
+        xs = xs.view(S, pfx + T, 3 * H)
+        assert torch.equal(x3[:, sl], xs[:, pfx:]) and torch.equal(x3[:, :pfx], xs[:, :pfx])
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, None, pfx, T, L.stream())
+    assert relerr(x, qkv) < 8e-3
+
+
+def test_scatter_add_rows_f32(L):
+    n, H, R = 9, 256, 20
+    src = torch.randn(n, H, device=dev())
+    idx = torch.tensor([3, 5, 3, 0, 19, 5, 3, 7, 8], dtype=torch.int32, device=dev())     # duplicates accumulate
+    dst = torch.randn(R, H, device=dev())
+    want = dst.clone().index_add_(0, idx.long(), src)
+    L.call("opadpo_scatter_add_rows_f32", src.data_ptr(), idx.data_ptr(), dst.data_ptr(), H, n, H, L.stream())
+    torch.cuda.synchronize()
+    assert float((dst - want).abs().max()) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -298,7 +399,7 @@ def test_rope(L):
     f = torch.outer(torch.arange(Ln).float(), inv)
     cos, sin = f.cos().to(dev()).contiguous(), f.sin().to(dev()).contiguous()
     x = qkv.clone()
-    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, None, L.stream())
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 0, None, 0, 0, L.stream())
     ref = qkv.float().view(S, Ln, 3 * nh, hd)
     c = torch.cat([f, f], -1).cos().to(dev())[None, :, None, :]
     s = torch.cat([f, f], -1).sin().to(dev())[None, :, None, :]
@@ -307,12 +408,12 @@ def test_rope(L):
     want[:, :, : 2 * nh] = (ref * c + rot * s)[:, :, : 2 * nh]
     assert relerr(x, want.reshape(S * Ln, 3 * H)) < 4e-3
     assert torch.equal(x[:, 2 * H:], qkv[:, 2 * H:])          # v untouched
-    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, None, L.stream())
+    L.call("opadpo_rope", x.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S * Ln, Ln, 2 * nh, hd, 1, None, 0, 0, L.stream())
     assert relerr(x, qkv) < 8e-3                               # inverse rotation restores the input
     # device-resident position offset (decode step replayed from a graph): one row per sequence at position 7
     one = qkv[:S].clone()
     pos = torch.tensor([7], dtype=torch.int32, device=dev())
-    L.call("opadpo_rope", one.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S, 1, 2 * nh, hd, 0, pos.data_ptr(), L.stream())
+    L.call("opadpo_rope", one.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), S, 1, 2 * nh, hd, 0, pos.data_ptr(), 0, 0, L.stream())
     r1 = qkv[:S].float().view(S, 3 * nh, hd)
     c7, s7 = torch.cat([f[7], f[7]]).cos().to(dev()), torch.cat([f[7], f[7]]).sin().to(dev())
     w1 = r1.clone()
@@ -508,7 +609,7 @@ def test_rope_kv_append(L):
     cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
     posd = torch.tensor([pos], dtype=torch.int32, device=dev())
     ref = qkv.clone()
-    L.call("opadpo_rope", ref.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), B, 1, 2 * nh, hd, 0, posd.data_ptr(), L.stream())
+    L.call("opadpo_rope", ref.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), B, 1, 2 * nh, hd, 0, posd.data_ptr(), 0, 0, L.stream())
     kc = torch.zeros(B, nh, max_ctx, hd, dtype=BF, device=dev())
     vc = torch.zeros_like(kc)
     got = qkv.clone()

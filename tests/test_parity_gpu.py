@@ -85,17 +85,23 @@ def test_vision_features(setup):
     assert e16 < 2e-2 and e32 < 3e-2, (e16, e32)
 
 
-def _policy(s, adapter, T):
+def _policy(s, adapter, T, pack=True):
     from opadpo_amd.policy import AutoregressivePolicy
-    return AutoregressivePolicy(s["eng"], adapter, response_len=T, temperature=1.0)
+    return AutoregressivePolicy(s["eng"], adapter, response_len=T, temperature=1.0, pack_responses=pack)
 
 
-def test_logprobs_forward(setup):
+# pack=True: the K responses of a sample share one pass over the image + query prefix (one row [prefix | r_0 | ... ], segment-
+# masked attention); pack=False: the reference's layout (K stacked sequences).  Both against the SAME oracle numbers.
+PACK = pytest.mark.parametrize("pack", [True, False])
+
+
+@PACK
+def test_logprobs_forward(setup, pack):
     s = setup
     LR = s["LR"]
     B, Q, T = 2, 12, 9
     images, queries, qmask, resp = make_inputs(s["d"], B, Q, T)
-    pol = _policy(s, s["ref"], T)
+    pol = _policy(s, s["ref"], T, pack)
     out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, temperature=0.9, **resp)
     torch.cuda.synchronize()
     want32 = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_ref"], s["od"], 0.9, emulate_bf16=False)
@@ -113,8 +119,8 @@ def test_logprobs_forward(setup):
                 worst16 = max(worst16, float(r.mean()))
             else:
                 worst32 = max(worst32, float(r.mean()))
-            REPORT[f"logp_{k}_maxrel_vs_{tag}"] = float(r.max())
-            REPORT[f"logp_{k}_meanrel_vs_{tag}"] = float(r.mean())
+            REPORT[f"logp_{k}_maxrel_vs_{tag}{'_packed' if pack else ''}"] = float(r.max())
+            REPORT[f"logp_{k}_meanrel_vs_{tag}{'_packed' if pack else ''}"] = float(r.mean())
         ge = out[k + "_entropies"].cpu()
         REPORT[f"ent_{k}_maxabs_vs_32"] = float((ge - want32[k + "_entropies"]).abs().max())
         assert float((ge - want32[k + "_entropies"]).abs().max()) < 5e-2
@@ -122,14 +128,15 @@ def test_logprobs_forward(setup):
     assert worst32 < 5e-3, f"mean relative log-prob error vs fp32 oracle {worst32}"
 
 
-def test_lora_backward(setup):
+@PACK
+def test_lora_backward(setup, pack):
     s = setup
     LR = s["LR"]
     from opadpo_amd.model import lora_blocks
     B, Q, T = 2, 12, 9
     images, queries, qmask, resp = make_inputs(s["d"], B, Q, T, seed=5)
     two = {k: resp[k] for k in ("standard_response", "original_generate_response")}
-    pol = _policy(s, s["pol"], T)
+    pol = _policy(s, s["pol"], T, pack)
     s["pol"].grad.zero_()
     out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, **two)
     g = torch.Generator().manual_seed(9)
@@ -154,13 +161,14 @@ def test_lora_backward(setup):
                 ref[r0:r0 + nr] = lora[f"base_model.model.model.layers.{i}.{mod}.{ab}.weight"].grad
             assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(ref).all()), f"non-finite gradient L{i} {name}"
             e = rel(got, ref)
-            REPORT[f"grad_L{i}_{name}"] = e
+            REPORT[f"grad_L{i}_{name}{'_packed' if pack else ''}"] = e
             worst = max(worst, e)
     assert worst < 3e-2, f"worst LoRA gradient block rel err {worst}: {REPORT}"
     s["pol"].grad.zero_()
 
 
-def test_trainer_step_against_oracle(setup):
+@PACK
+def test_trainer_step_against_oracle(setup, pack):
     """rollout -> compute_policy_loss (CoPO + AncPO + scores) -> backward -> clip -> AdamW, vs the oracle."""
     s = setup
     LR = s["LR"]
@@ -181,7 +189,7 @@ def test_trainer_step_against_oracle(setup):
                            learning_rate=1e-3, warmup_steps=0, total_epochs=1, max_step=100, save_steps=1000,
                            output_dir="/tmp/none", seed=0, weight_decay=0.0, CoPO=True, AncPO=True, temperature=1.0)
     master0 = s["pol"].master.clone()
-    tr = DPOTrainer(args, _policy(s, s["pol"], T), _policy(s, s["ref"], T))
+    tr = DPOTrainer(args, _policy(s, s["pol"], T, pack), _policy(s, s["ref"], T, pack))
     tr.total_sched_steps = 10
     tr.optimizer.lr = 1e-3
     torch.manual_seed(77)                      # CoPO mask positions come from the global CPU RNG
@@ -240,6 +248,11 @@ def test_trainer_step_against_oracle(setup):
     REPORT["grad_norm_post_clip"] = tr.optimizer.grad_norm_post_clip()
     assert cos > 0.9, cos    # first Adam step is sign-like: near-zero gradient entries may flip
     assert abs(tr.optimizer.grad_norm_post_clip() - min(1.0, float(flat_g.norm()))) < 5e-2
+    # leave the shared fixture as it was (the optimizer moved the policy adapter)
+    s["pol"].master.copy_(master0)
+    s["pol"].work.copy_(master0.to(BF))
+    s["pol"].refresh_transposed()
+    s["pol"].grad.zero_()
 
 
 def test_generation_kv_cache_against_oracle(setup):
@@ -305,17 +318,18 @@ def test_wide_model_parity():
     want = LR.policy_forward(images, queries, qmask, two, W, ol, od, 1.0)
     oloss = sum((want[k + "_logprobs"] * wts[k]).sum() for k in two)
     oloss.backward()
-    for variant in (8, 10):          # forced 256x256 ping-pong GEMM everywhere / default auto dispatch
-        _wide_check(variant, lib, eng, ad, d, dev, images, queries, qmask, two, wts, want, ol, T)
+    # forced 256x256 ping-pong GEMM everywhere / default auto dispatch; responses packed on a shared prefix or stacked
+    for variant, pack in ((8, True), (10, True), (10, False)):
+        _wide_check(f"{variant}{'p' if pack else ''}", variant, pack, lib, eng, ad, d, dev, images, queries, qmask, two, wts, want, ol, T)
 
 
-def _wide_check(variant, lib, eng, ad, d, dev, images, queries, qmask, two, wts, want, ol, T):
+def _wide_check(tag, variant, pack, lib, eng, ad, d, dev, images, queries, qmask, two, wts, want, ol, T):
     from opadpo_amd.model import _peft_map, lora_blocks
     from opadpo_amd.policy import AutoregressivePolicy
     ad.grad.zero_()
     lib.set_flags(variant, True)
     try:
-        pol = AutoregressivePolicy(eng, ad, T)
+        pol = AutoregressivePolicy(eng, ad, T, pack_responses=pack)
         out = pol(images=images.to(dev), queries=queries, queries_attn_masks=qmask, **two)
         loss = sum((out[k + "_logprobs"] * wts[k].to(dev)).sum() for k in two)
         loss.backward()
@@ -327,7 +341,7 @@ def _wide_check(variant, lib, eng, ad, d, dev, images, queries, qmask, two, wts,
         got, w = out[k + "_logprobs"].detach().cpu(), want[k + "_logprobs"].detach()
         valid = two[k] != 0
         r = (got - w).abs()[valid] / w.abs()[valid].clamp_min(1e-3)
-        REPORT[f"wide_v{variant}_{k}_meanrel"], REPORT[f"wide_v{variant}_{k}_maxrel"] = float(r.mean()), float(r.max())
+        REPORT[f"wide_v{tag}_{k}_meanrel"], REPORT[f"wide_v{tag}_{k}_maxrel"] = float(r.mean()), float(r.max())
         worst = max(worst, float(r.mean()))
         assert bool((got[~valid] == 0).all())
     # bf16 noise floor at 7B width: measured 1.4e-3 mean relative against the fp32 oracle (|logp| ~ 10.4, i.e. ~0.015 nats);
@@ -343,7 +357,7 @@ def _wide_check(variant, lib, eng, ad, d, dev, images, queries, qmask, two, wts,
                 ref[r0:r0 + nr] = ol[f"base_model.model.model.layers.{i}.{mod}.{ab}.weight"].grad
             assert bool(torch.isfinite(got).all())
             e = rel(got, ref)
-            REPORT[f"wide_v{variant}_grad_L{i}_{name}"] = e
+            REPORT[f"wide_v{tag}_grad_L{i}_{name}"] = e
             gw = max(gw, e)
     assert gw < 3e-2, f"7B-width worst LoRA gradient block rel err {gw}"
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")

@@ -116,7 +116,7 @@ def main():
     for tr in (1, 0):
         L.set_flags(True, bool(tr))
         f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
-                           lse.data_ptr(), None, S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
+                           lse.data_ptr(), None, S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
         t = timeit(f)
         fl = S * nh * 2 * Ln * Ln * hd * 2 / 2
         res.append(dict(kernel="attn_fwd", tr=tr, ms=t * 1e3, tflops=fl / t / 1e12))
@@ -127,7 +127,7 @@ def main():
         do = torch.randn(S * Ln, H, device=dev).to(BF)
         f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
                            do.data_ptr(), H, lse.data_ptr(), None, dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
-                           None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, L.stream())
+                           None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
         t = timeit(f)
         res.append(dict(kernel="attn_bwd", tr=tr, ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
         print(res[-1], flush=True)
