@@ -71,7 +71,7 @@ def test_build_batch_stacking(golden_dir):
     assert response_keys(kw) == ["standard_response", "original_generate_response", "mask_standard_response"]
     eng = types.SimpleNamespace(dev=torch.device("cpu"), d=DM.LlavaDims.tiny())
     ad = types.SimpleNamespace(trainable=False)
-    pol = AutoregressivePolicy(eng, ad, response_len=5)
+    pol = AutoregressivePolicy(eng, ad, response_len=5, pack_responses=False)      # the reference's stacked layout
     g = load(golden_dir, "ref_policy_forward.npz")
     queries, qmask = t(g["queries"]), t(g["qmask"]).bool()
     resp = {k[5:]: t(v) for k, v in g.items() if k.startswith("resp_")}
@@ -87,6 +87,18 @@ def test_build_batch_stacking(golden_dir):
     im[0, 3] = False
     keys, b2 = pol.build_batch(queries, torch.cat([im, qmask], 1), resp)
     assert torch.equal(b2.text_mask.bool(), mask) and torch.equal(b2.image_mask.bool(), im.repeat(2, 1))
+    # packed layout (default): ONE row per sample = [query | response_0 | response_1 | ...]; the stacked rows of the
+    # reference are recovered by slicing segment k out of it
+    K, B, Q, T = len(keys), queries.shape[0], queries.shape[1], 5
+    polp = AutoregressivePolicy(eng, ad, response_len=5)
+    keys_p, bp = polp.build_batch(queries, torch.cat([im, qmask], 1), resp)
+    assert keys_p == keys and bp.K == K and bp.T == T and tuple(bp.ids.shape) == (B, Q + K * T)
+    assert bp.feat_row.tolist() == list(range(B)) and torch.equal(bp.image_mask.bool(), im)
+    for k in range(K):
+        seg = slice(Q + k * T, Q + (k + 1) * T)
+        assert torch.equal(torch.cat([bp.ids[:, :Q], bp.ids[:, seg]], 1).long(), ids[k * B:(k + 1) * B])
+        assert torch.equal(torch.cat([bp.text_mask[:, :Q], bp.text_mask[:, seg]], 1).bool(), mask[k * B:(k + 1) * B])
+    assert abs(DM.pair_flops_packed(DM.LlavaDims(), 128, 384, 2) / DM.pair_flops(DM.LlavaDims(), 128, 384) - 0.682) < 0.01
 
 
 def test_schedule_shards_and_arith():
