@@ -190,7 +190,10 @@ def main():
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
                           "loss": float(loss)},
                "executed_flops_per_pair_TF": fl / 1e12, "reference_layout_flops_per_pair_TF": fl_ref / 1e12,
+               # hardware utilisation: FLOPs this run executes; algorithmic: SURVEY.md §8(d) F_pair (4 full sequence forwards + dgrad +
+               # wgrad per pair — the shared prefix counted once per response like the reference computes it)
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+               "mfma_roofline_frac_algorithmic": value / world * fl_ref / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "roofline": roof}
         if args.model == "7b" and world == 1 and not args.no_cpu_baseline:
             try:
