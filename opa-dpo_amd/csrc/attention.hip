@@ -118,10 +118,14 @@ __device__ __forceinline__ void tile_commit(char* dst, const TileRegs<HD>& r, in
   }
 }
 
+// key-mask bytes of one K/V tile -> Ms[0..63]; Ms[64] = 1 when any key of the tile is masked or past L (block-uniform)
 __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, int s, int L, int k0, int tid) {
   if (tid < 64) {
     const int kp = k0 + tid;
-    Ms[tid] = (kp < L) ? (key_mask ? key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+    const uint8_t m = (kp < L) ? (key_mask ? key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+    Ms[tid] = m;
+    const uint64_t dead = __ballot(m == 0);
+    if (tid == 0) Ms[64] = dead != 0;
   }
 }
 
@@ -151,8 +155,8 @@ struct SegSkip {       // block-uniform: K/V tiles [lo, hi) are excluded for eve
 
 // ------------------------------------------------------------------------------------------------
 template <int HD, bool TR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 64];
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 80];
   char* Ks = smem;
   char* Vs = smem + 64 * HD * 2;
   uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
@@ -183,6 +187,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
   const SegSkip sk(p, q0, n_kt);
   const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
+  const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;     // end of the excluded key range of the tile's LAST row
+  const float scale2 = p.scale * 1.4426950408889634f;
   TileRegs<HD> kreg, vreg;
   tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
   tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
@@ -206,37 +212,51 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       for (int kk = 0; kk < KK; ++kk)
         sc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Ks, kf * 16 + c, kk, g), qf[kk], sc[kf], 0, 0, 0);
     }
-    // sc[kf][r] = S^T[key = kf*16 + g*4 + r][q = c]
+    // sc[kf][r] = S^T[key = kf*16 + g*4 + r][q = c]; scores in log2 units (scale2 = scale * log2 e -> bare v_exp_f32)
+    // `clean` (block-uniform): every key of the tile is visible to every row -> no mask arithmetic at all
+    const bool clean = !Ms[64] && (!p.causal || k0 + 63 <= q0) && (k0 + 63 < xlo || k0 >= xhi_blk);
     float mx = NEG_BIG;
-    bool ok[4][4];
+    if (clean) {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kl = kf * 16 + g * 4 + r;
-        ok[kf][r] = Ms[kl] && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
-        sc[kf][r] = ok[kf][r] ? sc[kf][r] * p.scale : NEG_BIG;
-        mx = fmaxf(mx, sc[kf][r]);
-      }
+        for (int r = 0; r < 4; ++r) {
+          sc[kf][r] *= scale2;
+          mx = fmaxf(mx, sc[kf][r]);
+        }
+    } else {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = kf * 16 + g * 4 + r;
+          const bool ok = Ms[kl] && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
+          sc[kf][r] = ok ? sc[kf][r] * scale2 : -INFINITY;      // exp2(-inf - m) = 0 (m stays finite: NEG_BIG floor)
+          mx = fmaxf(mx, sc[kf][r]);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = ok[kf][r] ? __expf(sc[kf][r] - m_new) : 0.f;
+        const float pv = fast_exp2(sc[kf][r] - m_new);
         sc[kf][r] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (__ballot(m_new != m_run)) {        // lazy rescale: the running max settles after a few tiles
+      const float alpha = fast_exp2(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int d = 0; d < DF; ++d) {
-      o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+      for (int d = 0; d < DF; ++d) {
+        o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+      }
     }
+    l_run += psum;
+    m_run = m_new;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const bf16x8_t pf = pack_frag(sc[2 * ks], sc[2 * ks + 1]);
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       v.y = pack_bf2(o[d][2] * inv, o[d][3] * inv);
       *(uint2*)(op + d * 16 + g * 4) = v;
     }
-    if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = l_run > 0.f ? m_run + __logf(l_run) : NEG_BIG;
+    if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
   }
 }
 
@@ -288,10 +308,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
 
 // ---- backward part 1: dK, dV (KV-outer) ---------------------------------------------------------
 template <int HD, bool TR>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   constexpr int KK = HD / 32, DF = HD / 16;
   constexpr int TILE = 64 * HD * 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64 * 4 * 2 + 64];
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64 * 4 * 2 + 80];
   char* Qs = smem;
   char* dOs = smem + TILE;
   float* lse_s = (float*)(smem + 2 * TILE);
@@ -323,9 +343,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
   for (int d = 0; d < DF; ++d) { dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   __syncthreads();
   const bool key_ok = Ms[w * 16 + c] != 0;
+  const bool keys_clean = !Ms[64];
+  const float scale2 = p.scale * 1.4426950408889634f;
 
   int n_qt = (L + 63) / 64;
   int kend = 0x7fffffff;                     // packed responses: a key in segment a is visible to queries < end of segment a
+  int kend_min = 0x7fffffff;                 // smallest kend over the keys of the tile (block-uniform)
+  if (p.seg_len > 0 && k0 + 63 >= p.seg_prefix)
+    kend_min = p.seg_prefix + ((max(k0, p.seg_prefix) - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
   if (p.seg_len > 0) {
     if (kpos >= p.seg_prefix) kend = p.seg_prefix + ((kpos - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
     if (k0 >= p.seg_prefix) {                // whole tile inside the response area: later segments never see it
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     stage_tile<HD>(dOs, p.dout, p.ldo, s, L, q0, h, tid);
     if (tid < 64) {
       const size_t li = ((size_t)s * p.nh + h) * L + min(q0 + tid, L - 1);
-      lse_s[tid] = p.lse[li];
+      lse_s[tid] = p.lse[li] * 1.4426950408889634f;      // log2 units
       dlt_s[tid] = p.delta[li];
     }
     __syncthreads();
@@ -356,14 +381,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
         dp[qf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(dOs, qf * 16 + c, kk, g), vf[kk], dp[qf], 0, 0, 0);
       }
     }
+    // block-uniform: every (q, key) of this tile pair is visible -> no mask arithmetic
+    const bool clean = keys_clean && q0 + 63 < L && (!p.causal || k0 + 63 <= q0) && q0 + 63 < kend_min;
 #pragma unroll
     for (int qf = 0; qf < 4; ++qf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = qf * 16 + g * 4 + r;
         const int qp = q0 + ql;
-        const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend;
-        const float pv = ok ? __expf(sc[qf][r] * p.scale - lse_s[ql]) : 0.f;
+        const bool ok = clean || (key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend);
+        const float pv = ok ? fast_exp2(sc[qf][r] * scale2 - lse_s[ql]) : 0.f;
         sc[qf][r] = pv;
         dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
       }
@@ -397,8 +424,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
 
 // ---- backward part 2: dQ (Q-outer, forward geometry, no atomics) ---------------------------------
 template <int HD, bool TR>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 64];
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 80];
   char* Ks = smem;
   char* Vs = smem + 64 * HD * 2;
   uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
@@ -425,7 +452,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     }
   }
   const size_t li = ((size_t)s * p.nh + h) * L + qrow;
-  const float lse = p.lse[li], dlt = p.delta[li];
+  const float lse2 = p.lse[li] * 1.4426950408889634f, dlt = p.delta[li];     // log2 units -> bare v_exp_f32
+  const float scale2 = p.scale * 1.4426950408889634f;
   f32x4_t dq[DF];
 #pragma unroll
   for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -433,6 +461,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
   const SegSkip sk(p, q0, n_kt);
   const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
+  const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;
   TileRegs<HD> kreg, vreg;
   tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
   tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
@@ -459,15 +488,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         dp[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row<HD>(Vs, kf * 16 + c, kk, g), dof[kk], dp[kf], 0, 0, 0);
       }
     }
+    const bool clean = !Ms[64] && q0 + 63 < L && (!p.causal || k0 + 63 <= q0) && (k0 + 63 < xlo || k0 >= xhi_blk);
+    if (clean) {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kl = kf * 16 + g * 4 + r;
-        const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
-        const float pv = ok ? __expf(sc[kf][r] * p.scale - lse) : 0.f;
-        dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const float pv = fast_exp2(sc[kf][r] * scale2 - lse2);
+          dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
+        }
+    } else {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = kf * 16 + g * 4 + r;
+          const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
+          const float pv = ok ? fast_exp2(sc[kf][r] * scale2 - lse2) : 0.f;
+          dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
+        }
+    }
     // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {

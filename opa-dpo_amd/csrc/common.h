@@ -15,17 +15,18 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
-// round-to-nearest-even, NaN preserved (same as torch .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, NaN preserved (same as torch .to(bfloat16)): gfx950 has the conversion in hardware
+// (v_cvt_pk_bf16_f32, two values per instruction) — a software rounding sequence costs ~6 VALU per value.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  const bf16x2_t r = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  return *(const uint32_t*)&r;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+
+// bare v_exp_f32 (2^x; exp2f() wraps it in denormal range scaling: +3 VALU per call)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);

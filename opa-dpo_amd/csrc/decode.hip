@@ -74,14 +74,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
       sc[u] = ok[u] ? a : -1.0e30f;
       mn = fmaxf(mn, sc[u]);
     }
-    const float alpha = exp2f(m - mn);
+    const float alpha = fast_exp2(m - mn);
     m = mn;
     l *= alpha;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= alpha;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float pj = ok[u] ? exp2f(sc[u] - m) : 0.f;
+      const float pj = ok[u] ? fast_exp2(sc[u] - m) : 0.f;
       float vf[8];
       unpack8(vv[u], vf);
       l += pj;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
     for (int i = 0; i < NG; ++i) M = fmaxf(M, sm_m[i]);
 #pragma unroll 4
     for (int i = 0; i < NG; ++i) {
-      const float w = exp2f(sm_m[i] - M);
+      const float w = fast_exp2(sm_m[i] - M);
       Lsum += sm_l[i] * w;
       O += sm_acc[i][tid] * w;
     }
@@ -124,7 +124,7 @@ __global__ void attn_decode_merge_kernel(const float* ws_part, bf16_t* o, int sp
   float LL = 0.f, OO = 0.f;
   for (int i = 0; i < splits; ++i) {
     const float* pi = p0 + (size_t)i * (HD + 2);
-    const float w = exp2f(pi[0] - MM);
+    const float w = fast_exp2(pi[0] - MM);
     LL += pi[1] * w;
     OO += pi[2 + tid] * w;
   }

@@ -34,6 +34,37 @@ def main():
     shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
               ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
     only = os.environ.get("GB_ONLY", "")
+    if only == "attn2":    # training attention at the bench shape: packed pairs [703 prefix | 384 | 384], realistic key mask
+        S, nh, hd, pfx, T, K = int(os.environ.get("GB_S", 22)), 32, 128, 703, 384, 2
+        Ln, H = pfx + K * T, nh * hd
+        qkv = torch.randn(S * Ln, 3 * H, device=dev).to(BF)
+        o = torch.empty(S * Ln, H, dtype=BF, device=dev)
+        lse = torch.empty(S, nh, Ln, device=dev)
+        km = torch.ones(S, Ln, dtype=torch.uint8, device=dev)
+        g = torch.Generator().manual_seed(0)
+        for s_ in range(S):
+            km[s_, 576:576 + int(torch.randint(0, 64, (1,), generator=g))] = 0          # left-padded query
+            for k in range(K):
+                n = int(torch.randint(64, 384, (1,), generator=g))
+                km[s_, pfx + k * T + n: pfx + (k + 1) * T] = 0                            # right-padded response
+        pairs = pfx * pfx / 2 + K * (T * pfx + T * T / 2)
+        fl = S * nh * 4 * hd * pairs
+        dqkv = torch.empty(S * Ln, 3 * H, dtype=BF, device=dev)
+        delta = torch.empty(S, nh, Ln, device=dev)
+        do = torch.randn(S * Ln, H, device=dev).to(BF)
+        for seg in ((pfx, T),):
+            f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+                               lse.data_ptr(), km.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, seg[0], seg[1], L.stream())
+            t = timeit(f, iters=5, warm=2)
+            res.append(dict(kernel="attn_fwd_packed", ms=t * 1e3, tflops=fl / t / 1e12))
+            print(res[-1], flush=True)
+            f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+                               do.data_ptr(), H, lse.data_ptr(), km.data_ptr(), dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
+                               None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, seg[0], seg[1], L.stream())
+            t = timeit(f, iters=5, warm=2)
+            res.append(dict(kernel="attn_bwd_packed", ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
+            print(res[-1], flush=True)
+        return
     if only == "skinny":   # decode-sized GEMMs: weight streaming rate; weights rotated over > 512 MB so MALL cannot hold them
         for M_ in (8, 16, 32, 64):
             for name, N, K1, K2, grp in shapes:
