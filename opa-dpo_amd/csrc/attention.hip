@@ -75,37 +75,35 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& a, const f32x4_t& b
   return u.v;
 }
 
-// stage a [64][HD] tile (rows = positions pos0.. of sequence s) into swizzled LDS, zero past L
+// Global side of a [64][HD] tile stream: one buffer descriptor per (operand, sequence) whose extent is exactly the L rows
+// of the sequence, so rows past L read as ZERO in hardware (no per-lane predicate, no exec juggling) and the per-tile
+// offset lives in the scalar soffset: a tile fetch is HD/32 buffer_load_dwordx4 with ONE precomputed VGPR offset.
 template <int HD>
-__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int ld, int s, int L, int pos0, int head, int tid) {
-  constexpr int CPR = HD / 8;  // 16-byte chunks per row
-#pragma unroll
-  for (int i = 0; i < (64 * CPR) / 256; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx / CPR, c16 = idx % CPR;
-    const int pos = pos0 + row;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (pos < L) v = *(const uint4*)(src + ((size_t)s * L + pos) * ld + head * HD + c16 * 8);
-    *(uint4*)(dst + row * (HD * 2) + ((c16 ^ swz_mask<HD>(row)) << 4)) = v;
+struct TileSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff;      // bytes: (row tid / CPR) * ld + head * HD + (tid % CPR) * 8 elements
+  int row_step;  // bytes between the row groups of consecutive passes
+  __device__ __forceinline__ TileSrc(const bf16_t* src, int ld, int s, int L, int head, int tid) {
+    constexpr int CPR = HD / 8;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)s * L * ld), 0, L * ld * 2, 0x00020000);
+    voff = ((tid / CPR) * ld + head * HD + (tid % CPR) * 8) * 2;
+    row_step = (256 / CPR) * ld * 2;
   }
-}
+};
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 // split staging (issue-early / write-late): global -> registers while the previous tile is being consumed,
 // registers -> swizzled LDS after the barrier that retires it.
 template <int HD>
-struct TileRegs { uint4 v[(64 * (HD / 8)) / 256]; };
+struct TileRegs { u32x4_t v[(64 * (HD / 8)) / 256]; };
 
 template <int HD>
-__device__ __forceinline__ void tile_fetch(TileRegs<HD>& r, const bf16_t* src, int ld, int s, int L, int pos0, int head, int tid) {
+__device__ __forceinline__ void tile_fetch(TileRegs<HD>& r, const TileSrc<HD>& ts, int ld, int pos0) {
   constexpr int CPR = HD / 8;
+  const int base = pos0 * ld * 2;
 #pragma unroll
-  for (int i = 0; i < (64 * CPR) / 256; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx / CPR, c16 = idx % CPR;
-    const int pos = pos0 + row;
-    r.v[i] = make_uint4(0, 0, 0, 0);
-    if (pos < L) r.v[i] = *(const uint4*)(src + ((size_t)s * L + pos) * ld + head * HD + c16 * 8);
-  }
+  for (int i = 0; i < (64 * CPR) / 256; ++i)
+    r.v[i] = __builtin_amdgcn_raw_buffer_load_b128(ts.rsrc, ts.voff, base + i * ts.row_step, 0);
 }
 template <int HD>
 __device__ __forceinline__ void tile_commit(char* dst, const TileRegs<HD>& r, int tid) {
@@ -114,8 +112,15 @@ __device__ __forceinline__ void tile_commit(char* dst, const TileRegs<HD>& r, in
   for (int i = 0; i < (64 * CPR) / 256; ++i) {
     const int idx = tid + i * 256;
     const int row = idx / CPR, c16 = idx % CPR;
-    *(uint4*)(dst + row * (HD * 2) + ((c16 ^ swz_mask<HD>(row)) << 4)) = r.v[i];
+    *(u32x4_t*)(dst + row * (HD * 2) + ((c16 ^ swz_mask<HD>(row)) << 4)) = r.v[i];
   }
+}
+// stage a [64][HD] tile (rows = positions pos0.. of the sequence) into swizzled LDS, zero past L
+template <int HD>
+__device__ __forceinline__ void stage_tile(char* dst, const TileSrc<HD>& ts, int ld, int pos0, int tid) {
+  TileRegs<HD> r;
+  tile_fetch<HD>(r, ts, ld, pos0);
+  tile_commit<HD>(dst, r, tid);
 }
 
 // key-mask bytes of one K/V tile -> Ms[0..63]; Ms[64] = 1 when any key of the tile is masked or past L (block-uniform)
@@ -189,9 +194,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
   const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;     // end of the excluded key range of the tile's LAST row
   const float scale2 = p.scale * 1.4426950408889634f;
+  const TileSrc<HD> ksrc(p.k, p.ld, s, L, h, tid), vsrc(p.v, p.ld, s, L, h, tid);
   TileRegs<HD> kreg, vreg;
-  tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
-  tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
+  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
   for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
     nxt = sk.next(kt);
     const int k0 = kt * 64;
@@ -200,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
     if (nxt < n_kt) {      // next tile's global loads fly while this one is consumed
-      tile_fetch<HD>(kreg, p.k, p.ld, s, L, nxt * 64, h, tid);
-      tile_fetch<HD>(vreg, p.v, p.ld, s, L, nxt * 64, h, tid);
+      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
     }
 
     f32x4_t sc[4];
@@ -344,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   __syncthreads();
   const bool key_ok = Ms[w * 16 + c] != 0;
   const bool keys_clean = !Ms[64];
+  const TileSrc<HD> qsrc(p.q, p.ld, s, L, h, tid), dosrc(p.dout, p.ldo, s, L, h, tid);
   const float scale2 = p.scale * 1.4426950408889634f;
 
   int n_qt = (L + 63) / 64;
@@ -360,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   }
   for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {       // (register budget: no prefetch ring here — 248 VGPRs already)
     const int q0 = qt * 64;
-    stage_tile<HD>(Qs, p.q, p.ld, s, L, q0, h, tid);
-    stage_tile<HD>(dOs, p.dout, p.ldo, s, L, q0, h, tid);
+    stage_tile<HD>(Qs, qsrc, p.ld, q0, tid);
+    stage_tile<HD>(dOs, dosrc, p.ldo, q0, tid);
     if (tid < 64) {
       const size_t li = ((size_t)s * p.nh + h) * L + min(q0 + tid, L - 1);
       lse_s[tid] = p.lse[li] * 1.4426950408889634f;      // log2 units
@@ -462,9 +469,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const SegSkip sk(p, q0, n_kt);
   const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
   const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;
+  const TileSrc<HD> ksrc(p.k, p.ld, s, L, h, tid), vsrc(p.v, p.ld, s, L, h, tid);
   TileRegs<HD> kreg, vreg;
-  tile_fetch<HD>(kreg, p.k, p.ld, s, L, sk.first() * 64, h, tid);
-  tile_fetch<HD>(vreg, p.v, p.ld, s, L, sk.first() * 64, h, tid);
+  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
   for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
     nxt = sk.next(kt);
     const int k0 = kt * 64;
@@ -473,8 +481,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     stage_mask(Ms, p.key_mask, s, L, k0, tid);
     __syncthreads();
     if (nxt < n_kt) {
-      tile_fetch<HD>(kreg, p.k, p.ld, s, L, nxt * 64, h, tid);
-      tile_fetch<HD>(vreg, p.v, p.ld, s, L, nxt * 64, h, tid);
+      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
     }
     f32x4_t sc[4], dp[4];
 #pragma unroll
