@@ -194,6 +194,7 @@ def main():
                # wgrad per pair — the shared prefix counted once per response like the reference computes it)
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "mfma_roofline_frac_algorithmic": value / world * fl_ref / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+               "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
                "roofline": roof}
         if args.model == "7b" and world == 1 and not args.no_cpu_baseline:
             try:

@@ -123,6 +123,33 @@ __device__ __forceinline__ void stage_tile(char* dst, const TileSrc<HD>& ts, int
   tile_commit<HD>(dst, r, tid);
 }
 
+// Direct-to-LDS staging (buffer_load_dwordx4 ... lds): no registers, no ds_write, completion tracked by vmcnt.  The DMA
+// writes lane-linear (wave instruction j of wave w fills the 1 KiB piece (j*4 + w) of the tile = 64/CPR consecutive rows), so
+// the tile's XOR swizzle is applied on the SOURCE side: lane (row r, LDS chunk c') fetches global chunk c' ^ swz(r).  swz only
+// depends on r mod 8, which is the same for every j -> ONE per-lane offset, the row group / tile position go in soffset.
+template <int HD>
+struct TileDma {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff, row_step, w;
+  __device__ __forceinline__ TileDma(const bf16_t* src, int ld, int s, int L, int head, int tid) {
+    constexpr int CPR = HD / 8, RPI = 64 / CPR;     // 16-B chunks per row, rows per wave instruction
+    const int lane = tid & 63;
+    w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = w * RPI + lane / CPR;             // row inside the 4*RPI-row group of one pass
+    const int c = (lane % CPR) ^ swz_mask<HD>(r);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)s * L * ld), 0, L * ld * 2, 0x00020000);
+    voff = (r * ld + head * HD + c * 8) * 2;
+    row_step = 4 * RPI * ld * 2;
+  }
+  __device__ __forceinline__ void issue(char* tile, int ld, int pos0) const {
+    constexpr int CPR = HD / 8, RPI = 64 / CPR;
+    const int base = pos0 * ld * 2;
+#pragma unroll
+    for (int j = 0; j < 64 / (4 * RPI); ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(void, tile + (j * 4 + w) * 1024), 16, voff, base + j * row_step, 0, 0);
+  }
+};
+
 // key-mask bytes of one K/V tile -> Ms[0..63]; Ms[64] = 1 when any key of the tile is masked or past L (block-uniform)
 __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, int s, int L, int k0, int tid) {
   if (tid < 64) {
@@ -159,12 +186,13 @@ struct SegSkip {       // block-uniform: K/V tiles [lo, hi) are excluded for eve
 };
 
 // ------------------------------------------------------------------------------------------------
-template <int HD, bool TR>
+// DMA: K/V tiles land in a double-buffered LDS ring through direct-to-LDS loads, one barrier per tile (the tile of the
+// next iteration is in flight while this one is consumed); !DMA: register-staged single buffer, two barriers per tile.
+template <int HD, bool TR, bool DMA>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 80];
-  char* Ks = smem;
-  char* Vs = smem + 64 * HD * 2;
-  uint8_t* Ms = (uint8_t*)(smem + 2 * 64 * HD * 2);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = 64 * HD * 2;
+  uint8_t* const ms_base = (uint8_t*)(smem + (DMA ? 4 : 2) * TILE);
   constexpr int KK = HD / 32, DF = HD / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -195,19 +223,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;     // end of the excluded key range of the tile's LAST row
   const float scale2 = p.scale * 1.4426950408889634f;
   const TileSrc<HD> ksrc(p.k, p.ld, s, L, h, tid), vsrc(p.v, p.ld, s, L, h, tid);
+  const TileDma<HD> kdma(p.k, p.ld, s, L, h, tid), vdma(p.v, p.ld, s, L, h, tid);
   TileRegs<HD> kreg, vreg;
-  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
-  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
+  if constexpr (DMA) {
+    kdma.issue(smem, p.ld, sk.first() * 64);
+    vdma.issue(smem + TILE, p.ld, sk.first() * 64);
+    stage_mask(ms_base, p.key_mask, s, L, sk.first() * 64, tid);
+  } else {
+    tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+    tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
+  }
+  int cur = 0;
   for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
     nxt = sk.next(kt);
     const int k0 = kt * 64;
-    tile_commit<HD>(Ks, kreg, tid);
-    tile_commit<HD>(Vs, vreg, tid);
-    stage_mask(Ms, p.key_mask, s, L, k0, tid);
-    __syncthreads();
-    if (nxt < n_kt) {      // next tile's global loads fly while this one is consumed
-      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
-      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
+    char* const Ks = smem + (DMA ? cur * 2 * TILE : 0);
+    char* const Vs = Ks + TILE;
+    uint8_t* const Ms = ms_base + (DMA ? cur * 80 : 0);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();        // tile kt has landed for everyone AND everyone is done reading the other buffer
+      if (nxt < n_kt) {
+        kdma.issue(smem + (cur ^ 1) * 2 * TILE, p.ld, nxt * 64);
+        vdma.issue(smem + (cur ^ 1) * 2 * TILE + TILE, p.ld, nxt * 64);
+        stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, s, L, nxt * 64, tid);
+      }
+      cur ^= 1;
+    } else {
+      tile_commit<HD>(Ks, kreg, tid);
+      tile_commit<HD>(Vs, vreg, tid);
+      stage_mask(Ms, p.key_mask, s, L, k0, tid);
+      __syncthreads();
+      if (nxt < n_kt) {      // next tile's global loads fly while this one is consumed
+        tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+        tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
+      }
     }
 
     f32x4_t sc[4];
@@ -272,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[d], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if constexpr (!DMA) __syncthreads();
   }
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -317,12 +367,11 @@ template <int HD, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   constexpr int KK = HD / 32, DF = HD / 16;
   constexpr int TILE = 64 * HD * 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64 * 4 * 2 + 80];
-  char* Qs = smem;
-  char* dOs = smem + TILE;
-  float* lse_s = (float*)(smem + 2 * TILE);
-  float* dlt_s = lse_s + 64;
-  uint8_t* Ms = (uint8_t*)(dlt_s + 64);
+  // Q / dO tiles: direct-to-LDS double-buffered ring (the kernel sits at 2 blocks per CU for its registers anyway, so the
+  // 64 KiB of LDS are free): the next q tile is in flight while this one is consumed, one barrier per tile.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const ls_base = (float*)(smem + 4 * TILE);        // [2][lse 64 | delta 64]
+  uint8_t* Ms = (uint8_t*)(ls_base + 256);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int s = blockIdx.z, h = blockIdx.y, kt = blockIdx.x;
@@ -350,7 +399,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   __syncthreads();
   const bool key_ok = Ms[w * 16 + c] != 0;
   const bool keys_clean = !Ms[64];
-  const TileSrc<HD> qsrc(p.q, p.ld, s, L, h, tid), dosrc(p.dout, p.ldo, s, L, h, tid);
   const float scale2 = p.scale * 1.4426950408889634f;
 
   int n_qt = (L + 63) / 64;
@@ -365,16 +413,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
       n_qt = min(n_qt, (q_cut + 63) / 64);
     }
   }
-  for (int qt = p.causal ? kt : 0; qt < n_qt; ++qt) {       // (register budget: no prefetch ring here — 248 VGPRs already)
-    const int q0 = qt * 64;
-    stage_tile<HD>(Qs, qsrc, p.ld, q0, tid);
-    stage_tile<HD>(dOs, dosrc, p.ldo, q0, tid);
+  const TileDma<HD> qdma(p.q, p.ld, s, L, h, tid), dodma(p.dout, p.ldo, s, L, h, tid);
+  float lse_r = 0.f, dlt_r = 0.f;      // wave 0: lse / delta of the tile in flight (written to LDS one iteration later, so
+                                       // that nobody waits on these loads right behind the DMA issue)
+  auto stage = [&](int buf, int q0) {
+    qdma.issue(smem + buf * 2 * TILE, p.ld, q0);
+    dodma.issue(smem + buf * 2 * TILE + TILE, p.ldo, q0);
     if (tid < 64) {
       const size_t li = ((size_t)s * p.nh + h) * L + min(q0 + tid, L - 1);
-      lse_s[tid] = p.lse[li] * 1.4426950408889634f;      // log2 units
-      dlt_s[tid] = p.delta[li];
+      lse_r = p.lse[li] * 1.4426950408889634f;      // log2 units
+      dlt_r = p.delta[li];
     }
-    __syncthreads();
+  };
+  const int qt0 = p.causal ? kt : 0;
+  if (qt0 < n_qt) stage(0, qt0 * 64);
+  int cur = 0;
+  for (int qt = qt0; qt < n_qt; ++qt) {
+    const int q0 = qt * 64;
+    const char* Qs = smem + cur * 2 * TILE;
+    const char* dOs = Qs + TILE;
+    const float* lse_s = ls_base + cur * 128;
+    const float* dlt_s = lse_s + 64;
+    if (tid < 64) {
+      ls_base[cur * 128 + tid] = lse_r;
+      ls_base[cur * 128 + 64 + tid] = dlt_r;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // tile qt landed for everyone; everyone is done with the other buffer
+    if (qt + 1 < n_qt) stage(cur ^ 1, q0 + 64);
+    cur ^= 1;
 
     f32x4_t sc[4], dp[4];
 #pragma unroll
@@ -413,7 +480,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
         dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_col<HD, TR>(Qs, r0, r1, d * 16, lane), dsf, dk[d], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
   if (kpos < L) {
     bf16_t* dkp = p.dk + ((size_t)s * L + kpos) * p.ld + h * HD;
@@ -549,19 +615,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
 }  // namespace
 
+static bool g_attn_dma = false;   // measured: the 64-KiB ring allows 2 blocks/CU, the 32-KiB register-staged kernel 3 -> 0.92 vs 1.01 ms
+void opadpo_set_attn_dma(bool on) { g_attn_dma = on; }
+
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
+  if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   const dim3 grid((a.L + 63) / 64, a.nh, a.S);
   const bool tr = opadpo_flag_tr();
-  if (a.hd == 128) {
-    if (tr) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, st, a);
-  } else if (a.hd == 64) {
-    if (tr) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, st, a);
-  } else {
-    return hipErrorInvalidValue;
+  const bool dma = g_attn_dma && (double)a.L * a.ld * 2 < 2.0e9;     // per-sequence extent must fit the 32-bit descriptor
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160);
+    attr_set = true;
   }
+#define FWD(HD_, TR_, DMA_) hipLaunchKernelGGL((attn_fwd_kernel<HD_, TR_, DMA_>), grid, dim3(256), (DMA_ ? 4 : 2) * 64 * HD_ * 2 + (DMA_ ? 160 : 80), st, a)
+  if (a.hd == 128) {
+    if (tr) { if (dma) FWD(128, true, true); else FWD(128, true, false); }
+    else    { if (dma) FWD(128, false, true); else FWD(128, false, false); }
+  } else {
+    if (tr) { if (dma) FWD(64, true, true); else FWD(64, true, false); }
+    else    { if (dma) FWD(64, false, true); else FWD(64, false, false); }
+  }
+#undef FWD
   return hipGetLastError();
 }
 
@@ -571,9 +648,16 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   const int total = a.S * a.L * a.nh;
   const dim3 grid((a.L + 63) / 64, a.nh, a.S);
   const bool tr = opadpo_flag_tr();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80);
+    attr_set = true;
+  }
+  if ((double)a.L * a.ld * 2 >= 2.0e9 || (double)a.L * a.ldo * 2 >= 2.0e9) return hipErrorInvalidValue;   // 32-bit buffer extents
 #define LAUNCH_BWD(HD_, TR_)                                                                              \
   hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((total + 3) / 4), dim3(256), 0, st, a);               \
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 0, st, a);                        \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 4 * 64 * HD_ * 2 + 1024 + 80, st, a); \
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
   if (a.hd == 128) {
     if (tr) { LAUNCH_BWD(128, true); } else { LAUNCH_BWD(128, false); }

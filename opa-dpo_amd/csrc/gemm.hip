@@ -859,7 +859,8 @@ static int g_gemm_variant = 10;   // 0: register staging, 1: LDS-DMA 16x16x32, 2
 static bool g_use_tr = true;
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
-  g_use_tr = use_tr != 0;
+  g_use_tr = (use_tr & 1) != 0;
+  opadpo_set_attn_dma((use_tr & 2) != 0);
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 

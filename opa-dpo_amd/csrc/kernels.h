@@ -51,6 +51,7 @@ struct AttnArgs {
 
 void opadpo_set_flags_impl(int use_glds, int use_tr);
 bool opadpo_flag_tr();
+void opadpo_set_attn_dma(bool on);
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);

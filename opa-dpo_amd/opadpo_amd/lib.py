@@ -92,7 +92,9 @@ def load() -> C.CDLL:
 def set_flags(use_glds=10, use_tr: bool = True) -> None:
     """gemm_nt variant: 0 register staging, 1 LDS-DMA + 16x16x32 MFMA, 2 LDS-DMA + 32x32x16, 3 three-stage ring
     128x256, 4 LDS-DMA + 16x16x32 + s_setprio at <=128 VGPRs, 5-7 BK=32 experiments, 8/9 256x256 ping-pong,
-    10 (default) auto: ping-pong for large GEMMs, variant 4 otherwise.  True -> default."""
+    10 (default) auto: ping-pong for large GEMMs, variant 4 otherwise.  True -> default.
+    use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V ring
+    (default: register-staged single buffer, 3 blocks per CU)."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 

@@ -197,11 +197,11 @@ def ref_attention(q, k, v, key_mask, causal, scale, seg=(0, 0)):
     return torch.einsum("shqk,skhd->sqhd", p, v)
 
 
-@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("tr", [1, 0, 3])      # 3 = transposed reads + direct-to-LDS double-buffered forward
 @pytest.mark.parametrize("S,Ln,nh,hd,causal,masked", [(2, 200, 2, 128, 1, True), (1, 64, 1, 128, 1, False),
                                                        (2, 77, 2, 64, 0, False), (1, 300, 1, 64, 1, True)])
 def test_attn_fwd(L, tr, S, Ln, nh, hd, causal, masked):
-    L.set_flags(True, bool(tr))
+    L.set_flags(True, tr)
     H = nh * hd
     qkv = rnd(S * Ln, 3 * H, scale=1.0, seed=7)
     km = None
@@ -262,13 +262,13 @@ def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
         assert e < 2e-2, f"attn_bwd {name} rel err {e}"
 
 
-@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("tr", [1, 0, 3])
 @pytest.mark.parametrize("S,nh,hd,pfx,T,K", [(2, 2, 128, 70, 37, 2), (1, 1, 128, 130, 100, 3), (2, 2, 64, 64, 64, 2), (1, 2, 128, 5, 150, 2),
                                              (1, 1, 128, 200, 128, 3)])
 def test_attn_packed_responses(L, tr, S, nh, hd, pfx, T, K):
     """seg_len > 0: rows are [prefix | response_0 | ... | response_{K-1}]; forward and backward equal (a) torch attention
     with the explicit segment mask and (b) K separate [prefix | response_k] sequences — what the reference runs."""
-    L.set_flags(True, bool(tr))
+    L.set_flags(True, tr)
     H = nh * hd
     Ln = pfx + K * T
     scale = hd ** -0.5

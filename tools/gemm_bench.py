@@ -52,6 +52,7 @@ def main():
         dqkv = torch.empty(S * Ln, 3 * H, dtype=BF, device=dev)
         delta = torch.empty(S, nh, Ln, device=dev)
         do = torch.randn(S * Ln, H, device=dev).to(BF)
+        L.set_flags(True, int(os.environ.get("GB_TR", 1)))
         for seg in ((pfx, T),):
             f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
                                lse.data_ptr(), km.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, seg[0], seg[1], L.stream())
