@@ -16,6 +16,7 @@
 //            atomics (gradients accumulate across micro-batches anyway).
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -658,6 +659,359 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_nt "w4" kernel: 256x256 tile, BK = 64, FOUR waves (2x2), each owning a 128x128 block of C in 64 accumulator
+// fragments (256 accumulator registers -> one wave per SIMD, 512-register budget), two 64-KiB LDS stages filled by
+// buffer_load ... lds.  One wave per SIMD means nothing else can feed the matrix pipe, so every non-MFMA instruction of
+// the K-loop is placed INSIDE the MFMA stream (one issue slot per 2-4 MFMAs, pinned with sched_barrier), the pipe never
+// waits for a phase change of a sibling wave, and a wave reads each LDS fragment for 8 MFMAs (128 KiB of LDS reads per
+// K-tile and block instead of 192 KiB in the 8-wave kernel):
+//   sub-step (t,0): 64 MFMAs on fragment set 0 | 16 ds_read_b128 of set 1 (k 32..63 of tile t) | DMA pieces 8..15 of tile t+1
+//   sub-step (t,1): 32 MFMAs on set 1 | s_waitcnt vmcnt(0) + ONE barrier (tile t+1 landed, tile t's stage is free)
+//                 | 32 MFMAs | 16 ds_read_b128 of set 0 of tile t+1 | DMA pieces 0..7 of tile t+2
+// so a DMA piece is issued >= 64 MFMAs (~1100 cycles) before the barrier that waits for it.
+// Measured on 8192^3 (uniform random operands): this schedule 1.26-1.32 PF/s; without the in-loop DMA 1.56-1.68, with every
+// K-tile re-reading k = 0 (all L2 hits) 1.40-1.46: about half of the DMA cost is HBM / Infinity-Cache miss latency that a
+// <= 1-tile lead cannot hide.  Releasing the stage per operand behind extra barriers (the schedule of the vendor library's
+// hand-written 256x256x64 kernel, which waits with vmcnt(13) three quarters into the NEXT tile: 1.55-1.6 PF/s) was tried in
+// two forms and measured 0.88-1.13 PF/s here (the extra barriers + lgkmcnt(0) drains cost more than the longer lead wins in
+// compiler-scheduled code); a cooperative L2 prefetch of tile t+3 (each block touches its share of the XCD's unique lines)
+// gave +6 % on 8192^3 and -6 % on 4096^3.  Kept as variant 16 (diagnostics 18-21); the default large-GEMM kernel is p8.
+// ------------------------------------------------------------------------------------------
+template <int EXP>   // EXP (diagnostics, wrong results): 1 = no DMA in the K-loop, 2 = no LDS fragment reads in the K-loop
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * P_BM, n0 = tn * P_BN;
+
+  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? a2 : p.A1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const unsigned lrow = (unsigned)(wave * 64 + srow);                     // row of this wave's piece 0 inside the 256-row tile
+  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  const unsigned m_last = (unsigned)(p.M - 1);
+  // q = 0..7: A pieces (8 rows x 128 B each) wave*8 + q, q = 8..15: B pieces
+  auto issue_piece = [&](int t, int q) {
+    const bool second = t >= nt1;
+    const int k0 = EXP == 4 ? 0 : (second ? (t - nt1) : t) * P_BK;
+    char* base = smem + (t & 1) * P_STAGE;
+    const int pi = q & 7;
+    const int piece = wave * 8 + pi;
+    if constexpr (EXP == 3) {
+      if (t >= 2) {      // timing experiment: same 1 KiB for every piece -> L1 hits, only the issue cost remains
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(void, base + (q < 8 ? 0 : P_TILE) + piece * 1024), 16, lane * 16, 0, 0, 0);
+        return;
+      }
+    }
+    if (q < 8) {
+      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
+      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, row * ld2 + csw[pi & 1], k0 * 2, 0, 0);
+    } else {
+      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+      const unsigned soff = ((unsigned)n0 + pi * 8u) * ld2 + k0 * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, lrow * ld2 + csw[pi & 1], soff, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[2][8], fb[2][8];
+  const int frow = lane & 15, fchk = lane >> 4;
+  const int fsw = (frow >> 1) & 7;                                       // swizzle term: same for every fragment of a lane
+  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + frow) * 128;
+  // fragment r of set kk of tile t: r = 0..7 -> B fragments, 8..15 -> A fragments
+  auto read_frag = [&](int t, int kk, int r) {
+    const char* st = smem + (t & 1) * P_STAGE;
+    const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
+    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + r * 2048 + cb);
+    else fa[kk][r - 8] = *(const bf16x8_t*)(st + offA + (r - 8) * 2048 + cb);
+  };
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+  // MFMAs idx0..idx0+n-1 of a sub-step (idx = i*8 + j: A fragment i is needed from idx 8i on)
+  auto mfma_run = [&](int kk, int idx0, int n) {
+#pragma unroll
+    for (int e = 0; e < n; ++e) {
+      const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto tile_body = [&](int t, auto ISSUE_B, auto HAS_NEXT, auto HAS_NEXT2) {
+    constexpr bool issue_b = decltype(ISSUE_B)::value, has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
+    // ---- sub-step 0: set 0 in registers; stream set 1 of this tile out of LDS, finish the DMA of tile t+1
+#pragma unroll
+    for (int g4 = 0; g4 < 16; ++g4) {
+      mfma_run(0, g4 * 4, 4);
+      W4_PIN();
+      if constexpr (EXP != 2) read_frag(t, 1, g4);
+      if constexpr (issue_b && EXP != 1) { if (g4 < 8) issue_piece(t + 1, 8 + g4); }
+      W4_PIN();
+    }
+    // ---- sub-step 1, first half
+    mfma_run(1, 0, 32);
+    W4_PIN();
+    if constexpr (has_next) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    W4_PIN();
+    // ---- second half: set 0 of the next tile, first DMA pieces of tile t+2 (its stage is the one just retired)
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) {
+      mfma_run(1, 32 + g4 * 4, 4);
+      W4_PIN();
+      if constexpr (has_next && EXP != 2) { read_frag(t + 1, 0, 2 * g4); read_frag(t + 1, 0, 2 * g4 + 1); }
+      if constexpr (has_next2 && EXP != 1) issue_piece(t + 2, g4);
+      W4_PIN();
+    }
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+
+#pragma unroll
+  for (int q = 0; q < 16; ++q) issue_piece(0, q);
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(1, q);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  W4_PIN();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
+  W4_PIN();
+  if (nt == 1) {
+    tile_body(0, F_{}, F_{}, F_{});
+  } else if (nt == 2) {
+    tile_body(0, F_{}, T_{}, F_{});
+    tile_body(1, F_{}, F_{}, F_{});
+  } else {
+    tile_body(0, F_{}, T_{}, T_{});
+    for (int t = 1; t < nt - 2; ++t) tile_body(t, T_{}, T_{}, T_{});
+    tile_body(nt - 2, T_{}, T_{}, F_{});
+    tile_body(nt - 1, F_{}, F_{}, F_{});
+  }
+#undef W4_PIN
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      epilogue4(p, m, n0 + wc * 128 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt "p8" kernel: the 256x256 / BK 64 / 8-wave (2x4, 128x64 per wave) geometry of the ping-pong kernel with FOUR
+// phases per K-tile instead of one.  A phase = read block (the ds_read_b128 of one 64x32 quadrant of the wave's C block,
+// TWO LDS-DMA pieces, a counted s_waitcnt vmcnt) | barrier | 16 MFMAs under s_setprio 1 | barrier.  The wave groups
+// G0 = waves 0-3 (rows 0..127) and G1 = waves 4-7 run the same program one barrier apart, so on every SIMD one wave is in
+// its MFMA block while its sibling is in its read block: a ~60-cycle LDS-DMA issue never sits between two MFMAs of the
+// only wave that could feed the matrix pipe, and read block (2 DMA + 4..12 reads) and MFMA block (16 x 17 cycles) are the
+// same length.  Quadrant order (a,b) = (0,0) (0,1) (1,1) (1,0): reads 12 / 4 / 8 / 0 fragments (both B halves stay in
+// registers), so every region of a stage is dead after the third phase and is re-staged for tile t+2 at least 3 slots
+// (a slot = half a phase) after its last reader and at least 4 of the issuing wave's read blocks before its first
+// reader: ONE rule, s_waitcnt vmcnt(8) (2 pieces x 4 read blocks stay in flight) in every read block.
+//   stage regions (8 KiB = 8 DMA pieces each): A rows 0-63 / 64-127 (read by G0 only), 128-191 / 192-255 (G1 only),
+//   B rows of the even 32-row blocks (b = 0) split in two, B rows of the odd blocks (b = 1) split in two.
+//   issue schedule (tile T = the tile being computed):     p0            p1            p2            p3
+//       G0 (2 pieces per wave and phase)                Bb1.h2(T+1)   A1.a1(T+1)    A1.a0(T+2)    Bb0.h2(T+2)
+//       G1                                              A0.a1(T+1)    A0.a0(T+2)    Bb0.h1(T+2)   Bb1.h1(T+2)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = tm * P_BM, n0 = tn * P_BN;
+
+  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? a2 : p.A1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  const unsigned m_last = (unsigned)(p.M - 1);
+  // one 1-KiB piece (8 rows x 128 B) of K-tile t: A piece pc = rows pc*8.. of the 256-row A tile, B piece likewise
+  auto issue_A = [&](int t, int pc) {
+    if (t >= nt) return;
+    const bool second = t >= nt1;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
+    const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
+    const unsigned row = min((unsigned)m0 + pc * 8u + srow, m_last);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, smem + (t & 1) * P_STAGE + pc * 1024), 16,
+                                             row * ld2 + csw[pc & 1], k0 * 2, 0, 0);
+  };
+  auto issue_B = [&](int t, int pc) {
+    if (t >= nt) return;
+    const bool second = t >= nt1;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
+    const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, smem + (t & 1) * P_STAGE + P_TILE + pc * 1024), 16,
+                                             (unsigned)srow * ld2 + csw[pc & 1], ((unsigned)n0 + pc * 8u) * ld2 + k0 * 2, 0, 0);
+  };
+  const int wl = wave & 3;
+  // region -> this wave's two pieces (e = wl*2 + j, j = 0,1)
+  auto piece_A = [&](int half, int a, int j) { return half * 16 + a * 8 + wl * 2 + j; };                 // A{half}.a{a}
+  auto piece_B = [&](int b, int h, int j) {                                                              // Bb{b}.h{h+1}
+    const int e = wl * 2 + j;                       // 0..7 inside the 8-piece half-region
+    return h * 16 + (e >> 2) * 8 + b * 4 + (e & 3);
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[2][4], bfr[2][4];
+  const int frow = lane & 15, fchk = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 64 + frow) * 128;
+  auto read_A = [&](int t, int a) {      // 8 fragments: rows a*64 + i*16 of the wave's 128
+    const char* st = smem + (t & 1) * P_STAGE + offA + a * 64 * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = *(const bf16x8_t*)(st + i * 2048 + (((kk * 4 + fchk) ^ fsw) << 4));
+  };
+  auto read_B = [&](int t, int b) {      // 4 fragments: cols b*32 + j*16 of the wave's 64
+    const char* st = smem + (t & 1) * P_STAGE + offB + b * 32 * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[kk][b * 2 + j] = *(const bf16x8_t*)(st + j * 2048 + (((kk * 4 + fchk) ^ fsw) << 4));
+  };
+  auto mfma_q = [&](int a, int b) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][b * 2 + j], af[kk][i], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define P8_BAR()                                   \
+  do {                                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    __builtin_amdgcn_s_barrier();                  \
+    __builtin_amdgcn_sched_barrier(0);             \
+  } while (0)
+  // phase tail: counted wait for this wave's older DMA pieces, barrier, fragments landed, MFMAs, barrier
+#define P8_COMPUTE(a, b, steady)                                                        \
+  do {                                                                                  \
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+    P8_BAR();                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    mfma_q(a, b);                                                                       \
+    P8_BAR();                                                                           \
+  } while (0)
+
+  // prologue: all of tile 0, and the regions of tile 1 that the in-loop schedule does not deliver during tile 0
+  // (A0.a0, A1.a0, Bb0.h1, Bb0.h2, Bb1.h1); in-loop: A0.a1(1), A1.a1(1), Bb1.h2(1)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { issue_A(0, wave * 4 + q); issue_B(0, wave * 4 + q); }
+  if (wr == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { issue_A(1, piece_A(0, 0, j)); issue_B(1, piece_B(0, 0, j)); issue_B(1, piece_B(1, 0, j)); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { issue_A(1, piece_A(1, 0, j)); issue_B(1, piece_B(0, 1, j)); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P8_BAR();
+
+  if (wr == 0) {
+    for (int t = 0; t < nt; ++t) {
+      const bool steady = t + 2 < nt;
+      read_A(t, 0); read_B(t, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_B(t + 1, piece_B(1, 1, 0)); issue_B(t + 1, piece_B(1, 1, 1));
+      P8_COMPUTE(0, 0, steady);
+      read_B(t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_A(t + 1, piece_A(1, 1, 0)); issue_A(t + 1, piece_A(1, 1, 1));
+      P8_COMPUTE(0, 1, steady);
+      read_A(t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_A(t + 2, piece_A(1, 0, 0)); issue_A(t + 2, piece_A(1, 0, 1));
+      P8_COMPUTE(1, 1, steady);
+      issue_B(t + 2, piece_B(0, 1, 0)); issue_B(t + 2, piece_B(0, 1, 1));
+      P8_COMPUTE(1, 0, steady);
+    }
+    P8_BAR();
+  } else {
+    P8_BAR();
+    for (int t = 0; t < nt; ++t) {
+      const bool steady = t + 2 < nt;
+      read_A(t, 0); read_B(t, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_A(t + 1, piece_A(0, 1, 0)); issue_A(t + 1, piece_A(0, 1, 1));
+      P8_COMPUTE(0, 0, steady);
+      read_B(t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_A(t + 2, piece_A(0, 0, 0)); issue_A(t + 2, piece_A(0, 0, 1));
+      P8_COMPUTE(0, 1, steady);
+      read_A(t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_B(t + 2, piece_B(0, 0, 0)); issue_B(t + 2, piece_B(0, 0, 1));
+      P8_COMPUTE(1, 1, steady);
+      issue_B(t + 2, piece_B(1, 0, 0)); issue_B(t + 2, piece_B(1, 0, 1));
+      P8_COMPUTE(1, 0, steady);
+    }
+  }
+#undef P8_COMPUTE
+#undef P8_BAR
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      epilogue4(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN (wgrad) GEMM
 // ------------------------------------------------------------------------------------------
 constexpr int TK = 64;  // rows (m) per LDS stage
@@ -879,6 +1233,12 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
 #define PP_ATTR(...) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE)
     PP_ATTR(false); PP_ATTR(true); PP_ATTR(false, false); PP_ATTR(false, true, false); PP_ATTR(false, true, true, 16); PP_ATTR(false, true, true, 4);
 #undef PP_ATTR
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
   }
@@ -900,6 +1260,21 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
   const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
   const bool auto_pp = g_gemm_variant == 10 && pp_tiles >= 384;
+  if (g_gemm_variant == 17 && pp_tiles > 0) {
+    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
+  if ((g_gemm_variant >= 18 && g_gemm_variant <= 21) && pp_tiles > 0) {      // timing experiments only (wrong results)
+    if (g_gemm_variant == 21) { hipLaunchKernelGGL(gemm_nt_w4_kernel<4>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a); return hipGetLastError(); }
+    if (g_gemm_variant == 20) hipLaunchKernelGGL(gemm_nt_w4_kernel<3>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    else if (g_gemm_variant == 18) hipLaunchKernelGGL(gemm_nt_w4_kernel<1>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<2>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
+  if (g_gemm_variant == 16 && pp_tiles > 0) {
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<0>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if (g_gemm_variant >= 11 && g_gemm_variant <= 14 && pp_tiles > 0) {      // schedule experiments
     const dim3 gr(pp_tiles), bl(512);
     if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false>), gr, bl, 2 * P_STAGE, st, a);
@@ -908,7 +1283,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 4>), gr, bl, 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if ((g_gemm_variant == 8 || g_gemm_variant == 9 || auto_pp) && pp_tiles > 0) {
+  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: the 4-phase-per-K-tile kernel
+    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
+  if ((g_gemm_variant == 8 || g_gemm_variant == 9) && pp_tiles > 0) {
     const int pt = pp_tiles;
     if (g_gemm_variant != 9) hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
     else hipLaunchKernelGGL(gemm_nt_pp_kernel<true>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);

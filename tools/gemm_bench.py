@@ -66,6 +66,21 @@ def main():
             res.append(dict(kernel="attn_bwd_packed", ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
             print(res[-1], flush=True)
         return
+    if only == "cube":     # yardstick shapes of the micro-architecture guide's 256^2 template: 4096^3 and 8192^3, uniform [-1,1)
+        for n in (4096, 8192):
+            a1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
+            b1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
+            out = torch.empty(n, n, dtype=BF, device=dev)
+            for variant in [int(v) for v in os.environ.get("GB_VARIANTS", "17,16,8,4,-1").split(",")]:
+                if variant >= 0:
+                    L.set_flags(variant, True)
+                    t = timeit(lambda: L.gemm_nt(a1, b1, out), iters=20, warm=5)
+                else:
+                    t = timeit(lambda: torch.matmul(a1, b1.t(), out=out), iters=20, warm=5)
+                res.append(dict(kernel={17: "p8_256", 16: "w4_256", 8: "pp256", 4: "x128", -1: "hipBLASLt"}.get(variant, f"v{variant}"), n=n, ms=t * 1e3, tflops=2.0 * n ** 3 / t / 1e12))
+                print(res[-1], flush=True)
+        L.set_flags(10, True)
+        return
     if only == "skinny":   # decode-sized GEMMs: weight streaming rate; weights rotated over > 512 MB so MALL cannot hold them
         for M_ in (8, 16, 32, 64):
             for name, N, K1, K2, grp in shapes:
@@ -107,7 +122,8 @@ def main():
                 L.gemm_nt(a1, b1, out, **kw)
         torch.cuda.synchronize()
         return
-    for glds in ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ((8, 9, 8, 9) if only == "pp" else ()))):
+    vlist = [int(v) for v in os.environ["GB_VARIANTS"].split(",")] if (only == "gemm" and os.environ.get("GB_VARIANTS")) else None
+    for glds in (vlist if vlist else ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ((8, 9, 8, 9) if only == "pp" else ())))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
