@@ -1244,9 +1244,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   }
   // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
   if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15)) {
-    const bool wide = a.N % 32 == 0 && a.N / 32 >= 512 && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) &&
-                      (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
     const int mf = (a.M + 15) / 16;
+    // 32 weight rows per workgroup halve the activation re-reads from L2 (they bound the kernel from M ~ 32 on) but also the
+    // number of blocks: measured better only while >= 384 blocks remain (N = 4096 at 128 blocks: 29 vs 24 us at M = 64)
+    const bool wide = a.N % 32 == 0 && a.N / 32 >= (mf >= 3 ? 384 : 512) && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) &&
+                      (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
     const dim3 bl(512), gr(wide ? a.N / 32 : a.N / 16);
 #define SK(MF_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<MF_, NR_, U_>), gr, bl, 0, st, a)
     if (wide) { if (mf == 1) SK(1, 2, 8); else if (mf == 2) SK(2, 2, 4); else if (mf == 3) SK(3, 2, 2); else SK(4, 2, 2); }

@@ -98,7 +98,10 @@ def main():
                     def fn():
                         w = ws[it[0] % copies]
                         it[0] += 1
-                        if variant >= 0:
+                        if variant == 10:
+                            with L.decode_schedule():
+                                L.gemm_nt(a1, w, out)
+                        elif variant >= 0:
                             L.gemm_nt(a1, w, out)
                         else:
                             torch.matmul(a1, w.t(), out=out)
