@@ -173,7 +173,7 @@ def main():
             tot_f = sum(p[0] for p in prof)
             tot_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
             ach = tot_f / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_nt (256x256 4-phase-per-K-tile / 128x128 bf16 MFMA GEMM, LDS-DMA staged, LoRA tail fused by K-concatenation)",
+            roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, long-lead LDS-DMA ring / 128x128 for skinny N; LoRA tail fused by K-concatenation)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                     "traffic": _pmc_traffic(), "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}

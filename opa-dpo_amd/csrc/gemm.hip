@@ -675,7 +675,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 // hand-written 256x256x64 kernel, which waits with vmcnt(13) three quarters into the NEXT tile: 1.55-1.6 PF/s) was tried in
 // two forms and measured 0.88-1.13 PF/s here (the extra barriers + lgkmcnt(0) drains cost more than the longer lead wins in
 // compiler-scheduled code); a cooperative L2 prefetch of tile t+3 (each block touches its share of the XCD's unique lines)
-// gave +6 % on 8192^3 and -6 % on 4096^3.  Kept as variant 16 (diagnostics 18-21); the default large-GEMM kernel is p8.
+// gave +6 % on 8192^3 and -6 % on 4096^3.  What was wrong with the long-lead forms was the COMPILER, not the schedule: across
+// their pinned scheduling regions it rotated the 64 accumulators through other AGPRs / VGPRs (152 v_accvgpr_* + 34 s_nop per
+// K-tile).  With the MFMA as inline asm and the accumulator tied in place ("+a") the long-lead schedule (EXP = 6, variant 23:
+// stage released after the 16 set-1 reads, DMA of tile t+2 waited with vmcnt(13) three quarters into tile t+1) is the fastest
+// kernel here: 1.33-1.38 PF/s on 8192^3, 1.25-1.30 on the training shapes -> DEFAULT for large GEMMs.  SQ counters on the
+// cubes (quad-cycles per launch set): single-barrier w4 244 M (24 % parked in s_waitcnt / s_barrier), long lead 228 M (21 %),
+// p8 2 x 245 M, vendor asm kernel 165 M (5 %); removing any ONE of its waits (racy diagnostics 24-26) gives +4.5 % each.
+// Variant 16 = single-barrier schedule, 18-21 / 24-26 = timing diagnostics (wrong results / racy).
 // ------------------------------------------------------------------------------------------
 template <int EXP>   // EXP (diagnostics, wrong results): 1 = no DMA in the K-loop, 2 = no LDS fragment reads in the K-loop
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
@@ -749,11 +756,14 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   };
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
   // MFMAs idx0..idx0+n-1 of a sub-step (idx = i*8 + j: A fragment i is needed from idx 8i on)
+  // The MFMA is written as inline asm with the accumulator tied in place in an AGPR tuple ("+a"): with the builtin, the
+  // register allocator rotates accumulators through other AGPRs / VGPRs across the pinned scheduling regions of the long
+  // schedules (152 v_accvgpr_* + 34 s_nop per K-tile were measured in the loop body).
   auto mfma_run = [&](int kk, int idx0, int n) {
 #pragma unroll
     for (int e = 0; e < n; ++e) {
       const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[kk][j]), "v"(fa[kk][i]));
     }
   };
   auto tile_body = [&](int t, auto ISSUE_B, auto HAS_NEXT, auto HAS_NEXT2) {
@@ -785,6 +795,70 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       W4_PIN();
     }
   };
+  // EXP == 6: long-lead schedule (stage released per operand, DMA of tile t+2 waited three quarters into tile t+1)
+  //   P1: 40 MFMAs(kk=0) | 16 reads set1(t)                  | lgkmcnt(0), barrier  -> the stage of tile t is dead
+  //   P2: 24 MFMAs(kk=0) | 6 DMA (t+2)
+  //   P3: 36 MFMAs(kk=1) | 7 DMA (t+2)                       | vmcnt(13), barrier   -> tile t+1 has landed
+  //   P4: 28 MFMAs(kk=1) | 16 reads set0(t+1), 3 DMA (t+2)
+  auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
+    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
+    constexpr bool dma = has_next2;
+    // ---- P1: the 16 fragment reads of set 1 behind the first 32 MFMAs, 8 more MFMAs cover their latency
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      mfma_run(0, g * 2, 2);
+      W4_PIN();
+      read_frag(t, 1, g);
+      W4_PIN();
+    }
+    mfma_run(0, 32, 8);
+    W4_PIN();
+    if constexpr (has_next2 && EXP != 7) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
+      W4_PIN();
+    }
+    // ---- P2: rest of kk = 0, first 6 DMA pieces of tile t+2
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      mfma_run(0, 40 + g * 4, 4);
+      W4_PIN();
+      if constexpr (dma) issue_piece(t + 2, g);
+      W4_PIN();
+    }
+    // ---- P3: 36 MFMAs of kk = 1, 7 more pieces
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      mfma_run(1, g * 5, 5);
+      W4_PIN();
+      if constexpr (dma) issue_piece(t + 2, 6 + g);
+      W4_PIN();
+    }
+    mfma_run(1, 35, 1);
+    W4_PIN();
+    if constexpr (has_next) {
+      if constexpr (EXP == 9) {
+      } else if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
+    }
+    W4_PIN();
+    // ---- P4: 28 MFMAs, the 16 reads of set 0 of tile t+1, the last 3 pieces
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      mfma_run(1, 36 + g * 3, 2);
+      W4_PIN();
+      if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
+      W4_PIN();
+      mfma_run(1, 36 + g * 3 + 2, 1);
+      W4_PIN();
+      if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) issue_piece(t + 2, 13 + (g - 1) / 3); }
+      W4_PIN();
+    }
+    mfma_run(1, 60, 4);
+    W4_PIN();
+  };
   using T_ = std::true_type; using F_ = std::false_type;
 
 #pragma unroll
@@ -801,7 +875,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   W4_PIN();
-  if (nt == 1) {
+  if constexpr (EXP >= 6) {
+    int t = 0;
+    for (; t + 2 < nt; ++t) tile_body_ll(t, T_{}, T_{});
+    if (t + 1 < nt) { tile_body_ll(t, T_{}, F_{}); ++t; }
+    tile_body_ll(t, F_{}, F_{});
+  } else if (nt == 1) {
     tile_body(0, F_{}, F_{}, F_{});
   } else if (nt == 2) {
     tile_body(0, F_{}, T_{}, F_{});
@@ -813,6 +892,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     tile_body(nt - 1, F_{}, F_{}, F_{});
   }
 #undef W4_PIN
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> VALU readers (the compiler does not see MFMAs in the asm)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + frow;
@@ -1238,6 +1318,10 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
@@ -1266,6 +1350,16 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
+  if (g_gemm_variant == 23 && pp_tiles > 0) {
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
+  if (g_gemm_variant >= 24 && g_gemm_variant <= 26 && pp_tiles > 0) {      // timing diagnostics (racy): a wait / barrier removed
+    if (g_gemm_variant == 24) hipLaunchKernelGGL(gemm_nt_w4_kernel<7>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    else if (g_gemm_variant == 25) hipLaunchKernelGGL(gemm_nt_w4_kernel<8>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<9>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if ((g_gemm_variant >= 18 && g_gemm_variant <= 21) && pp_tiles > 0) {      // timing experiments only (wrong results)
     if (g_gemm_variant == 21) { hipLaunchKernelGGL(gemm_nt_w4_kernel<4>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a); return hipGetLastError(); }
     if (g_gemm_variant == 20) hipLaunchKernelGGL(gemm_nt_w4_kernel<3>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
@@ -1285,8 +1379,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 4>), gr, bl, 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: the 4-phase-per-K-tile kernel
-    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
+  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: 4 waves x 128x128, long-lead DMA schedule
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   if ((g_gemm_variant == 8 || g_gemm_variant == 9) && pp_tiles > 0) {

@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        name = next((n for n in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq", "gemm_nt_pp", "gemm_tn") if n in k), None)
+        name = next((n for n in ("attn_fwd", "attn_bwd_dkdv", "attn_bwd_dq", "gemm_nt_pp", "gemm_nt_p8", "gemm_nt_w4", "gemm_nt_kernel_x", "Cijk", "gemm_tn") if n in k), None)
         if name:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
