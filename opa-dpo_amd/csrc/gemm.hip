@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     tile_body(nt - 1, F_{}, F_{}, F_{});
   }
 #undef W4_PIN
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> VALU readers (the compiler does not see MFMAs in the asm)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + frow;
