@@ -803,42 +803,42 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
     constexpr bool dma = has_next2;
-    // ---- P1: the 16 fragment reads of set 1 behind the first 32 MFMAs, 8 more MFMAs cover their latency
+    // schedule knobs (EXP 6 = default; 7, 8, 9 = variants measured against it)
+    //   R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
+    //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
+    constexpr int R1 = EXP == 8 ? 16 : (EXP == 6 ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      mfma_run(0, g * 2, 2);
+      mfma_run(0, (g * R1) / 16, ((g + 1) * R1) / 16 - (g * R1) / 16);
       W4_PIN();
       read_frag(t, 1, g);
       W4_PIN();
     }
-    mfma_run(0, 32, 8);
+    mfma_run(0, R1, B1 - R1);
     W4_PIN();
-    if constexpr (has_next2 && EXP != 7) {
+    if constexpr (has_next2) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
     }
-    // ---- P2: rest of kk = 0, first 6 DMA pieces of tile t+2
+    // ---- P2/P3: MFMAs B1..99 (kk = 0 up to 63, then kk = 1), 13 DMA pieces of tile t+2, one per DSTEP MFMAs
+    {
+      constexpr int NM = 100 - B1;             // MFMAs in this span
 #pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      mfma_run(0, 40 + g * 4, 4);
-      W4_PIN();
-      if constexpr (dma) issue_piece(t + 2, g);
-      W4_PIN();
+      for (int m = 0; m < NM; ++m) {
+        const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
+        mfma_run(gi >> 6, gi & 63, 1);
+        if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
+          W4_PIN();
+          if constexpr (dma) issue_piece(t + 2, (m + 1) / DSTEP - 1);
+          W4_PIN();
+        }
+      }
     }
-    // ---- P3: 36 MFMAs of kk = 1, 7 more pieces
-#pragma unroll
-    for (int g = 0; g < 7; ++g) {
-      mfma_run(1, g * 5, 5);
-      W4_PIN();
-      if constexpr (dma) issue_piece(t + 2, 6 + g);
-      W4_PIN();
-    }
-    mfma_run(1, 35, 1);
     W4_PIN();
     if constexpr (has_next) {
-      if constexpr (EXP == 9) {
-      } else if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
+      if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
     }
