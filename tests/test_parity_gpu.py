@@ -289,6 +289,23 @@ def test_generation_kv_cache_against_oracle(setup):
     REPORT["generation_checked_steps"] = N
 
 
+def test_eval_generation_from_checkpoint(setup, tmp_path):
+    """save_adapter (PEFT layout) -> generate_from_checkpoint == generation with the in-memory adapter (greedy and sampled)."""
+    s = setup
+    from opadpo_amd.eval_generate import generate_from_checkpoint
+    from opadpo_amd.trainer import save_adapter
+    ckpt = tmp_path / "checkpoint-3"
+    save_adapter(s["pol"], str(ckpt / "adapter_model" / "lora_policy"), s["d"])
+    images, queries, qmask, _ = make_inputs(s["d"], 2, 12, 9, seed=41)
+    for kw in (dict(temperature=0.0), dict(temperature=0.7, top_k=20, top_p=0.9, seed=5)):
+        a = generate_from_checkpoint(s["eng"], str(ckpt), queries, qmask, images.to(s["dev"]), max_new_tokens=10, **kw)
+        b = generate_from_checkpoint(s["eng"], None, queries, qmask, images.to(s["dev"]), max_new_tokens=10, adapter=s["pol"], **kw)
+        assert torch.equal(a, b) and a.shape == (2, 10)
+        for row in a.tolist():                     # pad after the first EOS
+            if 2 in row:
+                assert all(t == 0 for t in row[row.index(2) + 1:])
+
+
 def test_wide_model_parity():
     """LLaVA-1.5-7B WIDTH (H 4096, FFN 11008, V 32000, r 256; 2 layers, small vision tower) so that the large-shape
     kernel paths (256x256 ping-pong GEMM, K = 11008, 125 vocabulary tiles) run inside the model; log-probs and LoRA

@@ -81,6 +81,23 @@ def main():
                 print(res[-1], flush=True)
         L.set_flags(10, True)
         return
+    if only == "tn":       # LoRA wgrad shapes of one decoder layer at the bench M
+        shapes_tn = [("dB_d", 4096, 256, 0, 0), ("dA_d", 256, 11008, 0, 0), ("dB_gu", 22016, 256, 11008, 256), ("dA_gu", 512, 4096, 0, 0),
+                     ("dB_o", 4096, 256, 0, 0), ("dA_o", 256, 4096, 0, 0), ("dB_qkv", 12288, 256, 4096, 256), ("dA_qkv", 768, 4096, 0, 0)]
+        tot = 0.0
+        for name, N1, N2, gn1, gs in shapes_tn:
+            G = N1 // gn1 if gn1 else 1
+            pm = torch.randn(M, N1, device=dev).to(BF)
+            qm = torch.randn(M, N2 * G, device=dev).to(BF)
+            c = torch.zeros(N1, N2, device=dev)
+            kw = dict(q_group_n1=gn1, q_group_stride=gs) if gn1 else {}
+            t = timeit(lambda: L.gemm_tn(pm, qm, c, **kw))
+            tot += t
+            res.append(dict(kernel="gemm_tn", name=name, M=M, N1=N1, N2=N2, ms=t * 1e3, tflops=2.0 * M * N1 * N2 / t / 1e12,
+                            GBps=(M * (N1 + N2 * G) * 2) / t / 1e9))
+            print(res[-1], flush=True)
+        print("total ms per layer", tot * 1e3)
+        return
     if only == "skinny":   # decode-sized GEMMs: weight streaming rate; weights rotated over > 512 MB so MALL cannot hold them
         for M_ in (8, 16, 32, 64):
             for name, N, K1, K2, grp in shapes:
