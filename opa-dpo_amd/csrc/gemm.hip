@@ -1287,14 +1287,132 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
       }
 }
 
+
+// ---- gemm_tn, wide tiles ------------------------------------------------------------------------------------------
+// The LoRA wgrads are tall-skinny reductions over M: dB = dY^T t has N2 = r = 256, dA = dT^T x has N1 = r, 2r or 3r.  With the
+// 128x128 tile the BIG operand (dY, resp. x) is fetched once per 128-wide slice of the small one — twice for dB, up to six
+// times for dA(q|k|v) — and the kernel runs at HBM speed on re-reads (dB(gate|up): 2 x 1.43 GB in 0.71 ms).  Here the tile
+// spans 256 of the small dimension (BN1 x BN2 = 128 x 256 for dB, 256 x 128 for dA; 4 waves of 64x128 / 128x64), rows past the
+// block's M-slice come back as zeros from a per-block buffer descriptor (no predicates, scalar row offsets), and each
+// transposed LDS fragment feeds 4 or 8 MFMAs instead of 4.
+// MEASURED (M = 32362, one decoder layer's 8 wgrads): 2.60 ms vs 2.37 ms with the 128x128 kernel — the re-reads hit the L2 /
+// Infinity Cache (the slices of one row block run concurrently), and at ~250 VGPRs the wide kernel hides less latency:
+// dA(down) 0.32 vs 0.38 ms, but dB(*) 0.18-0.78 vs 0.13-0.71 ms.  Kept behind set_flags(use_tr bit 2), off by default.
+template <int ROWB>
+__device__ __forceinline__ const char* tn2_at(const char* tile, int row, int col) {
+  const int b = col * 2;
+  return tile + row * ROWB + ((((b >> 4) ^ ((row & 7) << 1))) << 4) + (b & 15);
+}
+template <bool TR, int ROWB>
+__device__ __forceinline__ bf16x8_t tn2_frag(const char* tile, int k0, int c0, int lane) {
+  union { bf16x8_t v; s16x4_t h[2]; uint16_t s[8]; } u;
+  const int g = lane >> 4, c = lane & 15;
+  if constexpr (TR) {
+    const int col = c0 + (c & 3) * 4;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn2_at<ROWB>(tile, k0 + g * 8 + (c >> 2), col)));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn2_at<ROWB>(tile, k0 + g * 8 + 4 + (c >> 2), col)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.s[j] = *(const uint16_t*)tn2_at<ROWB>(tile, k0 + g * 8 + j, c0 + c);
+  }
+  return u.v;
+}
+
+template <bool TR, int BN1, int BN2>
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs p) {
+  constexpr int RB1 = BN1 * 2, RB2 = BN2 * 2;                       // LDS row bytes of the P / Q tile
+  constexpr int NP = (TK * BN1 * 2) / (256 * 16), NQ = (TK * BN2 * 2) / (256 * 16);   // 16-B pieces per thread and stage
+  constexpr int F1 = BN1 / 32, F2 = BN2 / 32;                       // 16-wide fragments per wave (2x2 waves)
+  __shared__ __attribute__((aligned(16))) char smem[TK * (RB1 + RB2)];
+  char* Ps = smem;
+  char* Qs = smem + TK * RB1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n2 = p.N2 / BN2;
+  const int t1 = blockIdx.x / tiles_n2, t2 = blockIdx.x % tiles_n2;
+  const int n1_0 = t1 * BN1, n2_0 = t2 * BN2;
+  const int chunk = (((p.M + gridDim.y - 1) / gridDim.y) + TK - 1) / TK * TK;
+  const int m_begin = blockIdx.y * chunk;
+  const int m_end = min(p.M, m_begin + chunk);
+  if (m_begin >= m_end) return;
+
+  const bf16_t* Q = p.Q + n2_0;
+  if (p.q_group_n1 > 0) Q += (size_t)(n1_0 / p.q_group_n1) * p.q_group_stride;
+  const bf16_t* P = p.P + n1_0;
+  // extents end at row m_end: later rows (they belong to the next split) read as zero
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, (int)((unsigned)m_end * (unsigned)p.ldp * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, (int)((unsigned)m_end * (unsigned)p.ldq * 2u), 0x00020000);
+  constexpr int CP = BN1 / 8, CQ = BN2 / 8;                         // 16-B chunks per row
+  const unsigned pv_off = (unsigned)((tid / CP) * p.ldp + (tid % CP) * 8) * 2u, pv_step = (unsigned)((256 / CP) * p.ldp) * 2u;
+  const unsigned qv_off = (unsigned)((tid / CQ) * p.ldq + (tid % CQ) * 8) * 2u, qv_step = (unsigned)((256 / CQ) * p.ldq) * 2u;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4_t acc[F1][F2];
+#pragma unroll
+  for (int i = 0; i < F1; ++i)
+#pragma unroll
+    for (int j = 0; j < F2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t pv[NP], qv[NQ];
+  auto fetch = [&](int mb) {
+    const unsigned pb = (unsigned)mb * (unsigned)p.ldp * 2u, qb = (unsigned)mb * (unsigned)p.ldq * 2u;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rP, pv_off, pb + i * pv_step, 0);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rQ, qv_off, qb + i * qv_step, 0);
+  };
+  fetch(m_begin);
+  for (int mb = m_begin; mb < m_end; mb += TK) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = tid / CP + i * (256 / CP), c16 = tid % CP;
+      *(u32x4_t*)(Ps + row * RB1 + ((c16 ^ ((row & 7) << 1)) << 4)) = pv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int row = tid / CQ + i * (256 / CQ), c16 = tid % CQ;
+      *(u32x4_t*)(Qs + row * RB2 + ((c16 ^ ((row & 7) << 1)) << 4)) = qv[i];
+    }
+    __syncthreads();
+    if (mb + TK < m_end) fetch(mb + TK);
+#pragma unroll
+    for (int kk = 0; kk < TK / 32; ++kk) {
+      bf16x8_t pf[F1], qf[F2];
+#pragma unroll
+      for (int i = 0; i < F1; ++i) pf[i] = tn2_frag<TR, RB1>(Ps, kk * 32, wm * (BN1 / 2) + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < F2; ++j) qf[j] = tn2_frag<TR, RB2>(Qs, kk * 32, wn * (BN2 / 2) + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < F1; ++i)
+#pragma unroll
+        for (int j = 0; j < F2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < F1; ++i)
+#pragma unroll
+    for (int j = 0; j < F2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n1 = n1_0 + wm * (BN1 / 2) + i * 16 + g * 4 + q;
+        const int n2 = n2_0 + wn * (BN2 / 2) + j * 16 + c;
+        atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[i][j][q] * p.alpha);
+      }
+}
+
 }  // namespace
 
 static int g_gemm_variant = 10;   // 0: register staging, 1: LDS-DMA 16x16x32, 2: LDS-DMA 32x32x16, 3: 3-stage ring 128x256, 4: LDS-DMA 16x16x32 + setprio, <=128 VGPR; 5-7: BK=32 experiments; 8/9: 256x256 ping-pong (16x16x32 / 32x32x16); 10 (default): auto 8|4
 static bool g_use_tr = true;
+static int g_tn_wide = 0;      // use_tr bit 2 set: wide (256 x 128 / 128 x 256) gemm_tn tiles — measured slower overall, see gemm_tn2_kernel
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
   opadpo_set_attn_dma((use_tr & 2) != 0);
+  g_tn_wide = (use_tr & 4) != 0;
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
@@ -1416,7 +1534,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (a.N1 % 128 || a.N2 % 128) return hipErrorInvalidValue;
-  const int tiles = (a.N1 / 128) * (a.N2 / 128);
+  // wide tiles: span 256 of the SMALL dimension so that the big operand is read once (twice / three times for 2r / 3r)
+  const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
+  int bn1 = 128, bn2 = 128;
+  if (g_tn_wide && off32 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
+    if (a.N2 % 256 == 0 && a.N2 <= a.N1) bn2 = 256;
+    else if (a.N1 % 256 == 0 && a.N1 < a.N2) bn1 = 256;
+  }
+  const int tiles = (a.N1 / bn1) * (a.N2 / bn2);
   int splits = a.splits;
   if (splits <= 0) {
     splits = (1024 + tiles - 1) / tiles;
@@ -1424,9 +1549,17 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
-  if (g_use_tr)
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles, splits), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles, splits), dim3(256), 0, st, a);
+  const dim3 grid(tiles, splits);
+  if (bn2 == 256) {
+    if (g_use_tr) hipLaunchKernelGGL((gemm_tn2_kernel<true, 128, 256>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn2_kernel<false, 128, 256>), grid, dim3(256), 0, st, a);
+  } else if (bn1 == 256) {
+    if (g_use_tr) hipLaunchKernelGGL((gemm_tn2_kernel<true, 256, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn2_kernel<false, 256, 128>), grid, dim3(256), 0, st, a);
+  } else if (g_use_tr) {
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
+  }
   return hipGetLastError();
 }

@@ -96,7 +96,7 @@ def set_flags(use_glds=10, use_tr: bool = True) -> None:
     16 w4 single-barrier schedule, 17 8-wave 4-phase kernel (p8), 23 = the default large-GEMM kernel forced,
     24-26 schedule knobs of it; 18-21 timing diagnostics that produce WRONG results.  True -> default.
     use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V ring
-    (default: register-staged single buffer, 3 blocks per CU)."""
+    (default: register-staged single buffer, 3 blocks per CU), bit 2 = wide gemm_tn tiles."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 

@@ -179,10 +179,12 @@ def test_gemm_nt_grouped_a1(L, variant):
     assert relerr(out, want) < 6e-3
 
 
-@pytest.mark.parametrize("tr", [1, 0])
-@pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0)])
+@pytest.mark.parametrize("tr", [1, 0, 5])      # 5 = transposed reads + wide (256-spanning) tiles
+@pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0),
+                                            (1100, 512, 256, 0), (1100, 256, 1024, 0), (1300, 768, 256, 3), (2100, 1024, 256, 2),
+                                            (999, 512, 384, 0), (70, 256, 256, 0)])
 def test_gemm_tn(L, tr, M, N1, N2, groups):
-    L.set_flags(True, bool(tr))
+    L.set_flags(True, tr)
     p = rnd(M, N1, seed=1)
     G = max(groups, 1)
     q = rnd(M, G * N2, seed=2)
