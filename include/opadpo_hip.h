@@ -84,6 +84,13 @@ int opadpo_rmsnorm_fwd(const void* x, int x_f32, const uint16_t* w, uint16_t* y,
 int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint16_t* w, const float* rstd,
                        const void* dres, int dres_f32, float* dx_f32, uint16_t* dx_bf16, int rows, int H, void* stream);
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
+/* CLIP / projector training path (OPA LoRA-SFT stage, opadpo/opa_train.py: the vision tower and mm_projector carry trainable
+ * LoRA there): LayerNorm backward w.r.t. x (affine parameters frozen; mean / rstd recomputed; dres nullable = residual-path
+ * gradient, added), and the activation applied / differentiated on a stored PRE-activation tensor (act = OPADPO_ACT_*). */
+int opadpo_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const uint16_t* dres, uint16_t* dx, int rows, int H,
+                         float eps, void* stream);
+int opadpo_act_fwd(const uint16_t* z, uint16_t* out, size_t n, int act, void* stream);
+int opadpo_act_bwd(const uint16_t* dout, const uint16_t* z, uint16_t* dz, size_t n, int act, void* stream);
 /* in-place half-split rotary on n_heads heads starting at column 0 of qk (row r has position
  * pos_base[0] + r % L; pos_base is a device int32 or NULL = 0 — device-resident so that a captured decode step can be
  * replayed); cos/sin: fp32 [max_pos, hd/2]; inverse=1 applies the transposed rotation (gradient).  seg_len > 0: packed

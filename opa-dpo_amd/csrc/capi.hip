@@ -102,6 +102,16 @@ int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint1
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream) {
   return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
 }
+int opadpo_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const uint16_t* dres, uint16_t* dx, int rows, int H,
+                         float eps, void* stream) {
+  return done(launch_layernorm_bwd(dy, x, w, dres, dx, rows, H, eps, S(stream)), "opadpo_layernorm_bwd");
+}
+int opadpo_act_fwd(const uint16_t* z, uint16_t* out, size_t n, int act, void* stream) {
+  return done(launch_act_fwd(z, out, n, act, S(stream)), "opadpo_act_fwd");
+}
+int opadpo_act_bwd(const uint16_t* dout, const uint16_t* z, uint16_t* dz, size_t n, int act, void* stream) {
+  return done(launch_act_bwd(dout, z, dz, n, act, S(stream)), "opadpo_act_bwd");
+}
 int opadpo_rope(uint16_t* qk, int ld, const float* cos_tab, const float* sin_tab, int rows, int L, int n_heads, int hd,
                 int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, void* stream) {
   if (ld % 8) return bad("opadpo_rope", "misaligned leading dimension");

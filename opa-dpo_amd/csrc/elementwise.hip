@@ -152,6 +152,91 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const flo
   }
 }
 
+// LayerNorm backward w.r.t. x (CLIP blocks; the affine parameters are frozen under LoRA): mean / rstd are recomputed
+// from x (one row = one block, three passes over <= 8 KiB that stay in L1/registers), dx = rstd * (g - mean(g) - xhat * mean(g xhat)),
+// g = dy * w; `dres` (nullable) is the gradient arriving over the residual connection and is added.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const bf16_t* dres,
+                                                             bf16_t* dx, int H, float eps) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  const bf16_t* xr = x + row * H;
+  const bf16_t* dyr = dy + row * H;
+  float s = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + i), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j];
+  }
+  const float mean = block_sum_256(s, red) / H;
+  float v = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + i), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; v += d * d; }
+  }
+  const float r = rsqrtf(block_sum_256(v, red) / H + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8], g[8], ww[8];
+    unpack8(*(const uint4*)(xr + i), f);
+    unpack8(*(const uint4*)(dyr + i), g);
+    unpack8(*(const uint4*)(w + i), ww);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float gj = g[j] * ww[j]; sg += gj; sgx += gj * (f[j] - mean) * r; }
+  }
+  const float mg = block_sum_256(sg, red) / H;
+  const float mgx = block_sum_256(sgx, red) / H;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8], g[8], ww[8], o[8];
+    unpack8(*(const uint4*)(xr + i), f);
+    unpack8(*(const uint4*)(dyr + i), g);
+    unpack8(*(const uint4*)(w + i), ww);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = r * (g[j] * ww[j] - mg - (f[j] - mean) * r * mgx);
+    if (dres) {
+      float d[8];
+      unpack8(*(const uint4*)(dres + row * H + i), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += d[j];
+    }
+    *(uint4*)(dx + row * H + i) = pack8(o);
+  }
+}
+
+// element-wise activation on a pre-activation tensor kept for backward (training forward of the CLIP MLP / projector)
+__device__ __forceinline__ float ew_act(float z, int act) {
+  if (act == OPADPO_ACT_QUICK_GELU) return z / (1.0f + __expf(-1.702f * z));
+  return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f));
+}
+__device__ __forceinline__ float ew_act_grad(float z, int act) {
+  if (act == OPADPO_ACT_QUICK_GELU) {
+    const float sg = 1.0f / (1.0f + __expf(-1.702f * z));
+    return sg + 1.702f * z * sg * (1.0f - sg);
+  }
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* z, bf16_t* out, size_t n8, int act) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    unpack8(*(const uint4*)(z + i * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = ew_act(f[j], act);
+    *(uint4*)(out + i * 8) = pack8(f);
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_t n8, int act) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float f[8], g[8];
+    unpack8(*(const uint4*)(z + i * 8), f);
+    unpack8(*(const uint4*)(dout + i * 8), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= ew_act_grad(f[j], act);
+    *(uint4*)(dz + i * 8) = pack8(g);
+  }
+}
+
 // ---- SwiGLU ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* gu, bf16_t* act, size_t rows, int F) {
   const int per_row = F / 8;
@@ -371,6 +456,25 @@ hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* 
   if (rows <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const bf16_t* dres, bf16_t* dx, int rows, int H,
+                                float eps, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(rows), dim3(256), 0, st, dy, x, w, dres, dx, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_act_fwd(const bf16_t* z, bf16_t* out, size_t n, int act, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (n % 8 || (act != OPADPO_ACT_QUICK_GELU && act != OPADPO_ACT_GELU)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, st, z, out, n / 8, act);
+  return hipGetLastError();
+}
+hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_t n, int act, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (n % 8 || (act != OPADPO_ACT_QUICK_GELU && act != OPADPO_ACT_GELU)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, st, dout, z, dz, n / 8, act);
   return hipGetLastError();
 }
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,

@@ -63,6 +63,10 @@ hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t*
 hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
 hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
+hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const bf16_t* dres, bf16_t* dx, int rows, int H,
+                                float eps, hipStream_t st);
+hipError_t launch_act_fwd(const bf16_t* z, bf16_t* out, size_t n, int act, hipStream_t st);
+hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_t n, int act, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
                        int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st);
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);

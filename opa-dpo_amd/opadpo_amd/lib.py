@@ -31,6 +31,9 @@ SIGNATURES = {
     "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_rmsnorm_bwd": [_p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_layernorm_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_act_fwd": [_p, _p, _sz, _i, _p],
+    "opadpo_act_bwd": [_p, _p, _p, _sz, _i, _p],
     "opadpo_rope": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "opadpo_silu_mul_fwd": [_p, _p, _i, _i, _p],
     "opadpo_silu_mul_bwd": [_p, _p, _p, _i, _i, _p],

@@ -451,8 +451,10 @@ class LlavaEngine:
                L.ptr(sv.lse_head), R, d.vocab, st)
         return logp.view(K * S, T), ent.view(K * S, T), sv
 
-    def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor) -> None:
-        """Accumulate d(loss)/d(LoRA A,B) into adapter.grad given dlogp [S,T] fp32."""
+    def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor, d_feats: Optional[torch.Tensor] = None) -> None:
+        """Accumulate d(loss)/d(LoRA A,B) into adapter.grad given dlogp [S,T] fp32.  d_feats (optional, fp32 [n_images, P, H],
+        accumulated): gradient w.r.t. the projected image features — only the OPA LoRA-SFT stage needs it (trainable vision /
+        projector LoRA, vision_train.py); the DPO stage stops at the frozen layer-0 input."""
         assert sv.train and adapter.trainable and self.base.need_backward
         d, b = self.d, self.base
         st = L.stream()
@@ -523,7 +525,16 @@ class LlavaEngine:
             L.gemm_nt(dqkv, adapter.wt(i, "b_qkv").view(3 * r, H), dt_3r, alpha=s, k1=H, a1_group_n=r, a1_group_stride=H)
             L.gemm_tn(dqkv, sv.t_qkv[i], adapter.g(i, "b_qkv"), q_group_n1=H, q_group_stride=r)
             L.gemm_tn(dt_3r, sv.n1[i], adapter.g(i, "a_qkv"))
-            if i > 0:   # layer-0 input is the frozen embedding / image features: no further dgrad
+            if i > 0 or d_feats is not None:   # layer-0 input is the frozen embedding / image features: no further dgrad (DPO)
                 L.gemm_nt(dqkv, w["wqkv_t"], d_n, a2=dt_3r, b2=adapter.wt(i, "a_qkv"))
                 L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.x[i]), 1, L.ptr(w["ln1"]), L.ptr(sv.rstd1[i]), L.ptr(d_h), 1,
                        L.ptr(dX), L.ptr(dXb), M, H, st)
+        if d_feats is not None:
+            # splice backward: rows [img_pos, img_pos + P) of every sequence hold its image's features (dims.IMAGE_TOKEN_INDEX
+            # sits at img_pos of the text ids); sequences sharing an image (stacked layout) accumulate.  Index plumbing in torch.
+            P = d.n_patches
+            ids = sv.batch.ids
+            img_pos = (ids == IMAGE_TOKEN_INDEX).int().argmax(dim=1)                                   # [S]
+            rows = (torch.arange(S, device=self.dev)[:, None] * Lp + img_pos[:, None] + torch.arange(P, device=self.dev)[None, :]).reshape(-1)
+            g_rows = dX.view(M, H).index_select(0, rows).view(S, P, H)
+            d_feats.index_add_(0, sv.batch.feat_row.long(), g_rows)

@@ -42,7 +42,7 @@ def built_lib():
 
 def test_header_declares_the_path():
     protos = parse_header()
-    assert len(protos) >= 29
+    assert len(protos) >= 33
     for need in ("opadpo_gemm_nt", "opadpo_gemm_tn", "opadpo_attn_fwd", "opadpo_attn_bwd", "opadpo_head_fwd",
                  "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_rope_kv_append", "opadpo_embed_splice"):
         assert need in protos

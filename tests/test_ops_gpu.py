@@ -408,6 +408,32 @@ def test_rmsnorm(L, xf32):
     assert torch.equal(dx16, dx32.to(BF))
 
 
+def test_layernorm_bwd_and_act(L):
+    """CLIP training-path pieces (OPA LoRA-SFT stage): LayerNorm backward w.r.t. x (+ residual-path gradient), activation fwd/bwd
+    on a stored pre-activation."""
+    rows, H = 41, 1024
+    x, w, b = rnd(rows, H, seed=1), (1 + 0.1 * torch.randn(H)).to(BF).to(dev()), rnd(H, scale=0.1, seed=3)
+    dy, dres = rnd(rows, H, seed=4), rnd(rows, H, seed=5)
+    dx = torch.empty_like(x)
+    L.call("opadpo_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), dres.data_ptr(), dx.data_ptr(), rows, H, 1e-5, L.stream())
+    xf = x.float().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xf, (H,), w.float(), b.float(), 1e-5)
+    y.backward(dy.float())
+    assert relerr(dx, xf.grad + dres.float()) < 6e-3
+    dx0 = torch.empty_like(x)
+    L.call("opadpo_layernorm_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), None, dx0.data_ptr(), rows, H, 1e-5, L.stream())
+    assert relerr(dx0, xf.grad) < 6e-3
+    for act, fn in ((1, lambda z: z * torch.sigmoid(1.702 * z)), (2, torch.nn.functional.gelu)):
+        z = rnd(37, 512, scale=1.5, seed=6 + act)
+        out, dz, do = torch.empty_like(z), torch.empty_like(z), rnd(37, 512, seed=9)
+        L.call("opadpo_act_fwd", z.data_ptr(), out.data_ptr(), z.numel(), act, L.stream())
+        L.call("opadpo_act_bwd", do.data_ptr(), z.data_ptr(), dz.data_ptr(), z.numel(), act, L.stream())
+        zf = z.float().requires_grad_(True)
+        ref = fn(zf)
+        ref.backward(do.float())
+        assert relerr(out, ref) < 4e-3 and relerr(dz, zf.grad) < 6e-3
+
+
 def test_layernorm(L):
     rows, H = 19, 256
     x, w, b = rnd(rows, H, seed=1), rnd(H, seed=2), rnd(H, seed=3)

@@ -306,6 +306,105 @@ def test_eval_generation_from_checkpoint(setup, tmp_path):
                 assert all(t == 0 for t in row[row.index(2) + 1:])
 
 
+def test_vision_projector_lora_backward(setup):
+    """OPA LoRA-SFT groundwork: CLIP + mm_projector with TRAINABLE LoRA (unmerged), forward features and the gradients of
+    every vision / projector LoRA block against fp32 autograd through the oracle."""
+    s = setup
+    LR = s["LR"]
+    from opadpo_amd.model import BaseWeights
+    from opadpo_amd.vision_train import VisionLoraAdapter, VisionTrainPath, _vis_peft_map, projector_lora_blocks, vision_lora_blocks
+    d, od = s["d"], s["od"]
+    base = BaseWeights(d, s["W"], s["dev"], need_backward=False)             # vision LoRA NOT merged
+    vad = VisionLoraAdapter(d, s["lora_pol"], s["dev"])
+    vt = VisionTrainPath(base, vad)
+    g = torch.Generator().manual_seed(17)
+    images = torch.randn(2, 3, d.image_size, d.image_size, generator=g).to(BF).float()
+    feats, sv = vt.forward(images.to(s["dev"]))
+    wts = torch.randn(2 * d.n_patches, d.hidden, generator=g)
+    vt.backward(sv, wts.to(s["dev"]))
+    torch.cuda.synchronize()
+    lora = {k: v.clone().requires_grad_("vision_tower" in k or "mm_projector" in k) for k, v in s["lora_pol"].items()}
+    want = LR.image_features(images, s["W"], lora, od).reshape(2 * d.n_patches, d.hidden)
+    assert rel(feats, want.detach()) < 2e-2
+    (want * wts.to(BF).float()).sum().backward()
+    from opadpo_amd.dims import LLM_PREFIX, PEFT_PREFIX, VIS_PREFIX
+    pm = _vis_peft_map(d)
+    worst = 0.0
+    for j in range(d.v_used_layers):
+        for name, rows, cols in vision_lora_blocks(d):
+            ref = torch.zeros(rows, cols)
+            for mod, ab, r0, nr in pm[name]:
+                ref[r0:r0 + nr] = lora[f"{PEFT_PREFIX}{VIS_PREFIX}encoder.layers.{j}.{mod}.{ab}.weight"].grad
+            got = vad.g(j, name).cpu()
+            assert bool(torch.isfinite(got).all())
+            e = rel(got, ref)
+            REPORT[f"vis_grad_L{j}_{name}"] = e
+            worst = max(worst, e)
+    for name, rows, cols in projector_lora_blocks(d):
+        mod = "mm_projector.0" if name.endswith("p0") else "mm_projector.2"
+        ab = "lora_A" if name.startswith("a_") else "lora_B"
+        e = rel(vad.g(d.v_used_layers, name).cpu(), lora[f"{PEFT_PREFIX}{LLM_PREFIX}{mod}.{ab}.weight"].grad)
+        REPORT[f"proj_grad_{name}"] = e
+        worst = max(worst, e)
+    assert worst < 4e-2, f"worst vision / projector LoRA gradient block rel err {worst}: {[(k, round(v, 4)) for k, v in REPORT.items() if 'vis_grad' in k or 'proj_grad' in k]}"
+
+
+def test_sft_step_gradients_end_to_end(setup):
+    """OPA LoRA-SFT shape of the problem: cross-entropy on the response tokens, gradient through the LLM LoRA, the splice
+    (d_feats), the projector and the CLIP tower LoRA — every block against fp32 autograd through the whole oracle model."""
+    s = setup
+    LR = s["LR"]
+    from opadpo_amd.dims import LLM_PREFIX, PEFT_PREFIX, VIS_PREFIX
+    from opadpo_amd.model import BaseWeights, _peft_map, lora_blocks
+    from opadpo_amd.vision_train import VisionLoraAdapter, VisionTrainPath, _vis_peft_map, projector_lora_blocks, vision_lora_blocks
+    d, od, dev = s["d"], s["od"], s["dev"]
+    B, Q, T = 2, 12, 9
+    images, queries, qmask, resp = make_inputs(d, B, Q, T, seed=23)
+    one = {"standard_response": resp["standard_response"]}
+    vt = VisionTrainPath(BaseWeights(d, s["W"], dev, need_backward=False), VisionLoraAdapter(d, s["lora_pol"], dev))
+    pol = _policy(s, s["pol"], T)
+    s["pol"].grad.zero_()
+    feats, vsv = vt.forward(images.to(dev))
+    keys, batch = pol.build_batch(queries, qmask, one)
+    logp, _, sv = s["eng"].seq_logprobs_fwd(s["pol"], batch, feats.view(B, d.n_patches, d.hidden), 1.0, train=True)
+    mask = (one["standard_response"] != 0).to(dev)
+    n = float(mask.sum())
+    loss = -float((logp * mask).sum()) / n
+    d_feats = torch.zeros(B, d.n_patches, d.hidden, device=dev)
+    s["eng"].seq_logprobs_bwd(s["pol"], sv, -(mask.float() / n), d_feats=d_feats)
+    vt.backward(vsv, d_feats.view(B * d.n_patches, d.hidden))
+    torch.cuda.synchronize()
+    lora = {k: v.clone().requires_grad_(True) for k, v in s["lora_pol"].items()}
+    want = LR.policy_forward(images, queries, qmask, one, s["W"], lora, od, 1.0)
+    om = one["standard_response"] != 0
+    oloss = -(want["standard_response_logprobs"] * om).sum() / om.sum()
+    oloss.backward()
+    assert abs(loss - float(oloss)) < 5e-3 * abs(float(oloss)) + 1e-3, (loss, float(oloss))
+    worst = {}
+    pm = _vis_peft_map(d)
+    for j in range(d.v_used_layers):
+        for name, rows, cols in vision_lora_blocks(d):
+            ref = torch.zeros(rows, cols)
+            for mod, ab, r0, nr in pm[name]:
+                ref[r0:r0 + nr] = lora[f"{PEFT_PREFIX}{VIS_PREFIX}encoder.layers.{j}.{mod}.{ab}.weight"].grad
+            worst[f"vis_L{j}_{name}"] = rel(vt.ad.g(j, name).cpu(), ref)
+    for name, rows, cols in projector_lora_blocks(d):
+        mod = "mm_projector.0" if name.endswith("p0") else "mm_projector.2"
+        ab = "lora_A" if name.startswith("a_") else "lora_B"
+        worst[f"proj_{name}"] = rel(vt.ad.g(d.v_used_layers, name).cpu(), lora[f"{PEFT_PREFIX}{LLM_PREFIX}{mod}.{ab}.weight"].grad)
+    pml = _peft_map(d)
+    for i in range(d.n_layers):
+        for name, rows, cols in lora_blocks(d):
+            ref = torch.zeros(rows, cols)
+            for mod, ab, r0, nr in pml[name]:
+                ref[r0:r0 + nr] = lora[f"{PEFT_PREFIX}model.layers.{i}.{mod}.{ab}.weight"].grad
+            worst[f"llm_L{i}_{name}"] = rel(s["pol"].g(i, name).cpu(), ref)
+    s["pol"].grad.zero_()
+    REPORT.update({f"sft_{k}": v for k, v in worst.items()})
+    bad = {k: round(v, 4) for k, v in worst.items() if not v < 6e-2}
+    assert not bad, bad
+
+
 def test_wide_model_parity():
     """LLaVA-1.5-7B WIDTH (H 4096, FFN 11008, V 32000, r 256; 2 layers, small vision tower) so that the large-shape
     kernel paths (256x256 ping-pong GEMM, K = 11008, 125 vocabulary tiles) run inside the model; log-probs and LoRA
