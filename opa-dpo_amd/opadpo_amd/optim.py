@@ -103,21 +103,37 @@ class FlatAdamW:
 
     def step(self, grad_accum_div: float = 1.0) -> None:
         """One optimizer step.  Effective gradient = sum over ranks / (world * grad_accum_div)."""
+        self.prepare(grad_accum_div)
+        self.apply()
+
+    def prepare(self, grad_accum_div: float = 1.0) -> None:
+        """Phase 1: gradient exchange + sum of squares of the (summed) gradient.  Several FlatAdamW instances that must be
+        clipped by ONE global norm (SFT stage: LLM LoRA + vision LoRA buffers) call prepare() on each, add their `sumsq`
+        tensors, write the total back into each (`share_sumsq`) and then call apply()."""
         self.step_count += 1
-        g = self._exchange()
-        grad_div = 1.0 / (self.world * grad_accum_div)
+        self._g = self._exchange()
+        self._grad_div = 1.0 / (self.world * grad_accum_div)
         self.sumsq.zero_()
         if self.max_grad_norm is not None:
-            self.sumsq_fn(g, self.sumsq)
+            self.sumsq_fn(self._g, self.sumsq)
             if self._collective and self.mode == "zero1":
                 dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
+
+    @staticmethod
+    def share_sumsq(*opts: "FlatAdamW") -> None:
+        total = sum(o.sumsq for o in opts)
+        for o in opts:
+            o.sumsq.copy_(total)
+
+    def apply(self) -> None:
+        """Phase 2: clip by the norm in `sumsq`, AdamW on this rank's slice, (ZeRO-1) all-gather of the working copy."""
+        g, grad_div = self._g, self._grad_div
         p = self.master[self.lo:self.hi]
         wk = self.work[self.lo:self.hi]
         self.adamw_fn(p, g, self.m, self.v, wk, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
                       weight_decay=self.wd, step=self.step_count,
                       sumsq=self.sumsq if self.max_grad_norm is not None else None,
                       max_norm=self.max_grad_norm, grad_div=grad_div)
-        self._grad_div = grad_div
         if self._collective and self.mode == "zero1":
             n = self.work.numel()
             self._wpad[self.lo:self.hi].copy_(wk)

@@ -1,0 +1,87 @@
+"""OPA LoRA-SFT step at tensor level.
+
+Reference: opadpo/opa_train.py + opadpo/opa_models/opa_trainer.py:58-125 — HF Trainer over LLaVA with LoRA on every
+nn.Linear except lm_head (LLM projections AND the CLIP tower's q/k/v/out_proj/fc1/fc2 AND mm_projector.0/.2), loss = the
+causal-LM cross-entropy over `labels != -100` (mean over the labelled tokens of the micro-batch), AdamW, global-norm clipping
+over ALL trainable tensors.  The optional entropy regulariser (`entropy_loss`, default False) is not built yet.
+
+Tensor contract of this build (the DPO collator's layout): `queries [B,Q]` left-padded with one image token, `responses
+[B,T]` right-padded with pad 0 — the labelled tokens are the non-pad response tokens (prompt tokens carry -100 in the
+reference's collator, utils/data_utils_sft.py).  Everything on the GPU path runs on the HIP kernels: vision_train.VisionTrainPath
+(trainable CLIP + projector LoRA), LlavaEngine.seq_logprobs_fwd/bwd (LLM LoRA, d_feats), optim.FlatAdamW x2 with ONE shared
+clipping norm; data parallel = the same flat-gradient exchange as the DPO stage, once per buffer.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .dims import PAD_ID
+from .model import LlavaEngine, LoraAdapter
+from .optim import FlatAdamW
+from .policy import AutoregressivePolicy
+from .vision_train import VisionLoraAdapter, VisionTrainPath
+
+
+class SFTTrainer:
+    def __init__(self, engine: LlavaEngine, llm_adapter: LoraAdapter, vis_adapter: VisionLoraAdapter, *, response_len: int,
+                 lr: float = 2e-5, max_grad_norm: Optional[float] = 1.0, weight_decay: float = 0.0, optimizer_mode: str = "allreduce"):
+        assert llm_adapter.trainable
+        self.engine, self.llm, self.vis = engine, llm_adapter, vis_adapter
+        self.vision = VisionTrainPath(engine.base, vis_adapter)
+        self._policy = AutoregressivePolicy(engine, llm_adapter, response_len)      # batch building only
+        kw = dict(lr=lr, max_grad_norm=max_grad_norm, weight_decay=weight_decay, mode=optimizer_mode)
+        self.opt_llm = FlatAdamW(llm_adapter.master, llm_adapter.grad, llm_adapter.work, **kw)
+        self.opt_vis = FlatAdamW(vis_adapter.master, vis_adapter.grad, vis_adapter.work, **kw)
+
+    def loss_and_backward(self, images: torch.Tensor, queries: torch.Tensor, queries_attn_masks: torch.Tensor,
+                          responses: torch.Tensor, loss_scale: float = 1.0) -> float:
+        """CE over the non-pad response tokens; accumulates into both flat gradients.  Returns the (unscaled) loss."""
+        eng, d, dev = self.engine, self.engine.d, self.engine.dev
+        B = queries.shape[0]
+        feats, vsv = self.vision.forward(images)
+        _, batch = self._policy.build_batch(queries, queries_attn_masks, {"response": responses})
+        logp, _, sv = eng.seq_logprobs_fwd(self.llm, batch, feats.view(B, d.n_patches, d.hidden), 1.0, train=True)
+        mask = (responses.to(dev) != PAD_ID)
+        n = mask.sum().clamp_min(1).float()
+        loss = -(logp * mask).sum() / n
+        d_feats = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
+        eng.seq_logprobs_bwd(self.llm, sv, -(mask.float() / n) * loss_scale, d_feats=d_feats)
+        self.vision.backward(vsv, d_feats.view(B * d.n_patches, d.hidden))
+        return float(loss)
+
+    def optimizer_step(self, grad_accum_div: float = 1.0) -> float:
+        """Clip by the global norm over BOTH buffers, AdamW, refresh the K-major copies.  Returns the pre-clip global norm."""
+        self.opt_llm.prepare(grad_accum_div)
+        self.opt_vis.prepare(grad_accum_div)
+        FlatAdamW.share_sumsq(self.opt_llm, self.opt_vis)
+        norm = float(self.opt_llm.sumsq.sqrt()) * self.opt_llm._grad_div
+        self.opt_llm.apply()
+        self.opt_vis.apply()
+        self.opt_llm.zero_grad()
+        self.opt_vis.zero_grad()
+        self.llm.refresh_transposed()
+        self.vis.refresh_transposed()
+        return norm
+
+    def save(self, directory: str, base_model_name_or_path: str = "") -> None:
+        """`checkpoint-final/`-style PEFT adapter (adapter_model.bin + adapter_config.json) holding the LLM, CLIP and projector
+        LoRA tensors: the file the DPO stage starts from (policy_model_name_or_path; its loader merges the vision part)."""
+        import json
+        import os
+        os.makedirs(directory, exist_ok=True)
+        state = self.llm.to_peft_state()
+        state.update(self.vis.to_peft_state())
+        torch.save(state, os.path.join(directory, "adapter_model.bin"))
+        d = self.engine.d
+        cfg = {"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": d.lora_r, "lora_alpha": d.lora_alpha, "lora_dropout": 0.0, "bias": "none",
+               "target_modules": ["q_proj", "k_proj", "v_proj", "o_proj", "out_proj", "gate_proj", "up_proj", "down_proj", "fc1", "fc2",
+                                  "mm_projector.0", "mm_projector.2"],
+               "base_model_name_or_path": base_model_name_or_path, "inference_mode": True, "fan_in_fan_out": False}
+        with open(os.path.join(directory, "adapter_config.json"), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True)
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        loss = self.loss_and_backward(batch["images"], batch["queries"], batch["queries_attn_masks"], batch["responses"])
+        return {"loss": loss, "grad_norm": self.optimizer_step()}

@@ -105,6 +105,22 @@ class VisionLoraAdapter:
                     L.call("opadpo_transpose", L.ptr(src[gi * per * cols:]), L.ptr(dst[gi * per * cols:]), per, cols, st)
 
 
+    def to_peft_state(self) -> Dict[str, torch.Tensor]:
+        """PEFT key layout of the CLIP / projector LoRA tensors (what the DPO stage merges into the vision weights at load)."""
+        out = {}
+        pm = _vis_peft_map(self.dims)
+        for j in range(self.dims.v_used_layers):
+            for name in self.offsets[j]:
+                view = self.w(j, name)
+                for mod, ab, r0, nr in pm[name]:
+                    out[f"{PEFT_PREFIX}{VIS_PREFIX}encoder.layers.{j}.{mod}.{ab}.weight"] = view[r0: r0 + nr].to(BF).cpu().clone()
+        for name in self.offsets[self.dims.v_used_layers]:
+            mod = "mm_projector.0" if name.endswith("p0") else "mm_projector.2"
+            ab = "lora_A" if name.startswith("a_") else "lora_B"
+            out[f"{PEFT_PREFIX}{LLM_PREFIX}{mod}.{ab}.weight"] = self.w(self.dims.v_used_layers, name).to(BF).cpu().clone()
+        return out
+
+
 class VisionTrainPath:
     """Forward with saved activations + LoRA backward for the vision tower and the projector."""
 

@@ -405,6 +405,59 @@ def test_sft_step_gradients_end_to_end(setup):
     assert not bad, bad
 
 
+def test_sft_trainer_step(setup):
+    """SFTTrainer: one clipped AdamW step over LLM + vision LoRA with ONE global norm; the norm equals the oracle's, the loss
+    goes down on the same batch, both buffers move."""
+    s = setup
+    LR = s["LR"]
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
+    from opadpo_amd.sft import SFTTrainer
+    from opadpo_amd.vision_train import VisionLoraAdapter
+    d, od, dev = s["d"], s["od"], s["dev"]
+    B, Q, T = 2, 12, 9
+    images, queries, qmask, resp = make_inputs(d, B, Q, T, seed=29)
+    r = resp["standard_response"]
+    eng = LlavaEngine(BaseWeights(d, s["W"], dev, need_backward=True))              # vision LoRA NOT merged
+    llm, vis = LoraAdapter(d, s["lora_pol"], dev, trainable=True), VisionLoraAdapter(d, s["lora_pol"], dev)
+    tr = SFTTrainer(eng, llm, vis, response_len=T, lr=2e-3, max_grad_norm=1.0)
+    m0_llm, m0_vis = llm.master.clone(), vis.master.clone()
+    batch = dict(images=images.to(dev), queries=queries, queries_attn_masks=qmask, responses=r)
+    st1 = tr.step(batch)
+    lora = {k: v.clone().requires_grad_(True) for k, v in s["lora_pol"].items()}
+    want = LR.policy_forward(images, queries, qmask, {"standard_response": r}, s["W"], lora, od, 1.0)
+    om = r != 0
+    oloss = -(want["standard_response_logprobs"] * om).sum() / om.sum()
+    oloss.backward()
+    used = [v.grad for k, v in lora.items() if v.grad is not None and not any(f"encoder.layers.{j}." in k for j in range(d.v_used_layers, d.v_layers))]
+    onorm = float(torch.sqrt(sum((g ** 2).sum() for g in used)))
+    assert abs(st1["loss"] - float(oloss)) < 5e-3 * abs(float(oloss)) + 1e-3
+    assert abs(st1["grad_norm"] - onorm) < 3e-2 * onorm, (st1["grad_norm"], onorm)
+    assert float((llm.master - m0_llm).abs().max()) > 0 and float((vis.master - m0_vis).abs().max()) > 0
+    losses = [st1["loss"]] + [tr.step(batch)["loss"] for _ in range(3)]
+    assert losses[-1] < losses[0], losses
+    REPORT["sft_losses"] = losses
+    # hand-over to the DPO stage: the saved adapter, loaded the DPO way (vision part merged into the weights), gives the
+    # features of the trained unmerged path and the same response log-probs
+    import tempfile
+    from opadpo_amd.checkpoint_io import load_adapter
+    from opadpo_amd.policy import AutoregressivePolicy
+    with tempfile.TemporaryDirectory() as td:
+        tr.save(td)
+        sd = load_adapter(td)
+    vis_sd = {k: v for k, v in sd.items() if "vision_tower" in k or "mm_projector" in k}
+    assert len(vis_sd) == 2 * (6 * d.v_used_layers + 2) and len(sd) == len(vis_sd) + 2 * 7 * d.n_layers
+    eng2 = LlavaEngine(BaseWeights(d, s["W"], dev, need_backward=False, vision_lora=vis_sd))
+    f_merged = eng2.encode_images(images.to(dev)).reshape(B * d.n_patches, d.hidden)
+    f_train, _ = tr.vision.forward(images.to(dev))
+    assert rel(f_merged, f_train.float().cpu()) < 2e-2
+    pol2 = AutoregressivePolicy(eng2, LoraAdapter(d, sd, dev, trainable=False), T)
+    with torch.no_grad():
+        o2 = pol2(images=images.to(dev), queries=queries, queries_attn_masks=qmask, standard_response=r)
+    keys, b1 = tr._policy.build_batch(queries, qmask, {"response": r})
+    lp1, _, _ = eng.seq_logprobs_fwd(llm, b1, f_train.view(B, d.n_patches, d.hidden), 1.0, train=False)
+    assert rel(o2["standard_response_logprobs"], lp1.cpu()) < 2e-2
+
+
 def test_wide_model_parity():
     """LLaVA-1.5-7B WIDTH (H 4096, FFN 11008, V 32000, r 256; 2 layers, small vision tower) so that the large-shape
     kernel paths (256x256 ping-pong GEMM, K = 11008, 125 vocabulary tiles) run inside the model; log-probs and LoRA
