@@ -125,9 +125,11 @@ int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int 
  * logits fp32 [rows,V] (ldl), labels int32 (0 = pad -> logp = -0.0, ent = 0), z = logits*inv_temp. */
 int opadpo_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,
                     float* lse, int rows, int V, void* stream);
-/* dz = dlogp * (onehot(label) - softmax(z)) * inv_temp as bf16 [rows,V] (ldz). */
+/* dz = [dlogp * (onehot(label) - p) - dent * p * (log p + ent)] * inv_temp as bf16 [rows,V] (ldz), p = softmax(z).  ent (the
+ * row entropies from head_fwd) and dent (their gradient) are nullable: only the OPA-SFT entropy regulariser
+ * (opa_models/opa_trainer.py:64-90) differentiates the entropy; the DPO path passes NULL. */
 int opadpo_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
-                    float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream);
+                    const float* ent, const float* dent, float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream);
 
 /* ---- clip_grad_norm_ + AdamW (rl_trainer.py:164-175; utils/trainer_utils.py:35) ------------------- */
 int opadpo_sumsq(const float* g, size_t n, float* out, void* stream);  /* out[0] += sum g^2 */

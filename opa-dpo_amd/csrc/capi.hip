@@ -164,9 +164,9 @@ int opadpo_head_fwd(const float* logits, int ldl, const int32_t* labels, float i
   return done(launch_head_fwd(logits, ldl, labels, inv_temp, logp, ent, lse, rows, V, S(stream)), "opadpo_head_fwd");
 }
 int opadpo_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
-                    float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream) {
-  if (!logits || !labels || !lse || !dlogp || !dz) return bad("opadpo_head_bwd", "null operand");
-  return done(launch_head_bwd(logits, ldl, labels, lse, dlogp, inv_temp, dz, ldz, rows, V, S(stream)), "opadpo_head_bwd");
+                    const float* ent, const float* dent, float inv_temp, uint16_t* dz, int ldz, int rows, int V, void* stream) {
+  if (!logits || !labels || !lse || !dlogp || !dz || (dent && !ent)) return bad("opadpo_head_bwd", "null operand");
+  return done(launch_head_bwd(logits, ldl, labels, lse, dlogp, ent, dent, inv_temp, dz, ldz, rows, V, S(stream)), "opadpo_head_bwd");
 }
 int opadpo_sumsq(const float* g, size_t n, float* out, void* stream) {
   return done(launch_sumsq(g, n, out, S(stream)), "opadpo_sumsq");

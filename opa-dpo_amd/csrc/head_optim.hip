@@ -44,12 +44,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* logits, int 
 }
 
 // dz[v] = dlogp * (1[v == label] - softmax(z)[v]) * inv_temp   (0 for pad rows), written as bf16
+// dz = inv_temp * [ dlogp * (onehot(label) - p)  +  dent * (-p * (log p + H)) ]   (H = -sum p log p, its gradient is only
+// needed by the OPA-SFT entropy regulariser: opa_trainer.py:64-90; ent / dent nullable)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* logits, int ldl, const int32_t* labels, const float* lse,
-                                                        const float* dlogp, float inv_temp, bf16_t* dz, int ldz, int V) {
+                                                        const float* dlogp, const float* ent, const float* dent, float inv_temp,
+                                                        bf16_t* dz, int ldz, int V) {
   const size_t row = blockIdx.x;
   const float* z = logits + row * ldl;
   const int lab = labels[row];
   const float g = (lab == 0) ? 0.f : dlogp[row];
+  const float ge = (lab == 0 || !dent) ? 0.f : dent[row];
+  const float Hrow = ent ? ent[row] : 0.f;
   const float l = lse[row];
   bf16_t* out = dz + row * ldz;
   for (int i = threadIdx.x * 4; i < V; i += 256 * 4) {
@@ -57,8 +62,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* logits, int 
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float pr = __expf(o[j] * inv_temp - l);
-      o[j] = g * (((i + j) == lab ? 1.0f : 0.0f) - pr) * inv_temp;
+      const float lp = o[j] * inv_temp - l;
+      const float pr = __expf(lp);
+      o[j] = (g * (((i + j) == lab ? 1.0f : 0.0f) - pr) - ge * pr * (lp + Hrow)) * inv_temp;
     }
     uint2 w;
     w.x = pack_bf2(o[0], o[1]);
@@ -123,10 +129,11 @@ hipError_t launch_head_fwd(const float* logits, int ldl, const int32_t* labels, 
   return hipGetLastError();
 }
 hipError_t launch_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
+                           const float* ent, const float* dent,
                            float inv_temp, bf16_t* dz, int ldz, int rows, int V, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (V % 4 || ldl % 4 || ldz % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(rows), dim3(256), 0, st, logits, ldl, labels, lse, dlogp, inv_temp, dz, ldz, V);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(rows), dim3(256), 0, st, logits, ldl, labels, lse, dlogp, ent, dent, inv_temp, dz, ldz, V);
   return hipGetLastError();
 }
 hipError_t launch_sumsq(const float* g, size_t n, float* out, hipStream_t st) {

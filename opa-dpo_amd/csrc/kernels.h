@@ -86,6 +86,7 @@ hipError_t launch_f32_to_bf16_strided(const float* in, bf16_t* out, size_t rows,
 hipError_t launch_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,
                            float* lse, int rows, int V, hipStream_t st);
 hipError_t launch_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
+                           const float* ent, const float* dent,
                            float inv_temp, bf16_t* dz, int ldz, int rows, int V, hipStream_t st);
 
 hipError_t launch_sumsq(const float* g, size_t n, float* out, hipStream_t st);

@@ -47,7 +47,7 @@ SIGNATURES = {
     "opadpo_f32_to_bf16": [_p, _p, _sz, _p],
     "opadpo_f32_to_bf16_strided": [_p, _p, _sz, _i, _i, _p],
     "opadpo_head_fwd": [_p, _i, _p, _f, _p, _p, _p, _i, _i, _p],
-    "opadpo_head_bwd": [_p, _i, _p, _p, _p, _f, _p, _i, _i, _i, _p],
+    "opadpo_head_bwd": [_p, _i, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p],
     "opadpo_sumsq": [_p, _sz, _p, _p],
     "opadpo_adamw": [_p, _p, _p, _p, _p, _sz, _d, _d, _d, _d, _d, _i, _p, _d, _d, _p],
     "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _f, _p, _sz, _p],

@@ -449,12 +449,15 @@ class LlavaEngine:
         ent = torch.empty(R, dtype=torch.float32, device=self.dev)
         L.call("opadpo_head_fwd", L.ptr(sv.logits), d.vocab, L.ptr(labels), 1.0 / temperature, L.ptr(logp), L.ptr(ent),
                L.ptr(sv.lse_head), R, d.vocab, st)
+        sv.ent = ent
         return logp.view(K * S, T), ent.view(K * S, T), sv
 
-    def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor, d_feats: Optional[torch.Tensor] = None) -> None:
+    def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor, d_feats: Optional[torch.Tensor] = None,
+                         d_ent: Optional[torch.Tensor] = None) -> None:
         """Accumulate d(loss)/d(LoRA A,B) into adapter.grad given dlogp [S,T] fp32.  d_feats (optional, fp32 [n_images, P, H],
         accumulated): gradient w.r.t. the projected image features — only the OPA LoRA-SFT stage needs it (trainable vision /
-        projector LoRA, vision_train.py); the DPO stage stops at the frozen layer-0 input."""
+        projector LoRA, vision_train.py); the DPO stage stops at the frozen layer-0 input.  d_ent (optional, [S,T]): gradient
+        w.r.t. the per-token entropies (SFT entropy regulariser)."""
         assert sv.train and adapter.trainable and self.base.need_backward
         d, b = self.d, self.base
         st = L.stream()
@@ -465,8 +468,10 @@ class LlavaEngine:
         seg = sv.seg
         dlogp = dlogp.to(device=self.dev, dtype=torch.float32).contiguous().view(-1)
         dz = self.buf("bw_dz", (R, V))
+        if d_ent is not None:
+            d_ent = d_ent.to(device=self.dev, dtype=torch.float32).contiguous().view(-1)
         L.call("opadpo_head_bwd", L.ptr(sv.logits), V, L.ptr(sv.labels), L.ptr(sv.lse_head), L.ptr(dlogp),
-               1.0 / sv.temperature, L.ptr(dz), V, R, V, st)
+               L.ptr(sv.ent) if d_ent is not None else None, L.ptr(d_ent), 1.0 / sv.temperature, L.ptr(dz), V, R, V, st)
         d_hn = self.buf("bw_dhn", (R, H))
         L.gemm_nt(dz, b.lm_head_t, d_hn)
         d_hs = self.buf("bw_dhs", (R, H), torch.float32)

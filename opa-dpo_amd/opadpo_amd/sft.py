@@ -3,7 +3,9 @@
 Reference: opadpo/opa_train.py + opadpo/opa_models/opa_trainer.py:58-125 — HF Trainer over LLaVA with LoRA on every
 nn.Linear except lm_head (LLM projections AND the CLIP tower's q/k/v/out_proj/fc1/fc2 AND mm_projector.0/.2), loss = the
 causal-LM cross-entropy over `labels != -100` (mean over the labelled tokens of the micro-batch), AdamW, global-norm clipping
-over ALL trainable tensors.  The optional entropy regulariser (`entropy_loss`, default False) is not built yet.
+over ALL trainable tensors; optional entropy regulariser (`entropy_loss`, default False in configs/llava/llava_opa.yaml): a
+second forward on the randomly masked image, loss += coef * mean_b( -sum_t (H_masked - H_clean) m / sum_t m ), gradient through
+BOTH forwards' entropies (opa_trainer.py:64-90; mask methods 'random' / 'blockwise' via losses.mask_single_image).
 
 Tensor contract of this build (the DPO collator's layout): `queries [B,Q]` left-padded with one image token, `responses
 [B,T]` right-padded with pad 0 — the labelled tokens are the non-pad response tokens (prompt tokens carry -100 in the
@@ -26,8 +28,13 @@ from .vision_train import VisionLoraAdapter, VisionTrainPath
 
 class SFTTrainer:
     def __init__(self, engine: LlavaEngine, llm_adapter: LoraAdapter, vis_adapter: VisionLoraAdapter, *, response_len: int,
-                 lr: float = 2e-5, max_grad_norm: Optional[float] = 1.0, weight_decay: float = 0.0, optimizer_mode: str = "allreduce"):
+                 lr: float = 2e-5, max_grad_norm: Optional[float] = 1.0, weight_decay: float = 0.0, optimizer_mode: str = "allreduce",
+                 entropy_loss: bool = False, entropy_mask_ratio: float = 0.2, entropy_mask_method: str = "random",
+                 entropy_loss_coef: float = 1.0, entropy_decay_coef: float = 1.0):
         assert llm_adapter.trainable
+        self.entropy_loss, self.entropy_mask_ratio, self.entropy_mask_method = entropy_loss, entropy_mask_ratio, entropy_mask_method
+        self.entropy_loss_coef, self.entropy_decay_coef = entropy_loss_coef, entropy_decay_coef
+        self.last = {}
         self.engine, self.llm, self.vis = engine, llm_adapter, vis_adapter
         self.vision = VisionTrainPath(engine.base, vis_adapter)
         self._policy = AutoregressivePolicy(engine, llm_adapter, response_len)      # batch building only
@@ -36,18 +43,39 @@ class SFTTrainer:
         self.opt_vis = FlatAdamW(vis_adapter.master, vis_adapter.grad, vis_adapter.work, **kw)
 
     def loss_and_backward(self, images: torch.Tensor, queries: torch.Tensor, queries_attn_masks: torch.Tensor,
-                          responses: torch.Tensor, loss_scale: float = 1.0) -> float:
-        """CE over the non-pad response tokens; accumulates into both flat gradients.  Returns the (unscaled) loss."""
+                          responses: torch.Tensor, loss_scale: float = 1.0, masked_images: Optional[torch.Tensor] = None) -> float:
+        """CE over the non-pad response tokens (+ the entropy regulariser); accumulates into both flat gradients.  Returns the
+        (unscaled) loss; self.last holds base_sft_loss / mask_sft_loss / entropy_loss like the reference's log (opa_trainer.py:92-94)."""
         eng, d, dev = self.engine, self.engine.d, self.engine.dev
         B = queries.shape[0]
-        feats, vsv = self.vision.forward(images)
         _, batch = self._policy.build_batch(queries, queries_attn_masks, {"response": responses})
-        logp, _, sv = eng.seq_logprobs_fwd(self.llm, batch, feats.view(B, d.n_patches, d.hidden), 1.0, train=True)
         mask = (responses.to(dev) != PAD_ID)
         n = mask.sum().clamp_min(1).float()
+        feats, vsv = self.vision.forward(images)
+        logp, ent, sv = eng.seq_logprobs_fwd(self.llm, batch, feats.view(B, d.n_patches, d.hidden), 1.0, train=True)
         loss = -(logp * mask).sum() / n
+        self.last = {"base_sft_loss": float(loss), "mask_sft_loss": 0.0, "entropy_loss": 0.0}
+        d_ent = None
+        if self.entropy_loss:
+            if masked_images is None:      # global CPU RNG, like the reference (mask_single_image draws torch.randperm)
+                from .losses import mask_single_image
+                masked_images = torch.stack([mask_single_image(images[i].unsqueeze(0).cpu(), self.entropy_mask_ratio, self.entropy_mask_method)
+                                             for i in range(B)]).squeeze(1)
+            feats2, vsv2 = self.vision.forward(masked_images)
+            logp2, ent2, sv2 = eng.seq_logprobs_fwd(self.llm, batch, feats2.view(B, d.n_patches, d.hidden), 1.0, train=True)
+            per_row = mask.sum(1).clamp_min(1).float()
+            e_loss = (-((ent2 - ent) * mask).sum(1) / per_row).mean()
+            self.entropy_loss_coef *= self.entropy_decay_coef                      # opa_trainer.py:119 (decay applied before use)
+            coef = self.entropy_loss_coef
+            self.last.update(mask_sft_loss=float(-(logp2 * mask).sum() / n), entropy_loss=float(e_loss))
+            loss = loss + coef * e_loss
+            w = (coef / B) * mask.float() / per_row[:, None]                       # d e_loss / d ent2 = -w, / d ent = +w
+            d_ent = w * loss_scale
+            d_feats2 = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
+            eng.seq_logprobs_bwd(self.llm, sv2, torch.zeros_like(logp2), d_feats=d_feats2, d_ent=-d_ent)
+            self.vision.backward(vsv2, d_feats2.view(B * d.n_patches, d.hidden))
         d_feats = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
-        eng.seq_logprobs_bwd(self.llm, sv, -(mask.float() / n) * loss_scale, d_feats=d_feats)
+        eng.seq_logprobs_bwd(self.llm, sv, -(mask.float() / n) * loss_scale, d_feats=d_feats, d_ent=d_ent)
         self.vision.backward(vsv, d_feats.view(B * d.n_patches, d.hidden))
         return float(loss)
 
@@ -83,5 +111,6 @@ class SFTTrainer:
             json.dump(cfg, f, indent=2, sort_keys=True)
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, float]:
-        loss = self.loss_and_backward(batch["images"], batch["queries"], batch["queries_attn_masks"], batch["responses"])
-        return {"loss": loss, "grad_norm": self.optimizer_step()}
+        loss = self.loss_and_backward(batch["images"], batch["queries"], batch["queries_attn_masks"], batch["responses"],
+                                      masked_images=batch.get("masked_images"))
+        return {"loss": loss, "grad_norm": self.optimizer_step(), **self.last}

@@ -581,12 +581,19 @@ def test_head(L):
     assert float(logp[3]) == 0.0 and math.copysign(1.0, float(logp[3])) == -1.0     # -0.0 on pad (Quirk Q4)
     dlogp = torch.randn(rows, device=dev())
     dz = torch.empty(rows, V, dtype=BF, device=dev())
-    L.call("opadpo_head_bwd", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), dlogp.data_ptr(), 1 / temp,
+    L.call("opadpo_head_bwd", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), dlogp.data_ptr(), None, None, 1 / temp,
            dz.data_ptr(), V, rows, V, L.stream())
-    (want_lp * dlogp).sum().backward()
+    (want_lp * dlogp).sum().backward(retain_graph=True)
     want_dz = z.grad / temp      # d/d logits
     assert relerr(dz, want_dz) < 5e-3
     assert float(dz[3].float().abs().max()) == 0.0
+    # entropy gradient (OPA-SFT regulariser): loss = sum(dlogp * logp) + sum(dent * H)
+    dent = torch.randn(rows, device=dev())
+    L.call("opadpo_head_bwd", logits.data_ptr(), V, labels.data_ptr(), lse.data_ptr(), dlogp.data_ptr(), ent.data_ptr(), dent.data_ptr(),
+           1 / temp, dz.data_ptr(), V, rows, V, L.stream())
+    z.grad = None
+    ((want_lp * dlogp).sum() + (want_ent * dent).sum()).backward()
+    assert relerr(dz, z.grad / temp) < 5e-3 and float(dz[3].float().abs().max()) == 0.0
 
 
 def test_adamw_and_sumsq(L):
