@@ -5,7 +5,8 @@ nn.Linear except lm_head (LLM projections AND the CLIP tower's q/k/v/out_proj/fc
 causal-LM cross-entropy over `labels != -100` (mean over the labelled tokens of the micro-batch), AdamW, global-norm clipping
 over ALL trainable tensors; optional entropy regulariser (`entropy_loss`, default False in configs/llava/llava_opa.yaml): a
 second forward on the randomly masked image, loss += coef * mean_b( -sum_t (H_masked - H_clean) m / sum_t m ), gradient through
-BOTH forwards' entropies (opa_trainer.py:64-90; mask methods 'random' / 'blockwise' via losses.mask_single_image).
+BOTH forwards' entropies (opa_trainer.py:64-90; mask methods 'random' / 'blockwise' via losses.mask_single_image, 'attention' =
+image keys dropped from the attention mask).
 
 Tensor contract of this build (the DPO collator's layout): `queries [B,Q]` left-padded with one image token, `responses
 [B,T]` right-padded with pad 0 — the labelled tokens are the non-pad response tokens (prompt tokens carry -100 in the
@@ -43,7 +44,8 @@ class SFTTrainer:
         self.opt_vis = FlatAdamW(vis_adapter.master, vis_adapter.grad, vis_adapter.work, **kw)
 
     def loss_and_backward(self, images: torch.Tensor, queries: torch.Tensor, queries_attn_masks: torch.Tensor,
-                          responses: torch.Tensor, loss_scale: float = 1.0, masked_images: Optional[torch.Tensor] = None) -> float:
+                          responses: torch.Tensor, loss_scale: float = 1.0, masked_images: Optional[torch.Tensor] = None,
+                          image_key_mask: Optional[torch.Tensor] = None) -> float:
         """CE over the non-pad response tokens (+ the entropy regulariser); accumulates into both flat gradients.  Returns the
         (unscaled) loss; self.last holds base_sft_loss / mask_sft_loss / entropy_loss like the reference's log (opa_trainer.py:92-94)."""
         eng, d, dev = self.engine, self.engine.d, self.engine.dev
@@ -56,13 +58,26 @@ class SFTTrainer:
         loss = -(logp * mask).sum() / n
         self.last = {"base_sft_loss": float(loss), "mask_sft_loss": 0.0, "entropy_loss": 0.0}
         d_ent = None
+        d_feats = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
         if self.entropy_loss:
-            if masked_images is None:      # global CPU RNG, like the reference (mask_single_image draws torch.randperm)
-                from .losses import mask_single_image
-                masked_images = torch.stack([mask_single_image(images[i].unsqueeze(0).cpu(), self.entropy_mask_ratio, self.entropy_mask_method)
-                                             for i in range(B)]).squeeze(1)
-            feats2, vsv2 = self.vision.forward(masked_images)
-            logp2, ent2, sv2 = eng.seq_logprobs_fwd(self.llm, batch, feats2.view(B, d.n_patches, d.hidden), 1.0, train=True)
+            if self.entropy_mask_method == "attention" and masked_images is None:
+                # opa_trainer.py:75-81: same pixels, 'entropy_mask_ratio' of the image KEYS dropped from the attention mask
+                # (the reference hard-codes 1369 keys = a 518-px tower; here the tower's own patch count)
+                from .losses import mask_percentage_per_row
+                im = image_key_mask if image_key_mask is not None else mask_percentage_per_row(
+                    torch.ones(B, d.n_patches, dtype=torch.bool), self.entropy_mask_ratio)
+                _, batch2 = self._policy.build_batch(queries, torch.cat([im.to(queries_attn_masks.device), queries_attn_masks.bool()], 1),
+                                                     {"response": responses})
+                feats2, vsv2, d_feats2 = feats, None, d_feats          # one vision pass: both LLM backwards add into d_feats
+            else:
+                if masked_images is None:      # global CPU RNG, like the reference (mask_single_image draws torch.randperm)
+                    from .losses import mask_single_image
+                    masked_images = torch.stack([mask_single_image(images[i].unsqueeze(0).cpu(), self.entropy_mask_ratio,
+                                                                   self.entropy_mask_method) for i in range(B)]).squeeze(1)
+                batch2 = batch
+                feats2, vsv2 = self.vision.forward(masked_images)
+                d_feats2 = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
+            logp2, ent2, sv2 = eng.seq_logprobs_fwd(self.llm, batch2, feats2.view(B, d.n_patches, d.hidden), 1.0, train=True)
             per_row = mask.sum(1).clamp_min(1).float()
             e_loss = (-((ent2 - ent) * mask).sum(1) / per_row).mean()
             self.entropy_loss_coef *= self.entropy_decay_coef                      # opa_trainer.py:119 (decay applied before use)
@@ -71,10 +86,9 @@ class SFTTrainer:
             loss = loss + coef * e_loss
             w = (coef / B) * mask.float() / per_row[:, None]                       # d e_loss / d ent2 = -w, / d ent = +w
             d_ent = w * loss_scale
-            d_feats2 = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
             eng.seq_logprobs_bwd(self.llm, sv2, torch.zeros_like(logp2), d_feats=d_feats2, d_ent=-d_ent)
-            self.vision.backward(vsv2, d_feats2.view(B * d.n_patches, d.hidden))
-        d_feats = torch.zeros(B, d.n_patches, d.hidden, dtype=torch.float32, device=dev)
+            if vsv2 is not None:
+                self.vision.backward(vsv2, d_feats2.view(B * d.n_patches, d.hidden))
         eng.seq_logprobs_bwd(self.llm, sv, -(mask.float() / n) * loss_scale, d_feats=d_feats, d_ent=d_ent)
         self.vision.backward(vsv, d_feats.view(B * d.n_patches, d.hidden))
         return float(loss)

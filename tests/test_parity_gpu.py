@@ -512,6 +512,50 @@ def test_sft_entropy_regulariser_gradients(setup):
     assert not bad, bad
 
 
+def test_sft_entropy_attention_mask_method(setup):
+    """entropy_mask_method='attention': the second forward sees the same pixels with a share of the image KEYS masked; one
+    vision pass, both LLM backwards feed d_feats.  Loss + projector / LLM gradients vs oracle autograd."""
+    s = setup
+    LR = s["LR"]
+    from opadpo_amd.dims import LLM_PREFIX, PEFT_PREFIX
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter, _peft_map, lora_blocks
+    from opadpo_amd.sft import SFTTrainer
+    from opadpo_amd.vision_train import VisionLoraAdapter, projector_lora_blocks
+    d, od, dev = s["d"], s["od"], s["dev"]
+    B, Q, T = 2, 12, 9
+    images, queries, qmask, resp = make_inputs(d, B, Q, T, seed=37)
+    r = resp["standard_response"]
+    im = torch.ones(B, d.n_patches, dtype=torch.bool)
+    im[0, 1] = im[0, 5] = im[1, 0] = im[1, 7] = False
+    eng = LlavaEngine(BaseWeights(d, s["W"], dev, need_backward=True))
+    llm, vis = LoraAdapter(d, s["lora_pol"], dev, trainable=True), VisionLoraAdapter(d, s["lora_pol"], dev)
+    tr = SFTTrainer(eng, llm, vis, response_len=T, entropy_loss=True, entropy_loss_coef=0.5, entropy_mask_method="attention")
+    loss = tr.loss_and_backward(images.to(dev), queries, qmask, r, image_key_mask=im)
+    torch.cuda.synchronize()
+    lora = {k: v.clone().requires_grad_(True) for k, v in s["lora_pol"].items()}
+    w1 = LR.policy_forward(images, queries, qmask, {"standard_response": r}, s["W"], lora, od, 1.0)
+    w2 = LR.policy_forward(images, queries, torch.cat([im, qmask], 1), {"standard_response": r}, s["W"], lora, od, 1.0)
+    om = (r != 0)
+    oloss = -(w1["standard_response_logprobs"] * om).sum() / om.sum() + 0.5 * (
+        -((w2["standard_response_entropies"] - w1["standard_response_entropies"]) * om).sum(1) / om.sum(1)).mean()
+    oloss.backward()
+    assert abs(loss - float(oloss)) < 5e-3 * abs(float(oloss)) + 2e-3, (loss, float(oloss))
+    worst = {}
+    for name, rows, cols in projector_lora_blocks(d):
+        mod = "mm_projector.0" if name.endswith("p0") else "mm_projector.2"
+        ab = "lora_A" if name.startswith("a_") else "lora_B"
+        worst[f"proj_{name}"] = rel(vis.g(d.v_used_layers, name).cpu(), lora[f"{PEFT_PREFIX}{LLM_PREFIX}{mod}.{ab}.weight"].grad)
+    pml = _peft_map(d)
+    for i in range(d.n_layers):
+        for name, rows, cols in lora_blocks(d):
+            ref = torch.zeros(rows, cols)
+            for mod, ab, r0, nr in pml[name]:
+                ref[r0:r0 + nr] = lora[f"{PEFT_PREFIX}model.layers.{i}.{mod}.{ab}.weight"].grad
+            worst[f"llm_L{i}_{name}"] = rel(llm.g(i, name).cpu(), ref)
+    bad = {k: round(v, 4) for k, v in worst.items() if not v < 8e-2}
+    assert not bad, bad
+
+
 def test_wide_model_parity():
     """LLaVA-1.5-7B WIDTH (H 4096, FFN 11008, V 32000, r 256; 2 layers, small vision tower) so that the large-shape
     kernel paths (256x256 ping-pong GEMM, K = 11008, 125 vocabulary tiles) run inside the model; log-probs and LoRA
