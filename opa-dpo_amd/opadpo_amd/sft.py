@@ -27,6 +27,16 @@ from .policy import AutoregressivePolicy
 from .vision_train import VisionLoraAdapter, VisionTrainPath
 
 
+def sft_batches_from_dpo_batch(batch: Dict[str, torch.Tensor]):
+    """utils/data_utils_sft.py:187-246: every OPA dataset row (query, standard_response, AI_pseudo_response, image) yields TWO
+    single-turn SFT samples, human = query, gpt = the GPT-4V corrected response resp. the AI pseudo response (the two copies of
+    the dataset are concatenated and shuffled there).  Given a collated DPO batch (data.DataCollatorForCausalLM: left-padded
+    queries, right-padded responses) this returns the two SFT batches in this build's tensor contract."""
+    common = dict(images=batch["images"], queries=batch["queries"],
+                  queries_attn_masks=batch.get("queries_attention_mask", batch.get("queries_attn_masks")))
+    return [dict(common, responses=batch["standard_response"]), dict(common, responses=batch["AI_pseudo_response"])]
+
+
 class SFTTrainer:
     def __init__(self, engine: LlavaEngine, llm_adapter: LoraAdapter, vis_adapter: VisionLoraAdapter, *, response_len: int,
                  lr: float = 2e-5, max_grad_norm: Optional[float] = 1.0, weight_decay: float = 0.0, optimizer_mode: str = "allreduce",

@@ -277,3 +277,12 @@ def test_checkpoint_io_roundtrip(tmp_path):
     torch.save(ad, tmp_path / "adapter_model.bin")
     back = CK.load_adapter(str(tmp_path))
     assert set(back) == set(ad)
+
+
+def test_sft_batches_from_dpo_batch():
+    from opadpo_amd.sft import sft_batches_from_dpo_batch
+    b = dict(images=torch.zeros(2, 3, 4, 4), queries=torch.ones(2, 5, dtype=torch.long), queries_attention_mask=torch.ones(2, 5, dtype=torch.bool),
+             standard_response=torch.full((2, 3), 7), AI_pseudo_response=torch.full((2, 3), 9), original_generate_response=torch.full((2, 3), 5))
+    std, ai = sft_batches_from_dpo_batch(b)
+    assert set(std) == {"images", "queries", "queries_attn_masks", "responses"}
+    assert int(std["responses"][0, 0]) == 7 and int(ai["responses"][0, 0]) == 9 and std["queries"] is b["queries"]
