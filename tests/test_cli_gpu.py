@@ -37,3 +37,27 @@ def test_train_entry_point_checkpoints_and_resume(tmp_path):
     assert path.endswith("checkpoint-2") and not done
     cli.main(argv)                                                    # resumes from checkpoint-2
     assert os.path.exists(os.path.join(out, "completed"))
+
+
+def test_sft_entry_point(tmp_path):
+    """opadpo/opa_train_custom.py flag surface (run/train_opa.sh) on a tiny synthetic model: accumulation, cosine schedule,
+    periodic + final PEFT checkpoints holding LLM, CLIP and projector LoRA tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd import cli_sft
+    out = str(tmp_path / "opa")
+    argv = ["--synthetic", "tiny", "--synthetic_samples", "16", "--output_dir", out, "--per_device_train_batch_size", "2",
+            "--gradient_accumulation_steps", "2", "--num_train_epochs", "2", "--save_steps", "3", "--learning_rate", "1e-3",
+            "--full_tune", "False", "--lora_tune", "True", "--tune_vision_tower", "True", "--entropy_loss", "True",
+            "--entropy_mask_ratio", "0.5", "--entropy_loss_coef", "0.01", "--cfg", "none", "--bf16", "--tf32", "--deepspeed", "x.json"]
+    cli_sft.main(argv)
+    fin = os.path.join(out, "checkpoint-final")
+    sd = torch.load(os.path.join(fin, "adapter_model.bin"))
+    cfg = json.load(open(os.path.join(fin, "adapter_config.json")))
+    assert cfg["r"] == 128 and "fc1" in cfg["target_modules"]
+    n_vis = sum(1 for k in sd if "vision_tower" in k)
+    assert n_vis == 2 * 6 * 2 and sum(1 for k in sd if "mm_projector" in k) == 4 and len(sd) == n_vis + 4 + 2 * 7 * 2
+    ck3 = torch.load(os.path.join(out, "checkpoint-3", "adapter_model.bin"))
+    assert set(ck3) == set(sd) and sum(float((ck3[k].float() - sd[k].float()).abs().sum()) for k in sd) > 0
+    with pytest.raises(SystemExit):
+        cli_sft.main(argv + ["--full_tune", "True"])
