@@ -202,10 +202,18 @@ def main():
                                                         ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    # RCCL writes a version banner to stdout (fd 1) at process exit: send everything after the JSON line to stderr so that the
+    # line above stays the last thing on stdout
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
 
 if __name__ == "__main__":
