@@ -1463,7 +1463,15 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   const bool off32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
   const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
-  const bool auto_pp = g_gemm_variant == 10 && pp_tiles >= 384;
+  // one 256x256 block per CU and round: below 1.5 rounds the big tile only pays when its last round fills the chip
+  // (M = 32362: N = 512 -> 254 blocks, w4 1.10-1.18 PF/s vs 0.75-0.79 for the 128x128 kernel; N = 768 -> 381 blocks = 1.49
+  // rounds, 8-wave p8 0.92 vs 0.84 vs w4 0.81; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
+  const int pp_slots = ((pp_tiles + 255) / 256) * 256;
+  const bool auto_pp = g_gemm_variant == 10 && (pp_tiles >= 384 || (pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88));
+  if (g_gemm_variant == 10 && !auto_pp && pp_tiles >= 320) {
+    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if (g_gemm_variant == 17 && pp_tiles > 0) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();

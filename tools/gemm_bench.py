@@ -34,6 +34,11 @@ def main():
     shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008),
               ("down", 4096, 11008, 256, 0), ("lora_t", 768, 4096, 0, 0), ("lm_head", 32000, 4096, 0, 0)]
     only = os.environ.get("GB_ONLY", "")
+    if only == "lora":     # the small-N projections of the LoRA path at the bench row count (22 packed pairs)
+        M = int(os.environ.get("GB_M", 22 * 1471))
+        shapes = [("a_qkv", 768, 4096, 0, 0), ("a_o", 256, 4096, 0, 0), ("a_gu", 512, 4096, 0, 0), ("a_d", 256, 11008, 0, 0),
+                  ("dt_2r", 512, 11008, 0, 0)]
+        only = "gemm" if os.environ.get("GB_VARIANTS") else "yard"
     if only == "attn2":    # training attention at the bench shape: packed pairs [703 prefix | 384 | 384], realistic key mask
         S, nh, hd, pfx, T, K = int(os.environ.get("GB_S", 22)), 32, 128, 703, 384, 2
         Ln, H = pfx + K * T, nh * hd
