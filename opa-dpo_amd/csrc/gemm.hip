@@ -17,6 +17,11 @@
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
+#include <vector>
+#include <array>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -33,18 +38,44 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-// epilogue for 4 consecutive output columns of one row
-__device__ __forceinline__ void epilogue4(const GemmNTArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
-  float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
-  if (p.bias) {
+// Epilogue modes.  The bias / activation choice is made ONCE per kernel (epi_dispatch) and the unrolled epilogue is
+// instantiated per mode: with the checks inside epilogue4, every one of its 16-64 inlined copies carried both activation
+// bodies behind branches, the taken branches hopped through ~200 KiB of cold code, and the instruction-cache misses made the
+// epilogue of a 256x256 block take 20-27 us (a fifth of the block's lifetime; measured with s_memtime stamps, variant 27).
+//   0: alpha only   1: + bias   2: (+ bias) quick-GELU   3: (+ bias) GELU
+template <class F>
+__device__ __forceinline__ void epi_dispatch(const GemmNTArgs& p, F&& f) {
+  if (p.act == 0) {
+    if (!p.bias) f(std::integral_constant<int, 0>{});
+    else f(std::integral_constant<int, 1>{});
+  } else if (p.act == OPADPO_ACT_QUICK_GELU) {
+    f(std::integral_constant<int, 2>{});
+  } else {
+    f(std::integral_constant<int, 3>{});
+  }
+}
+
+// alpha, bias and activation of 4 consecutive output columns n..n+3
+template <int MD>
+__device__ __forceinline__ void epi_pre4(const GemmNTArgs& p, int n, float (&v)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
+  if (MD == 1 || (MD >= 2 && p.bias)) {
     const uint2 b = *(const uint2*)(p.bias + n);
     v[0] += __uint_as_float(b.x << 16); v[1] += __uint_as_float(b.x & 0xffff0000u);
     v[2] += __uint_as_float(b.y << 16); v[3] += __uint_as_float(b.y & 0xffff0000u);
   }
-  if (p.act) {
+  if (MD >= 2) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], p.act);
+    for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q], MD == 2 ? OPADPO_ACT_QUICK_GELU : OPADPO_ACT_GELU);
   }
+}
+
+// epilogue for 4 consecutive output columns of one row
+template <int MD>
+__device__ __forceinline__ void epilogue4(const GemmNTArgs& p, int m, int n, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  epi_pre4<MD>(p, n, v);
   if (p.R) {
     if (p.r_f32) {
       const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
@@ -175,14 +206,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
       cur ^= 1;
     }
     // lane holds C[m][n..n+3], m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4
+    epi_dispatch(p, [&](auto MD_) {
+      constexpr int md = decltype(MD_)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + frow;
-      if (m >= p.M) continue;
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        epilogue4(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    }
+        for (int j = 0; j < 4; ++j)
+          epilogue4<md>(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    });
   } else {
     f32x16_t acc[2][2];
 #pragma unroll
@@ -223,17 +257,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
       cur ^= 1;
     }
     // D[i' = n][j' = m]: lane holds m = m_base + i*32 + (lane&31); n = n_base + j*32 + 8*q + 4*(lane>>5) + (reg&3)
+    epi_dispatch(p, [&](auto MD_) {
+      constexpr int md = decltype(MD_)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + frow;
-      if (m >= p.M) continue;
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + frow;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          epilogue4(p, m, n0 + wn * 64 + j * 32 + q * 8 + fchk * 4, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
-                    acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-    }
+          for (int q = 0; q < 4; ++q)
+            epilogue4<md>(p, m, n0 + wn * 64 + j * 32 + q * 8 + fchk * 4, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
+                      acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+      }
+    });
   }
 }
 
@@ -338,14 +375,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ring_kernel(GemmNTArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     stage = (stage == 2) ? 0 : stage + 1;
   }
+  epi_dispatch(p, [&](auto MD_) {
+    constexpr int md = decltype(MD_)::value;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + i * 16 + frow;
-    if (m >= p.M) continue;
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + i * 16 + frow;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue4(p, m, n0 + wave * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-  }
+      for (int j = 0; j < 4; ++j)
+        epilogue4<md>(p, m, n0 + wave * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -432,14 +472,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
     __syncthreads();
     cur ^= 1;
   }
+  epi_dispatch(p, [&](auto MD_) {
+    constexpr int md = decltype(MD_)::value;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
-    if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + frow;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue4(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-  }
+      for (int j = 0; j < 4; ++j)
+        epilogue4<md>(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,26 +678,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 #undef PP_BARRIER
   if constexpr (MF32) {
     // D[i' = n][j' = m]: lane holds m = .. + (lane&31); n = .. + 8*q + 4*(lane>>5) + (reg&3)
+    epi_dispatch(p, [&](auto MD_) {
+      constexpr int md = decltype(MD_)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wr * 128 + i * 32 + frow;
-      if (m >= p.M) continue;
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 128 + i * 32 + frow;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          epilogue4(p, m, n0 + wc * 64 + j * 32 + q * 8 + fchk * 4, acc32[i][j][q * 4 + 0], acc32[i][j][q * 4 + 1],
-                    acc32[i][j][q * 4 + 2], acc32[i][j][q * 4 + 3]);
-    }
+          for (int q = 0; q < 4; ++q)
+            epilogue4<md>(p, m, n0 + wc * 64 + j * 32 + q * 8 + fchk * 4, acc32[i][j][q * 4 + 0], acc32[i][j][q * 4 + 1],
+                      acc32[i][j][q * 4 + 2], acc32[i][j][q * 4 + 3]);
+      }
+    });
   } else {
+    epi_dispatch(p, [&](auto MD_) {
+      constexpr int md = decltype(MD_)::value;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + frow;
-      if (m >= p.M) continue;
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + frow;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        epilogue4(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
-    }
+        for (int j = 0; j < 4; ++j)
+          epilogue4<md>(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
+      }
+    });
   }
 }
 
@@ -684,12 +733,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 // p8 2 x 245 M, vendor asm kernel 165 M (5 %); removing any ONE of its waits (racy diagnostics 24-26) gives +4.5 % each.
 // Variant 16 = single-barrier schedule, 18-21 / 24-26 = timing diagnostics (wrong results / racy).
 // ------------------------------------------------------------------------------------------
+// EXP == 10 (variant 27, diagnostic): the default schedule with s_memtime stamps around its two wait points; per wave
+// {cycles in the K-loop, cycles parked at wait 1 (lgkmcnt + barrier), at wait 2 (vmcnt + barrier), 100-MHz ticks, K-tiles}
+constexpr int W4_PROF_MAX_WG = 4096;
+constexpr int W4_PROF_N = 13;
+__device__ unsigned long long g_w4_prof[W4_PROF_MAX_WG * 4 * W4_PROF_N];
+
 template <int EXP>   // EXP (diagnostics, wrong results): 1 = no DMA in the K-loop, 2 = no LDS fragment reads in the K-loop
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
+  unsigned long long prof_e0 = 0, prof_r0 = 0;
+  int diag = 0;
+  if constexpr (EXP == 10) {
+    diag = p.act >> 9; p.act &= 0xff;      // diagnostics: bit 0 = skip the stores, bits 1.. = first-round stagger in units of 4 us
+    prof_e0 = __builtin_readcyclecounter(); prof_r0 = __builtin_amdgcn_s_memrealtime();
+    const int stag = diag >> 1;
+    if (stag > 0 && blockIdx.x < 256) {
+      const unsigned long long until = prof_r0 + (unsigned long long)((blockIdx.x * 37) & 255) * (unsigned)stag * 400ull / 256ull;
+      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+      prof_e0 = __builtin_readcyclecounter();
+    }
+  }
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
@@ -699,18 +766,26 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int gsz = min(tiles_m - first_m, GROUP_M);
   const int tm = first_m + (swz % width) % gsz;
   const int tn = (swz % width) / gsz;
-  const int m0 = tm * P_BM, n0 = tn * P_BN;
+  const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
 
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
-  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  const bf16_t* a1 = p.A1;
+  if (p.a1_group_n > 0) a1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
   const int srow = lane >> 3, spos = lane & 7;
 
-  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? a2 : p.A1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
+  // the resource descriptors must sit in SGPRs: a base the compiler cannot prove wave-uniform turns every buffer_load into
+  // a readfirstlane "waterfall" loop (seen once: +45 % K-loop time), so uniformity is stated explicitly
+  auto uni = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(uni(a1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? a2 : a1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
   const unsigned lrow = (unsigned)(wave * 64 + srow);                     // row of this wave's piece 0 inside the 256-row tile
   const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
   const unsigned m_last = (unsigned)(p.M - 1);
@@ -733,7 +808,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, row * ld2 + csw[pi & 1], k0 * 2, 0, 0);
     } else {
       const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-      const unsigned soff = ((unsigned)n0 + pi * 8u) * ld2 + k0 * 2;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)n0 + pi * 8u) * ld2 + k0 * 2));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, lrow * ld2 + csw[pi & 1], soff, 0, 0);
     }
   };
@@ -800,13 +875,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   //   P2: 24 MFMAs(kk=0) | 6 DMA (t+2)
   //   P3: 36 MFMAs(kk=1) | 7 DMA (t+2)                       | vmcnt(13), barrier   -> tile t+1 has landed
   //   P4: 28 MFMAs(kk=1) | 16 reads set0(t+1), 3 DMA (t+2)
+  unsigned long long prof_w1 = 0, prof_w2 = 0, prof_p1 = 0, prof_p23 = 0, prof_p4 = 0, prof_tb = 0;
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
     constexpr bool dma = has_next2;
     // schedule knobs (EXP 6 = default; 7, 8, 9 = variants measured against it)
     //   R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
     //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
-    constexpr int R1 = EXP == 8 ? 16 : (EXP == 6 ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    unsigned long long ts = 0;
+    if constexpr (EXP == 10) { ts = __builtin_readcyclecounter(); W4_PIN(); }
+    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
     // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -818,9 +896,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     mfma_run(0, R1, B1 - R1);
     W4_PIN();
     if constexpr (has_next2) {
+      unsigned long long ta = 0;
+      if constexpr (EXP == 10) { ta = __builtin_readcyclecounter(); W4_PIN(); prof_p1 += ta - ts; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
+      if constexpr (EXP == 10) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
     }
     // ---- P2/P3: MFMAs B1..99 (kk = 0 up to 63, then kk = 1), 13 DMA pieces of tile t+2, one per DSTEP MFMAs
     {
@@ -838,9 +919,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     }
     W4_PIN();
     if constexpr (has_next) {
+      unsigned long long tc = 0;
+      if constexpr (EXP == 10) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) prof_p23 += tc - prof_tb; }
       if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
+      if constexpr (EXP == 10) { W4_PIN(); prof_tb = __builtin_readcyclecounter(); prof_w2 += prof_tb - tc; }
     }
     W4_PIN();
     // ---- P4: 28 MFMAs, the 16 reads of set 0 of tile t+1, the last 3 pieces
@@ -858,6 +942,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     }
     mfma_run(1, 60, 4);
     W4_PIN();
+    if constexpr (EXP == 10 && has_next) { prof_p4 += __builtin_readcyclecounter() - prof_tb; W4_PIN(); }
   };
   using T_ = std::true_type; using F_ = std::false_type;
 
@@ -875,11 +960,26 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   W4_PIN();
+  unsigned long long prof_l1 = 0;
   if constexpr (EXP >= 6) {
+    unsigned long long pt0 = 0, pr0 = 0;
+    if constexpr (EXP == 10) { pt0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     int t = 0;
     for (; t + 2 < nt; ++t) tile_body_ll(t, T_{}, T_{});
     if (t + 1 < nt) { tile_body_ll(t, T_{}, F_{}); ++t; }
     tile_body_ll(t, F_{}, F_{});
+    if constexpr (EXP == 10) {
+      const unsigned long long pt1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
+        unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
+        o[0] = pt1 - pt0; o[1] = prof_w1; o[2] = prof_w2; o[3] = pr1 - pr0; o[4] = (unsigned long long)nt;
+        o[10] = prof_p1; o[11] = prof_p23; o[12] = prof_p4;
+        o[5] = pt0 - prof_e0;                                  // entry -> K-loop (index math, 32 DMA pieces, first landing)
+        o[7] = prof_r0;
+        o[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff00u);
+      }
+      prof_l1 = pt1;
+    }
   } else if (nt == 1) {
     tile_body(0, F_{}, F_{}, F_{});
   } else if (nt == 2) {
@@ -893,13 +993,99 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   }
 #undef W4_PIN
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
+  if constexpr (EXP >= 6) {
+    // Row-contiguous epilogue: an accumulator fragment holds 4 columns of 16 different rows per 16 lanes, so storing it
+    // directly writes 32-byte pieces of 16 rows per instruction - measured 27 us per block (a fifth of its lifetime).  Each
+    // wave instead transposes its 128x128 block through its own 32 KiB of the (now dead) stages, 64 rows at a time in fp32
+    // (16-byte chunks XOR-swizzled by the row), and writes whole rows: 256 B (bf16) / 512 B (fp32) contiguous per row.
+    __builtin_amdgcn_s_barrier();                       // every wave has read its last fragments out of the stages
+    char* stg = smem + wave * 32768;
+    const int ncol0 = n0 + wc * 128;
+    auto half = [&](auto HF, auto MD_) {
+      constexpr int hf = decltype(HF)::value, md = decltype(MD_)::value;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + frow;
-    if (m >= p.M) continue;
+      for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      epilogue4(p, m, n0 + wc * 128 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        for (int j = 0; j < 8; ++j) {
+          const f32x4_t a = acc[hf * 4 + i4][j];
+          float v[4] = {a[0], a[1], a[2], a[3]};
+          epi_pre4<md>(p, ncol0 + j * 16 + fchk * 4, v);
+          *(float4*)(stg + (i4 * 16 + frow) * 512 + (((j * 4 + fchk) ^ frow) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mbase = m0 + wr * 128 + hf * 64;
+      if (p.out_f32) {
+#pragma unroll 4
+        for (int ps = 0; ps < 32; ++ps) {
+          const int row = ps * 2 + (lane >> 5), c = lane & 31, m = mbase + row, n = ncol0 + c * 4;
+          float4 v = *(const float4*)(stg + row * 512 + ((c ^ (row & 15)) << 4));
+          if (m < p.M && !(diag & 1)) {
+            if (p.R) {
+              if (p.r_f32) {
+                const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+              } else {
+                const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+                v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+                v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+              }
+            }
+            *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+          const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mbase + row, n = ncol0 + g * 8;
+          const float4 lo = *(const float4*)(stg + row * 512 + (((2 * g) ^ (row & 15)) << 4));
+          const float4 hi = *(const float4*)(stg + row * 512 + (((2 * g + 1) ^ (row & 15)) << 4));
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          if (m < p.M && !(diag & 1)) {
+            if (p.R) {
+              if (p.r_f32) {
+                const float4 r0 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+                const float4 r1 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n + 4);
+                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+              } else {
+                const uint4 r = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+                v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xffff0000u);
+                v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xffff0000u);
+              }
+            }
+            uint4 o;
+            o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+            *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+      if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the second half overwrites the staging rows
+    };
+    epi_dispatch(p, [&](auto MD_) {
+      half(std::integral_constant<int, 0>{}, MD_);
+      half(std::integral_constant<int, 1>{}, MD_);
+    });
+  } else {
+    epi_dispatch(p, [&](auto MD_) {
+      constexpr int md = decltype(MD_)::value;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          epilogue4<md>(p, m, n0 + wc * 128 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    });
+  }
+  if constexpr (EXP == 10) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pe = __builtin_readcyclecounter(), re = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
+      unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
+      o[6] = pe - prof_l1; o[8] = re;
+    }
   }
 }
 
@@ -1081,14 +1267,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p8_kernel(GemmNTArgs p) {
   }
 #undef P8_COMPUTE
 #undef P8_BAR
+  epi_dispatch(p, [&](auto MD_) {
+    constexpr int md = decltype(MD_)::value;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + frow;
-    if (m >= p.M) continue;
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + frow;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue4(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-  }
+      for (int j = 0; j < 4; ++j)
+        epilogue4<md>(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1179,7 +1368,7 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
     for (int w2 = 1; w2 < 8; ++w2) v += *(const f32x4_t*)red[w2][idx][lane];
     const int i = idx / MF, f = idx % MF;
     const int m = f * 16 + r;
-    if (m < p.M) epilogue4(p, m, n0 + i * 16 + c * 4, v[0], v[1], v[2], v[3]);
+    if (m < p.M) epi_dispatch(p, [&](auto MD_) { epilogue4<decltype(MD_)::value>(p, m, n0 + i * 16 + c * 4, v[0], v[1], v[2], v[3]); });
   }
 }
 
@@ -1440,6 +1629,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
@@ -1475,6 +1665,37 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (g_gemm_variant == 17 && pp_tiles > 0) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
+  }
+  if (g_gemm_variant == 27 && pp_tiles > 0) {      // diagnostic: stamped default schedule, summary on stderr (synchronous)
+    if (const char* e = getenv("OPADPO_W4_DIAG")) a.act |= atoi(e) << 9;
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<10>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    if (hipStreamSynchronize(st) != hipSuccess) return hipGetLastError();
+    const int nw = (pp_tiles < W4_PROF_MAX_WG ? pp_tiles : W4_PROF_MAX_WG) * 4;
+    constexpr int PN = W4_PROF_N;
+    std::vector<unsigned long long> h((size_t)nw * PN);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w4_prof), h.size() * 8) != hipSuccess) return hipGetLastError();
+    double cyc = 0, w1 = 0, w2 = 0, rt = 0, tiles = 0, pro = 0, epi = 0, life = 0, p1 = 0, p23 = 0, p4 = 0;
+    for (int i = 0; i < nw; ++i) {
+      cyc += h[i * PN]; w1 += h[i * PN + 1]; w2 += h[i * PN + 2]; rt += h[i * PN + 3]; tiles += h[i * PN + 4];
+      pro += h[i * PN + 5]; epi += h[i * PN + 6]; p1 += h[i * PN + 10]; p23 += h[i * PN + 11]; p4 += h[i * PN + 12]; life += (double)(h[i * PN + 8] - h[i * PN + 7]);
+    }
+    // gaps between consecutive workgroups on the same CU (wave 0 records; 100-MHz ticks)
+    std::vector<std::array<unsigned long long, 3>> wg;      // {cu key, start, end}
+    for (int i = 0; i < nw; i += 4) wg.push_back({h[i * PN + 9], h[i * PN + 7], h[i * PN + 8]});
+    std::sort(wg.begin(), wg.end());
+    double gap = 0; int ngap = 0, ncu = 0;
+    unsigned long long t_first = ~0ull, t_last = 0;
+    for (size_t i = 0; i < wg.size(); ++i) {
+      if (i == 0 || wg[i][0] != wg[i - 1][0]) ++ncu;
+      else { gap += (double)wg[i][1] - (double)wg[i - 1][2]; ++ngap; }
+      t_first = std::min(t_first, wg[i][1]); t_last = std::max(t_last, wg[i][2]);
+    }
+    const double mhz = cyc / rt * 100.0;
+    fprintf(stderr, "[w4 prof] M=%d N=%d K=%d blocks=%d on %d CUs, clock %.0f MHz | per K-tile %.0f cycles (MFMA floor 2048), wait1 %.0f, wait2 %.0f; P1 (40 MFMA + 16 LDS reads) %.0f, P2+P3 (60 MFMA + 13 DMA) %.0f, P4 (28 MFMA + 16 reads + 3 DMA) %.0f"
+            " | per block: prologue %.2f us, K-loop %.2f us, epilogue %.2f us, lifetime %.2f us, gap to next block on the CU %.2f us | span %.1f us\n",
+            a.M, a.N, a.K1 + a.K2, nw / 4, ncu, mhz, cyc / tiles, w1 / tiles, w2 / tiles, p1 / tiles, p23 / tiles, p4 / tiles, pro / nw / mhz, cyc / nw / mhz, epi / nw / mhz,
+            life / nw / 100.0, ngap ? gap / ngap / 100.0 : 0.0, (double)(t_last - t_first) / 100.0);
+    return hipSuccess;
   }
   if (g_gemm_variant == 23 && pp_tiles > 0) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
