@@ -789,28 +789,54 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const unsigned lrow = (unsigned)(wave * 64 + srow);                     // row of this wave's piece 0 inside the 256-row tile
   const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
   const unsigned m_last = (unsigned)(p.M - 1);
-  // q = 0..7: A pieces (8 rows x 128 B each) wave*8 + q, q = 8..15: B pieces
+  // q = 0..7: A pieces (8 rows x 128 B each) wave*8 + q, q = 8..15: B pieces.  No vector ALU work per piece: the 16 per-lane
+  // byte offsets sit in registers (recomputed only where the K-concatenated tail switches operands), the K position is the
+  // scalar offset, the descriptor is chosen per tile on the scalar unit (the vendor library's hand-written kernel of this
+  // geometry does the same; a v_mad_u64_u32 per piece between two MFMAs is a quarter-rate instruction in an in-order wave).
+  unsigned voff[16];
+  auto set_voff = [&](bool second, int which = 0) {      // which: 0 = A and B pieces, 1 = A only, 2 = B only
+    const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi) {
+      if (which != 2) voff[pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
+      if (which != 1) voff[8 + pi] = ((unsigned)n0 + lrow + pi * 8u) * ldb + csw[pi & 1];
+    }
+  };
   auto issue_piece = [&](int t, int q) {
     const bool second = t >= nt1;
     const int k0 = EXP == 4 ? 0 : (second ? (t - nt1) : t) * P_BK;
     char* base = smem + (t & 1) * P_STAGE;
-    const int pi = q & 7;
-    const int piece = wave * 8 + pi;
+    const int piece = wave * 8 + (q & 7);
     if constexpr (EXP == 3) {
       if (t >= 2) {      // timing experiment: same 1 KiB for every piece -> L1 hits, only the issue cost remains
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(void, base + (q < 8 ? 0 : P_TILE) + piece * 1024), 16, lane * 16, 0, 0, 0);
         return;
       }
     }
+    if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
+  };
+
+  // EXP == 11: operands staged through registers (buffer_load -> VGPR, ds_write_b128 later) instead of LDS-DMA
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4r_t;
+  u32x4r_t G[16];
+  auto load_piece = [&](int t, int q) {
+    const bool second = t >= nt1;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
+    const int pi = q & 7;
     if (q < 8) {
       const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
       const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, row * ld2 + csw[pi & 1], k0 * 2, 0, 0);
+      G[q] = __builtin_amdgcn_raw_buffer_load_b128(second ? rA2 : rA1, row * ld2 + csw[pi & 1], k0 * 2, 0);
     } else {
       const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
       const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)n0 + pi * 8u) * ld2 + k0 * 2));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, lrow * ld2 + csw[pi & 1], soff, 0, 0);
+      G[q] = __builtin_amdgcn_raw_buffer_load_b128(second ? rB2 : rB1, lrow * ld2 + csw[pi & 1], soff, 0);
     }
+  };
+  const int g_lds = wave * 8192 + lane * 16;
+  auto store_piece = [&](int t, int q) {
+    *(u32x4r_t*)(smem + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + g_lds + (q & 7) * 1024) = G[q];
   };
 
   f32x4_t acc[8][8];
@@ -844,6 +870,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   auto tile_body = [&](int t, auto ISSUE_B, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool issue_b = decltype(ISSUE_B)::value, has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
     // ---- sub-step 0: set 0 in registers; stream set 1 of this tile out of LDS, finish the DMA of tile t+1
+    if constexpr (issue_b) { if (t + 1 == nt1) { set_voff(true, 2); W4_PIN(); } }
 #pragma unroll
     for (int g4 = 0; g4 < 16; ++g4) {
       mfma_run(0, g4 * 4, 4);
@@ -861,6 +888,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     }
     W4_PIN();
     // ---- second half: set 0 of the next tile, first DMA pieces of tile t+2 (its stage is the one just retired)
+    if constexpr (has_next2) { if (t + 2 == nt1) { set_voff(true, 1); W4_PIN(); } }
 #pragma unroll
     for (int g4 = 0; g4 < 8; ++g4) {
       mfma_run(1, 32 + g4 * 4, 4);
@@ -902,6 +930,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
       if constexpr (EXP == 10) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
+      if (t + 2 == nt1) { set_voff(true); W4_PIN(); }
     }
     // ---- P2/P3: MFMAs B1..99 (kk = 0 up to 63, then kk = 1), 13 DMA pieces of tile t+2, one per DSTEP MFMAs
     {
@@ -944,16 +973,95 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     W4_PIN();
     if constexpr (EXP == 10 && has_next) { prof_p4 += __builtin_readcyclecounter() - prof_tb; W4_PIN(); }
   };
+  // EXP == 11 (variant 28): register-staged operands, ONE barrier per K-tile.  A buffer_load into VGPRs costs the MFMA
+  // stream ~3 cycles and a ds_write_b128 ~2, an LDS-DMA instruction ~35 (tools/micro/mfma_dma.hip), so the 16 pieces per wave
+  // and tile cost ~80 instead of ~560 cycles; the price is 64 VGPRs of in-flight data and a lead of exactly one tile:
+  //   P1: 40 MFMAs(kk=0) | 16 reads set1(t)          | lgkmcnt(0), barrier: stage t&1 is dead AND every wave's ds_writes of
+  //                                                     tile t+1 (issued during tile t-1) are complete
+  //   P2-P4: 88 MFMAs | 16 x { ds_write piece q of tile t+2 (loaded during tile t-1) ; buffer_load piece q of tile t+3 }
+  //   P4 also: 16 reads set0(t+1)
+  auto tile_body_rs = [&](int t, auto HAS_NEXT, auto HAS_NEXT2, auto HAS_NEXT3) {
+    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value, has_next3 = decltype(HAS_NEXT3)::value;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      mfma_run(0, g * 2, 2);
+      W4_PIN();
+      read_frag(t, 1, g);
+      W4_PIN();
+    }
+    mfma_run(0, 32, 8);
+    W4_PIN();
+    if constexpr (has_next) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      W4_PIN();
+    }
+    // MFMAs 40..99: 13 pieces, one per 4 MFMAs from MFMA 44 on
+#pragma unroll
+    for (int m = 0; m < 60; ++m) {
+      const int gi = 40 + m;
+      mfma_run(gi >> 6, gi & 63, 1);
+      if ((m + 1) % 4 == 0 && (m + 1) / 4 <= 13) {
+        const int q = (m + 1) / 4 - 1;
+        W4_PIN();
+        if constexpr (has_next2) store_piece(t + 2, q);
+        W4_PIN();
+        if constexpr (has_next3) load_piece(t + 3, q);
+        W4_PIN();
+      }
+    }
+    W4_PIN();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      mfma_run(1, 36 + g * 3, 2);
+      W4_PIN();
+      if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
+      W4_PIN();
+      mfma_run(1, 36 + g * 3 + 2, 1);
+      W4_PIN();
+      if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
+      if (g == 1 || g == 4 || g == 7) {
+        const int q = 13 + (g - 1) / 3;
+        W4_PIN();
+        if constexpr (has_next2) store_piece(t + 2, q);
+        W4_PIN();
+        if constexpr (has_next3) load_piece(t + 3, q);
+      }
+      W4_PIN();
+    }
+    mfma_run(1, 60, 4);
+    W4_PIN();
+  };
   using T_ = std::true_type; using F_ = std::false_type;
 
+  if constexpr (EXP == 11) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) issue_piece(0, q);
-  if (nt > 1) {
+    for (int q = 0; q < 16; ++q) load_piece(0, q);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) issue_piece(1, q);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    for (int q = 0; q < 16; ++q) store_piece(0, q);
+    if (nt > 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) load_piece(1, q);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) store_piece(1, q);
+    }
+    if (nt > 2) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) load_piece(2, q);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    set_voff(false);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(0, q);
+    if (nt > 1) {
+      if (nt1 == 1) set_voff(true);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) issue_piece(1, q);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __builtin_amdgcn_s_barrier();
   W4_PIN();
@@ -961,7 +1069,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   W4_PIN();
   unsigned long long prof_l1 = 0;
-  if constexpr (EXP >= 6) {
+  if constexpr (EXP == 11) {
+    int t = 0;
+    for (; t + 3 < nt; ++t) tile_body_rs(t, T_{}, T_{}, T_{});
+    if (t + 2 < nt) { tile_body_rs(t, T_{}, T_{}, F_{}); ++t; }
+    if (t + 1 < nt) { tile_body_rs(t, T_{}, F_{}, F_{}); ++t; }
+    tile_body_rs(t, F_{}, F_{}, F_{});
+  } else if constexpr (EXP >= 6) {
     unsigned long long pt0 = 0, pr0 = 0;
     if constexpr (EXP == 10) { pt0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     int t = 0;
@@ -1087,6 +1201,265 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       o[6] = pe - prof_l1; o[8] = re;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt "w4m" kernel: the w4 geometry and long-lead schedule with v_mfma_f32_32x32x16_bf16 (32 cycles in the matrix pipe
+// instead of 16).  One wave per SIMD issues in order, so an instruction between two MFMAs is free only if it issues within
+// the running MFMA's shadow; measured (tools/micro/mfma_dma.hip): an LDS-DMA instruction costs the 16-cycle MFMA stream ~35
+// cycles, the 32-cycle stream ~19; ds_read_b128 ~1, buffer_load into VGPRs ~3.  Same operand bytes, LDS reads (32 ds_read_b128
+// per tile), accumulator registers (16 x f32x16) and DMA pieces as w4; 64 MFMAs per K-tile:
+//   fragment sets: set s = k-steps 2s, 2s+1 (16 k each): r = 0..15 -> (ks_l = r >> 3; r & 7 < 4: B block, else A block)
+//   P1: 20 MFMAs(set 0) | 16 reads set1(t)                      | lgkmcnt(0), barrier -> the stage of tile t is dead
+//   P2/P3: 30 MFMAs | 13 DMA pieces of tile t+2 (one per 2 MFMAs) | vmcnt(13), barrier -> tile t+1 has landed
+//   P4: 14 MFMAs | 16 reads set0(t+1), 3 DMA pieces
+// Accumulator layout (operands swapped, D[n][m]): lane holds C row (lane & 31) of a 32-row block and, per 32-column block,
+// 4 groups q of 4 consecutive columns q*8 + (lane >> 5)*4.
+// ------------------------------------------------------------------------------------------
+template <bool PROF>
+__global__ __launch_bounds__(256) void gemm_nt_w4m_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int width = GROUP_M * tiles_n;
+  const int group_id = swz / width;
+  const int first_m = group_id * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (swz % width) % gsz;
+  const int tn = (swz % width) / gsz;
+  const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
+
+  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  const bf16_t* a1 = p.A1;
+  if (p.a1_group_n > 0) a1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  const int srow = lane >> 3, spos = lane & 7;
+  auto uni = [](const void* q) -> void* {      // resource bases stated wave-uniform (see gemm_nt_w4_kernel)
+    const unsigned long long v = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(uni(a1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? a2 : a1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const unsigned lrow = (unsigned)(wave * 64 + srow);
+  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  const unsigned m_last = (unsigned)(p.M - 1);
+  auto issue_piece = [&](int t, int q) {      // q = 0..7: A pieces (8 rows x 128 B) wave*8 + q, q = 8..15: B pieces
+    const bool second = t >= nt1;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
+    char* base = smem + (t & 1) * P_STAGE;
+    const int pi = q & 7;
+    const int piece = wave * 8 + pi;
+    if (q < 8) {
+      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
+      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, row * ld2 + csw[pi & 1], k0 * 2, 0, 0);
+    } else {
+      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)n0 + pi * 8u) * ld2 + k0 * 2));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, lrow * ld2 + csw[pi & 1], soff, 0, 0);
+    }
+  };
+
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8_t fa[2][8], fb[2][8];                         // [set][ks_l * 4 + block]
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + frow) * 128;
+  auto read_frag = [&](int t, int s, int r) {
+    const char* st = smem + (t & 1) * P_STAGE;
+    const int ksl = r >> 3, b = r & 3;
+    const int cb = ((((s * 2 + ksl) * 2) + fhalf) ^ fsw) << 4;
+    if ((r & 7) < 4) fb[s][ksl * 4 + b] = *(const bf16x8_t*)(st + offB + b * 4096 + cb);
+    else fa[s][ksl * 4 + b] = *(const bf16x8_t*)(st + offA + b * 4096 + cb);
+  };
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+  // MFMAs idx0..idx0+n-1 of a set (idx = ks_l*16 + i*4 + j), accumulators tied in place
+  auto mfma_run = [&](int s, int idx0, int n) {
+#pragma unroll
+    for (int e = 0; e < n; ++e) {
+      const int idx = idx0 + e, ksl = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[s][ksl * 4 + j]), "v"(fa[s][ksl * 4 + i]));
+    }
+  };
+  unsigned long long prof_w1 = 0, prof_w2 = 0, prof_p1 = 0, prof_p23 = 0, prof_p4 = 0, prof_tb = 0;
+  auto tile_body = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
+    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
+    unsigned long long ts = 0;
+    if constexpr (PROF) { ts = __builtin_readcyclecounter(); W4_PIN(); }
+    // ---- P1: one read of set 1 per MFMA, 4 MFMAs of slack
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      mfma_run(0, g, 1);
+      W4_PIN();
+      read_frag(t, 1, g);
+      W4_PIN();
+    }
+    mfma_run(0, 16, 4);
+    W4_PIN();
+    if constexpr (has_next2) {
+      unsigned long long ta = 0;
+      if constexpr (PROF) { ta = __builtin_readcyclecounter(); W4_PIN(); prof_p1 += ta - ts; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
+      W4_PIN();
+      if constexpr (PROF) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
+    }
+    // ---- P2/P3: MFMAs 20..49, one DMA piece of tile t+2 per 2 MFMAs (13 pieces)
+#pragma unroll
+    for (int m = 0; m < 30; ++m) {
+      const int gi = 20 + m;
+      mfma_run(gi >> 5, gi & 31, 1);
+      if ((m + 1) % 2 == 0 && (m + 1) / 2 <= 13) {
+        W4_PIN();
+        if constexpr (has_next2) issue_piece(t + 2, (m + 1) / 2 - 1);
+        W4_PIN();
+      }
+    }
+    W4_PIN();
+    if constexpr (has_next) {
+      unsigned long long tc = 0;
+      if constexpr (PROF) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) prof_p23 += tc - prof_tb; }
+      if constexpr (has_next2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
+      if constexpr (PROF) { W4_PIN(); prof_tb = __builtin_readcyclecounter(); prof_w2 += prof_tb - tc; }
+    }
+    W4_PIN();
+    // ---- P4: MFMAs 50..63 (set 1, idx 18..31), the 16 reads of set 0 of tile t+1, the last 3 pieces
+#pragma unroll
+    for (int g = 0; g < 14; ++g) {
+      mfma_run(1, 18 + g, 1);
+      W4_PIN();
+      if constexpr (has_next) {
+        read_frag(t + 1, 0, g);
+        if (g < 2) { W4_PIN(); read_frag(t + 1, 0, 14 + g); }
+      }
+      if constexpr (has_next2) { if (g == 4 || g == 8 || g == 12) { W4_PIN(); issue_piece(t + 2, 13 + (g - 4) / 4); } }
+      W4_PIN();
+    }
+    if constexpr (PROF && has_next) { prof_p4 += __builtin_readcyclecounter() - prof_tb; W4_PIN(); }
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+
+#pragma unroll
+  for (int q = 0; q < 16; ++q) issue_piece(0, q);
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(1, q);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  W4_PIN();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
+  W4_PIN();
+  {
+    unsigned long long pt0 = 0, pr0 = 0;
+    if constexpr (PROF) { pt0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+    int t = 0;
+    for (; t + 2 < nt; ++t) tile_body(t, T_{}, T_{});
+    if (t + 1 < nt) { tile_body(t, T_{}, F_{}); ++t; }
+    tile_body(t, F_{}, F_{});
+    if constexpr (PROF) {
+      const unsigned long long pt1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
+      if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
+        unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
+        o[0] = pt1 - pt0; o[1] = prof_w1; o[2] = prof_w2; o[3] = pr1 - pr0; o[4] = (unsigned long long)nt;
+        o[5] = 0; o[6] = 0; o[7] = pr0; o[8] = pr1; o[9] = blockIdx.x;
+        o[10] = prof_p1; o[11] = prof_p23; o[12] = prof_p4;
+      }
+    }
+  }
+#undef W4_PIN
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA (16 passes) -> VALU readers
+  // row-contiguous epilogue through the dead stages (see gemm_nt_w4_kernel): 64 rows x 128 fp32 columns per wave and pass
+  __builtin_amdgcn_s_barrier();
+  char* stg = smem + wave * 32768;
+  const int ncol0 = n0 + wc * 128;
+  auto half = [&](auto HF, auto MD_) {
+    constexpr int hf = decltype(HF)::value, md = decltype(MD_)::value;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x16_t a = acc[hf * 2 + i2][j];
+          float v[4] = {a[q * 4 + 0], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+          const int c = j * 8 + q * 2 + fhalf;
+          epi_pre4<md>(p, ncol0 + c * 4, v);
+          *(float4*)(stg + (i2 * 32 + frow) * 512 + ((c ^ frow) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mbase = m0 + wr * 128 + hf * 64;
+    if (p.out_f32) {
+#pragma unroll 4
+      for (int ps = 0; ps < 32; ++ps) {
+        const int row = ps * 2 + (lane >> 5), c = lane & 31, m = mbase + row, n = ncol0 + c * 4;
+        float4 v = *(const float4*)(stg + row * 512 + ((c ^ (row & 31)) << 4));
+        if (m < p.M) {
+          if (p.R) {
+            if (p.r_f32) {
+              const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            } else {
+              const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+              v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+              v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+            }
+          }
+          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int ps = 0; ps < 16; ++ps) {
+        const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mbase + row, n = ncol0 + g * 8;
+        const float4 lo = *(const float4*)(stg + row * 512 + (((2 * g) ^ (row & 31)) << 4));
+        const float4 hi = *(const float4*)(stg + row * 512 + (((2 * g + 1) ^ (row & 31)) << 4));
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (m < p.M) {
+          if (p.R) {
+            if (p.r_f32) {
+              const float4 r0 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
+              const float4 r1 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n + 4);
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+              const uint4 r = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
+              v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+              v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+              v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xffff0000u);
+              v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xffff0000u);
+            }
+          }
+          uint4 o;
+          o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+          *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        }
+      }
+    }
+    if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  epi_dispatch(p, [&](auto MD_) {
+    half(std::integral_constant<int, 0>{}, MD_);
+    half(std::integral_constant<int, 1>{}, MD_);
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1630,6 +2003,9 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
@@ -1666,9 +2042,13 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (g_gemm_variant == 27 && pp_tiles > 0) {      // diagnostic: stamped default schedule, summary on stderr (synchronous)
-    if (const char* e = getenv("OPADPO_W4_DIAG")) a.act |= atoi(e) << 9;
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<10>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+  if ((g_gemm_variant == 27 || g_gemm_variant == 30) && pp_tiles > 0) {      // diagnostic: stamped schedule (27: w4, 30: w4m), summary on stderr (synchronous)
+    if (g_gemm_variant == 27) {
+      if (const char* e = getenv("OPADPO_W4_DIAG")) a.act |= atoi(e) << 9;
+      hipLaunchKernelGGL(gemm_nt_w4_kernel<10>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    } else {
+      hipLaunchKernelGGL(gemm_nt_w4m_kernel<true>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    }
     if (hipStreamSynchronize(st) != hipSuccess) return hipGetLastError();
     const int nw = (pp_tiles < W4_PROF_MAX_WG ? pp_tiles : W4_PROF_MAX_WG) * 4;
     constexpr int PN = W4_PROF_N;
@@ -1696,6 +2076,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
             a.M, a.N, a.K1 + a.K2, nw / 4, ncu, mhz, cyc / tiles, w1 / tiles, w2 / tiles, p1 / tiles, p23 / tiles, p4 / tiles, pro / nw / mhz, cyc / nw / mhz, epi / nw / mhz,
             life / nw / 100.0, ngap ? gap / ngap / 100.0 : 0.0, (double)(t_last - t_first) / 100.0);
     return hipSuccess;
+  }
+  if (g_gemm_variant == 29 && pp_tiles > 0) {      // w4 geometry, 32x32x16 MFMA
+    hipLaunchKernelGGL(gemm_nt_w4m_kernel<false>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
+  if (g_gemm_variant == 28 && pp_tiles > 0) {      // register-staged operands, one barrier per K-tile
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<11>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
   }
   if (g_gemm_variant == 23 && pp_tiles > 0) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);

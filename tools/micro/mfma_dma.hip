@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc16[i][j] = 0;
   bf16x8_t sink = a; uint4 vs = {0, 0, 0, 0};
   __syncthreads();
-  const unsigned long long t0 = __builtin_readcyclecounter();
+  const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
     constexpr int N = MODE == 0 ? 64 : 32;       // same MFMA-pipe time per iteration: 1024 cycles
 #pragma unroll
@@ -47,25 +47,27 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
     if constexpr (EVERY > 0 && KIND != 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = sink[0] + (float)vs.x;
   for (int i = 0; i < 16; ++i) s += acc4[i][0];
   for (int i = 0; i < 4; ++i) s += acc16[i][0];
-  if (lane == 0) { out[(blockIdx.x * 4 + wave) * 2] = t1 - t0; out[(blockIdx.x * 4 + wave) * 2 + 1] = (unsigned long long)s; }
+  if (lane == 0) { out[(blockIdx.x * 4 + wave) * 2] = t1 - t0; out[(blockIdx.x * 4 + wave) * 2 + 1] = (r1 - r0) + ((unsigned long long)(s == 12345.f) << 60); }
 }
 
 template <int MODE, int EVERY, int KIND>
 void run(const char* name, const char* src, unsigned long long* out, int blocks) {
-  const int iters = 2000;
+  const int iters = 20000;
   hipFuncSetAttribute((const void*)k<MODE, EVERY, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE, EVERY, KIND>), dim3(blocks), dim3(256), 65536, 0, src, out, iters);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(blocks * 8);
   hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
-  double c = 0; for (int i = 0; i < blocks * 4; ++i) c += h[i * 2];
+  double c = 0, rt = 0; for (int i = 0; i < blocks * 4; ++i) { c += h[i * 2]; rt += h[i * 2 + 1] & 0xffffffffffull; }
+  const double mhz = c / rt * 100.0;
   c /= blocks * 4.0 * iters;
   const int nmem = EVERY ? (MODE == 0 ? 64 : 32) / EVERY : 0;
-  printf("%-44s %7.1f cycles per 1024-cycle MFMA block  (%d mem instr -> %.1f extra cycles each)\n", name, c, nmem, nmem ? (c - 1024.0) / nmem : 0.0);
+  printf("%-44s %7.1f cycles per 1024-cycle MFMA block  (%d mem instr -> %.1f extra cycles each)  clock %.0f MHz -> %.2f PF/s dense-equivalent\n", name, c, nmem,
+         nmem ? (c - 1024.0) / nmem : 0.0, mhz, 1024.0 / c * mhz * 1e6 * 1024 * 1017.0 / 1e15 * (blocks / 256.0 > 1 ? 1 : blocks / 256.0));
 }
 
 int main() {
