@@ -42,12 +42,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // instantiated per mode: with the checks inside epilogue4, every one of its 16-64 inlined copies carried both activation
 // bodies behind branches, the taken branches hopped through ~200 KiB of cold code, and the instruction-cache misses made the
 // epilogue of a 256x256 block take 20-27 us (a fifth of the block's lifetime; measured with s_memtime stamps, variant 27).
-//   0: alpha only   1: + bias   2: (+ bias) quick-GELU   3: (+ bias) GELU
+//   0: alpha only   1: + bias   2: (+ bias) quick-GELU   3: (+ bias) GELU   4: nothing (alpha == 1)
 template <class F>
 __device__ __forceinline__ void epi_dispatch(const GemmNTArgs& p, F&& f) {
   if (p.act == 0) {
-    if (!p.bias) f(std::integral_constant<int, 0>{});
-    else f(std::integral_constant<int, 1>{});
+    if (!p.bias) {
+      if (p.alpha == 1.0f) f(std::integral_constant<int, 4>{});
+      else f(std::integral_constant<int, 0>{});
+    } else {
+      f(std::integral_constant<int, 1>{});
+    }
   } else if (p.act == OPADPO_ACT_QUICK_GELU) {
     f(std::integral_constant<int, 2>{});
   } else {
@@ -55,9 +59,27 @@ __device__ __forceinline__ void epi_dispatch(const GemmNTArgs& p, F&& f) {
   }
 }
 
+// An accumulator that lives in an AGPR tuple (tied there by the inline-asm MFMAs) is copied out with explicit
+// v_accvgpr_read: left to the register allocator, the 64 tuples of the w4 kernels were spilled to scratch around the epilogue.
+__device__ __forceinline__ void acc_read4(const f32x4_t& a, float (&v)[4]) {
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[0]) : "a"(a[0]));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[1]) : "a"(a[1]));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[2]) : "a"(a[2]));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(a[3]));
+}
+
+// the w4 kernels take only bias-free, activation-free problems (the launcher routes the others to the 8-wave kernel): two
+// epilogue instantiations instead of five keep the hot kernel's code small
+template <class F>
+__device__ __forceinline__ void epi_dispatch_plain(const GemmNTArgs& p, F&& f) {
+  if (p.alpha == 1.0f) f(std::integral_constant<int, 4>{});
+  else f(std::integral_constant<int, 0>{});
+}
+
 // alpha, bias and activation of 4 consecutive output columns n..n+3
 template <int MD>
 __device__ __forceinline__ void epi_pre4(const GemmNTArgs& p, int n, float (&v)[4]) {
+  if (MD == 4) return;
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
   if (MD == 1 || (MD >= 2 && p.bias)) {
@@ -748,14 +770,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   unsigned long long prof_e0 = 0, prof_r0 = 0;
   int diag = 0;
   if constexpr (EXP == 10) {
-    diag = p.act >> 9; p.act &= 0xff;      // diagnostics: bit 0 = skip the stores, bits 1.. = first-round stagger in units of 4 us
+    diag = p.act >> 9; p.act &= 0xff;      // diagnostics: bit 0 = skip the stores of the staged epilogue, bit 1 = direct (fragment-layout) epilogue
     prof_e0 = __builtin_readcyclecounter(); prof_r0 = __builtin_amdgcn_s_memrealtime();
-    const int stag = diag >> 1;
-    if (stag > 0 && blockIdx.x < 256) {
-      const unsigned long long until = prof_r0 + (unsigned long long)((blockIdx.x * 37) & 255) * (unsigned)stag * 400ull / 256ull;
-      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-      prof_e0 = __builtin_readcyclecounter();
-    }
   }
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
@@ -1107,7 +1123,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   }
 #undef W4_PIN
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
-  if constexpr (EXP >= 6) {
+  __builtin_amdgcn_sched_barrier(0);                                             // ... and no accumulator read may be scheduled above them
+  auto staged_epi = [&]() {
     // Row-contiguous epilogue: an accumulator fragment holds 4 columns of 16 different rows per 16 lanes, so storing it
     // directly writes 32-byte pieces of 16 rows per instruction - measured 27 us per block (a fifth of its lifetime).  Each
     // wave instead transposes its 128x128 block through its own 32 KiB of the (now dead) stages, 64 rows at a time in fp32
@@ -1118,14 +1135,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     auto half = [&](auto HF, auto MD_) {
       constexpr int hf = decltype(HF)::value, md = decltype(MD_)::value;
 #pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4)
+      for (int i4 = 0; i4 < 4; ++i4) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const f32x4_t a = acc[hf * 4 + i4][j];
-          float v[4] = {a[0], a[1], a[2], a[3]};
+          float v[4];
+          acc_read4(acc[hf * 4 + i4][j], v);
           epi_pre4<md>(p, ncol0 + j * 16 + fchk * 4, v);
           *(float4*)(stg + (i4 * 16 + frow) * 512 + (((j * 4 + fchk) ^ frow) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int mbase = m0 + wr * 128 + hf * 64;
       if (p.out_f32) {
@@ -1176,12 +1195,42 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       }
       if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the second half overwrites the staging rows
     };
-    epi_dispatch(p, [&](auto MD_) {
+    if (!p.out_f32 && !p.R) {
+      // bf16 result without residual: the whole 128x128 block fits the wave's 32 KiB as bf16 -> one LDS round trip, half the bytes
+      // (32-byte groups XOR-swizzled by row & 7; 8-byte writes in fragment layout, 16-byte reads along rows)
+      epi_dispatch_plain(p, [&](auto MD_) {
+        constexpr int md = decltype(MD_)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v[4];
+            acc_read4(acc[i][j], v);
+            epi_pre4<md>(p, ncol0 + j * 16 + fchk * 4, v);
+            uint2 o;
+            o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(stg + (i * 16 + frow) * 256 + ((j ^ (frow & 7)) << 5) + fchk * 8) = o;
+          }
+          __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps 8, not 64, accumulators live in VGPRs
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int mb = m0 + wr * 128;
+#pragma unroll 8
+      for (int ps = 0; ps < 32; ++ps) {
+        const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mb + row;
+        const uint4 o = *(const uint4*)(stg + row * 256 + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16);
+        if (m < p.M && !(diag & 1)) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = o;
+      }
+      return;
+    }
+    epi_dispatch_plain(p, [&](auto MD_) {
       half(std::integral_constant<int, 0>{}, MD_);
       half(std::integral_constant<int, 1>{}, MD_);
     });
-  } else {
-    epi_dispatch(p, [&](auto MD_) {
+  };
+  auto direct_epi = [&]() {
+    epi_dispatch_plain(p, [&](auto MD_) {
       constexpr int md = decltype(MD_)::value;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -1192,7 +1241,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           epilogue4<md>(p, m, n0 + wc * 128 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     });
-  }
+  };
+  if constexpr (EXP == 10) { if (diag & 2) direct_epi(); else staged_epi(); }
+  else if constexpr (EXP >= 6) staged_epi();
+  else direct_epi();
   if constexpr (EXP == 10) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long pe = __builtin_readcyclecounter(), re = __builtin_amdgcn_s_memrealtime();
@@ -1456,7 +1508,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4m_kernel(GemmNTArgs p) {
     }
     if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  epi_dispatch(p, [&](auto MD_) {
+  epi_dispatch_plain(p, [&](auto MD_) {
     half(std::integral_constant<int, 0>{}, MD_);
     half(std::integral_constant<int, 1>{}, MD_);
   });
@@ -2029,15 +2081,16 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   const bool off32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
   const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
-  // one 256x256 block per CU and round: below 1.5 rounds the big tile only pays when its last round fills the chip
+  // one 256x256 block per CU and round: below 1.25 rounds the big tile only pays when its last round fills the chip
   // (M = 32362: N = 512 -> 254 blocks, w4 1.10-1.18 PF/s vs 0.75-0.79 for the 128x128 kernel; N = 768 -> 381 blocks = 1.49
-  // rounds, 8-wave p8 0.92 vs 0.84 vs w4 0.81; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
-  const int pp_slots = ((pp_tiles + 255) / 256) * 256;
-  const bool auto_pp = g_gemm_variant == 10 && (pp_tiles >= 384 || (pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88));
-  if (g_gemm_variant == 10 && !auto_pp && pp_tiles >= 320) {
+  // rounds, w4 1.10 vs 0.84; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
+  const bool plain = !a.bias && !a.act;                 // the w4 kernels are instantiated for alpha-only epilogues
+  if (!plain && pp_tiles > 0 && (g_gemm_variant == 10 ? pp_tiles >= 320 : (g_gemm_variant == 16 || (g_gemm_variant >= 18 && g_gemm_variant <= 30 && g_gemm_variant != 17)))) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
+  const int pp_slots = ((pp_tiles + 255) / 256) * 256;
+  const bool auto_pp = g_gemm_variant == 10 && plain && (pp_tiles >= 320 || (pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88));
   if (g_gemm_variant == 17 && pp_tiles > 0) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();

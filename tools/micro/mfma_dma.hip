@@ -14,8 +14,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <int MODE, int EVERY, int KIND>
 __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)0xffffffffu, 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+  i32x4_t rq;
+  rq[0] = __builtin_amdgcn_readfirstlane((int)(unsigned long long)src); rq[1] = __builtin_amdgcn_readfirstlane((int)((unsigned long long)src >> 32));
+  rq[2] = -1; rq[3] = 0x00020000;
   bf16x8_t a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(lane * 0.01f); b[i] = (__bf16)(i * 0.5f); }
   f32x4_t acc4[16]; f32x16_t acc16[4];
@@ -28,6 +32,13 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
     constexpr int N = MODE == 0 ? 64 : 32;       // same MFMA-pipe time per iteration: 1024 cycles
 #pragma unroll
     for (int m = 0; m < N; ++m) {
+      if constexpr (EVERY > 0 && KIND == 3) {
+        if ((m + 2) % EVERY == 0) {       // one MFMA ahead of the DMA: M0 = LDS destination
+          const int q = (m + 2) / EVERY - 1;
+          const unsigned dst = (unsigned)(size_t)LDS_PTR(smem) + wave * 16384 + (q & 15) * 1024;
+          asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory");
+        }
+      }
       if constexpr (MODE == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc4[m & 15]) : "v"(b), "v"(a));
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc16[m & 3]) : "v"(b), "v"(a));
       if constexpr (EVERY > 0) {
@@ -36,6 +47,8 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (KIND == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(smem + wave * 16384 + (q & 15) * 1024), 16, lane * 16, ((it * 16 + q) & 1023) * 1024, 0, 0);
+          else if constexpr (KIND == 3)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(lane * 16), "s"(rq), "s"(((it * 16 + q) & 1023) * 1024) : "memory");
           else if constexpr (KIND == 1)
             sink = *(const bf16x8_t*)(smem + wave * 16384 + (q & 15) * 1024 + lane * 16);
           else
@@ -81,6 +94,8 @@ int main() {
   run<0, 4, 0>("16x16x32 + LDS-DMA every 4 (16 per block)", src, out, B);
   run<1, 4, 0>("32x32x16 + LDS-DMA every 4 (8 per block)", src, out, B);
   run<1, 2, 0>("32x32x16 + LDS-DMA every 2 (16 per block)", src, out, B);
+  run<0, 4, 3>("16x16x32 + LDS-DMA (M0 set 1 MFMA ahead) /4", src, out, B);
+  run<0, 2, 3>("16x16x32 + LDS-DMA (M0 set 1 MFMA ahead) /2", src, out, B);
   run<0, 4, 2>("16x16x32 + buffer_load->VGPR every 4 (16)", src, out, B);
   run<1, 2, 2>("32x32x16 + buffer_load->VGPR every 2 (16)", src, out, B);
   run<0, 2, 1>("16x16x32 + ds_read_b128 every 2 (32)", src, out, B);
