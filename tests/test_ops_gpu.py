@@ -110,6 +110,34 @@ def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
     assert torch.equal(o5, o32)
 
 
+@pytest.mark.parametrize("variant", [10, 23, 17])
+def test_gemm_nt_epilogue_large(L, variant):
+    """Epilogues at a size the auto dispatch sends to the 256x256 kernels (>= 320 blocks, ragged M edge): the 4-wave kernel's
+    row-contiguous staged paths (bf16 one pass; fp32 two passes with fp32 / bf16 residual, alpha != 1) and the routing of
+    bias / activation problems to the 8-wave kernel."""
+    L.set_flags(variant, True)
+    M, N, K = 5000, 4096, 192
+    a, b = rnd(M, K, scale=0.5, seed=1), rnd(N, K, scale=0.5, seed=2)
+    want = a.float() @ b.float().t()
+    bias, res32, resb = rnd(N, seed=3), torch.randn(M, N, device=dev()), rnd(M, N, seed=4)
+    ob = torch.full((M + 3, N), 7.0, dtype=BF, device=dev())
+    L.gemm_nt(a, b, ob[:M])
+    assert relerr(ob[:M], want) < 6e-3 and float((ob[M:].float() - 7.0).abs().max()) == 0.0
+    L.gemm_nt(a, b, ob[:M], residual=resb, alpha=0.5)
+    assert relerr(ob[:M], 0.5 * want + resb.float()) < 6e-3
+    o32 = torch.empty(M, N, device=dev())
+    L.gemm_nt(a, b, o32, residual=res32)
+    assert relerr(o32, want + res32) < 1e-5
+    L.gemm_nt(a, b, o32, residual=resb, alpha=0.25)
+    assert relerr(o32, 0.25 * want + resb.float()) < 1e-5
+    L.gemm_nt(a, b, o32, bias=bias, residual=res32, alpha=0.25, act=1)
+    v = 0.25 * want + bias.float()
+    assert relerr(o32, v * torch.sigmoid(1.702 * v) + res32) < 1e-5
+    L.gemm_nt(a, b, ob[:M], bias=bias, act=2)
+    assert relerr(ob[:M], torch.nn.functional.gelu(want + bias.float())) < 6e-3
+    L.set_flags(10, True)
+
+
 def test_gemm_nt_256_kernels_race_screen(L):
     """The three 256x256 kernels (ping-pong 8, 4-wave 16, 4-phase 17 = default for large GEMMs) accumulate every output in
     the same k order, so their results must be BIT-identical; repeated on a shape with many K-tiles, a LoRA tail, a ragged M
@@ -134,7 +162,7 @@ def test_gemm_nt_256_kernels_race_screen(L):
     assert relerr(outs[17], want) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9, 16, 17])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9, 16, 17, 23, 10])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):
     L.set_flags(variant, True)
