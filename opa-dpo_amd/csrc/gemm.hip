@@ -928,7 +928,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
     unsigned long long ts = 0;
     if constexpr (EXP == 10) { ts = __builtin_readcyclecounter(); W4_PIN(); }
-    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10 || EXP == 7) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    constexpr bool WM = EXP != 7;            // one MFMA between each s_waitcnt and its s_barrier (EXP 7 = without, for A/B)
     // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -937,22 +938,26 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       read_frag(t, 1, g);
       W4_PIN();
     }
-    mfma_run(0, R1, B1 - R1);
+    mfma_run(0, R1, B1 - R1 - (WM ? 1 : 0));
     W4_PIN();
     if constexpr (has_next2) {
       unsigned long long ta = 0;
       if constexpr (EXP == 10) { ta = __builtin_readcyclecounter(); W4_PIN(); prof_p1 += ta - ts; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (WM) { W4_PIN(); mfma_run(0, B1 - 1, 1); W4_PIN(); }
       __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
       if constexpr (EXP == 10) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
       if (t + 2 == nt1) { set_voff(true); W4_PIN(); }
+    } else if constexpr (WM) {
+      mfma_run(0, B1 - 1, 1);
+      W4_PIN();
     }
     // ---- P2/P3: MFMAs B1..99 (kk = 0 up to 63, then kk = 1), 13 DMA pieces of tile t+2, one per DSTEP MFMAs
     {
       constexpr int NM = 100 - B1;             // MFMAs in this span
 #pragma unroll
-      for (int m = 0; m < NM; ++m) {
+      for (int m = 0; m < NM - (WM ? 1 : 0); ++m) {
         const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
         mfma_run(gi >> 6, gi & 63, 1);
         if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
@@ -968,8 +973,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       if constexpr (EXP == 10) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) prof_p23 += tc - prof_tb; }
       if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (WM) { W4_PIN(); mfma_run(1, 35, 1); W4_PIN(); }
       __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
       if constexpr (EXP == 10) { W4_PIN(); prof_tb = __builtin_readcyclecounter(); prof_w2 += prof_tb - tc; }
+    } else if constexpr (WM) {
+      mfma_run(1, 35, 1);
     }
     W4_PIN();
     // ---- P4: 28 MFMAs, the 16 reads of set 0 of tile t+1, the last 3 pieces
