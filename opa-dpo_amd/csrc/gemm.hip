@@ -2027,14 +2027,253 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs p) {
 
 }  // namespace
 
+namespace {
+// 512-byte rows, 16-byte chunks: chunk ^= ((row & 7) << 1) ^ (((row >> 3) & 1) << 3).  A ds_read_b64_tr_b16 half-wave reads rows
+// r..r+3 and r+8..r+11 (two 16-lane transposition groups): the second term moves the second group to the other 32 banks.
+__device__ __forceinline__ int tn3_mask(int row) { return ((row & 7) << 1) ^ (((row >> 3) & 1) << 3); }
+__device__ __forceinline__ int tn3_off(int row, int col) {
+  const int b = col * 2;
+  return row * 512 + ((((b >> 4) ^ tn3_mask(row))) << 4) + (b & 15);
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_tn "w4" kernel: C[N1,N2] (fp32, atomics) += alpha * P[M,N1]^T Q[M,N2] with the geometry of gemm_nt_w4_kernel: 256x256
+// tile, FOUR waves x 128x128 (256 AGPR accumulators tied in place), K-step = 64 rows of M, two 64-KiB LDS stages filled by
+// buffer_load ... lds.  The 128x128 kernel re-reads both operands once per 128-wide slice of the other (dB(gate|up): 5.7 GB
+// through the L2 for 1.45 GB of operands); this tile halves that and feeds each fragment to 8 MFMAs.
+//   LDS image: [64 m][256 cols] per operand (512-byte rows, chunk swizzle tn3_mask on the per-lane SOURCE address); MFMA
+//     fragments (16 cols x 32 m) come out of it with two ds_read_b64_tr_b16 each (64 per K-step and wave).
+//   Rows past M: the buffer descriptors end at M rows, out-of-range pieces land as zeros.
+//   Work: linear order (K-chunk s of p.splits, tile, K-step inside the chunk) cut into gridDim.x equal contiguous runs (one block
+//     per CU, one round); a run that crosses a tile boundary flushes its accumulators and starts the next tile.  Consecutive runs
+//     are neighbouring tiles over the SAME rows of M, and the block -> run map hands each XCD (blocks are dealt round-robin over
+//     the 8 XCDs) a contiguous range of runs.  Every partial result is an fp32 atomic add.
+//   The LDS-DMA is inline asm: behind the builtin the compiler cannot tell the transposing LDS reads (an intrinsic without alias
+//     information) from the DMA's LDS writes and put s_waitcnt vmcnt(0) in front of them - an HBM round trip per fragment group
+//     (measured 6.9 k cycles per K-step instead of 3.3 k).  The waits for DMA data are the explicit ones of the schedule.
+//   Schedule of one K-step (MFMA index m = 0..127).  The 2 x 32 transposing reads are spread over 40 and 48 MFMAs (32 and 28 in
+//     gemm_nt_w4), the "K-step t+1 has landed" barrier sits at MFMA 80:
+//       m 0..39  : 16 fragments of set 1 (k 32..63 of this step)          | lgkmcnt(0), barrier at 48: the stage is dead
+//       m 48..78 : DMA pieces 0..7 of K-step t+2, one per 4 MFMAs          | vmcnt(8), barrier at 80: K-step t+1 has landed
+//       m 80..127: 16 fragments of set 0 of K-step t+1 (one per 3 MFMAs), DMA pieces 8..15
+//   Measured (M = 32362, one decoder layer's 8 LoRA wgrads): 1.63 ms vs 2.35 ms with the 128x128 kernel; 1.1 PF/s on a 4096^2
+//   output.  PROF = s_memtime stamps (OPADPO_TN_PROF=1), summary on stderr.
+// ------------------------------------------------------------------------------------------
+template <bool PROF>
+__global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n2 = p.N2 / 256, tiles = (p.N1 / 256) * tiles_n2;
+  const int ksteps = (p.M + 63) / 64;
+  const int chunk_len = (ksteps + p.splits - 1) / p.splits;
+  const long long total = (long long)p.splits * tiles * chunk_len;
+  const long long per = (total + gridDim.x - 1) / gridDim.x;
+  const int lrun = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  long long run_s = (long long)lrun * per;
+  const long long run_e = min(total, run_s + per);
+  // per-lane pieces: piece = wave*8 + q holds rows 2*piece, 2*piece + 1 (lane >> 5) of the K-step, 32 chunks of 16 B each
+  const int prow = lane >> 5, pchk = lane & 31;
+  // fragment read offsets: [frag][half] for the P (n1) and Q (n2) side; row = g*8 + (c >> 2) (+4), col = c0 + (c & 3)*4
+  const int fg = lane >> 4, fc = lane & 15;
+  int offP[8][2], offQ[8][2];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = fg * 8 + h * 4 + (fc >> 2);
+      offP[f][h] = tn3_off(row, wr * 128 + f * 16 + (fc & 3) * 4);
+      offQ[f][h] = P_TILE + tn3_off(row, wc * 128 + f * 16 + (fc & 3) * 4);
+    }
+  const int c = lane & 15, g = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
+  unsigned long long pf_loop = 0, pf_w1 = 0, pf_w2 = 0, pf_p1 = 0, pf_p23 = 0, pf_p4 = 0, pf_rt = 0, pf_nt = 0, pf_epi = 0, pf_tb = 0;
+
+  while (run_s < run_e) {
+    const long long cidx = run_s / chunk_len;
+    const int kin = (int)(run_s % chunk_len), sidx = (int)(cidx / tiles), tile = (int)(cidx % tiles);
+    const int seg = (int)min((long long)(chunk_len - kin), run_e - run_s);      // K-steps of this segment inside the padded chunk
+    run_s += seg;
+    const int ks0 = sidx * chunk_len + kin;
+    const int nt = min(seg, ksteps - ks0);                                        // ... that exist (the last chunk is shorter)
+    if (nt <= 0) continue;
+    const int n1_0 = __builtin_amdgcn_readfirstlane((tile / tiles_n2) * 256), n2_0 = __builtin_amdgcn_readfirstlane((tile % tiles_n2) * 256);
+    const int qshift = p.q_group_n1 > 0 ? (n1_0 / p.q_group_n1) * p.q_group_stride : 0;
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    auto mk_rsrc = [&](const void* base, unsigned nrec) {
+      const unsigned long long v = (unsigned long long)base;
+      i32x4_t r;
+      r[0] = __builtin_amdgcn_readfirstlane((int)v); r[1] = __builtin_amdgcn_readfirstlane((int)((v >> 32) & 0xffffu));
+      r[2] = __builtin_amdgcn_readfirstlane((int)nrec); r[3] = 0x00020000;
+      return r;
+    };
+    const i32x4_t rP = mk_rsrc(p.P, (unsigned)p.M * (unsigned)p.ldp * 2u);
+    const i32x4_t rQ = mk_rsrc(p.Q + qshift, (unsigned)p.M * (unsigned)p.ldq * 2u - (unsigned)qshift * 2u);
+    unsigned voff[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = (wave * 8 + q) * 2 + prow;                         // row of the K-step
+      const int sc = pchk ^ tn3_mask(r);                               // source chunk that lands at LDS chunk pchk
+      voff[q] = (unsigned)r * (unsigned)p.ldp * 2u + (unsigned)(n1_0 + sc * 8) * 2u;
+      voff[8 + q] = (unsigned)r * (unsigned)p.ldq * 2u + (unsigned)(n2_0 + sc * 8) * 2u;
+    }
+    const unsigned stepP = 64u * (unsigned)p.ldp * 2u, stepQ = 64u * (unsigned)p.ldq * 2u;
+    auto issue_piece = [&](int t, int q) {      // K-step t of this run; q = 0..7: P pieces, 8..15: Q pieces
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ks0 + t) * (q < 8 ? stepP : stepQ)));
+      if (q < 8) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(rP), "s"(soff), "s"(dst) : "memory");
+      else asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(rQ), "s"(soff), "s"(dst) : "memory");
+    };
+
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa[2][8], fb[2][8];
+    // fragment r of set kk (m 32*kk..) of K-step t: r = 0..7 -> Q fragments, 8..15 -> P fragments.  The two 64-bit halves are
+    // joined as a register sequence (a union would be assembled with moves right behind the loads).
+    auto read_frag = [&](int t, int kk, int r) {
+      const char* st = smem + (t & 1) * P_STAGE + kk * (32 * 512);
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const int o0 = r < 8 ? offQ[r][0] : offP[r - 8][0], o1 = r < 8 ? offQ[r][1] : offP[r - 8][1];
+      const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, st + o0));
+      const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, st + o1));
+      const bf16x8_t v = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      if (r < 8) fb[kk][r] = v;
+      else fa[kk][r - 8] = v;
+    };
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto mfma_run = [&](int kk, int idx0, int n) {      // idx = i*8 + j
+#pragma unroll
+      for (int e = 0; e < n; ++e) {
+        const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
+      }
+    };
+    auto tile_body = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
+      constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
+      unsigned long long ts = 0, ta = 0, tc = 0;
+      if constexpr (PROF) { ts = __builtin_readcyclecounter(); W4_PIN(); }
+      // m 0..39: the 16 fragments of set 1, one per 2 / 3 MFMAs
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) {
+        mfma_run(0, (g2 * 5) / 2, ((g2 + 1) * 5) / 2 - (g2 * 5) / 2);
+        W4_PIN();
+        read_frag(t, 1, g2);
+        W4_PIN();
+      }
+      mfma_run(0, 40, 7);
+      W4_PIN();
+      if constexpr (has_next2) {
+        if constexpr (PROF) { ta = __builtin_readcyclecounter(); W4_PIN(); pf_p1 += ta - ts; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_PIN(); mfma_run(0, 47, 1); W4_PIN();
+        __builtin_amdgcn_s_barrier();            // the stage of K-step t is dead: it takes K-step t+2
+        W4_PIN();
+        if constexpr (PROF) { pf_tb = __builtin_readcyclecounter(); pf_w1 += pf_tb - ta; W4_PIN(); }
+      } else {
+        mfma_run(0, 47, 1);
+        W4_PIN();
+      }
+      // m 48..78: DMA pieces 0..7 of K-step t+2, one per 4 MFMAs (after m = 50, 54, ... 78)
+#pragma unroll
+      for (int m = 48; m < 79; ++m) {
+        mfma_run(m >> 6, m & 63, 1);
+        if ((m - 48) % 4 == 2) {
+          W4_PIN();
+          if constexpr (has_next2) issue_piece(t + 2, (m - 48) / 4);
+          W4_PIN();
+        }
+      }
+      W4_PIN();
+      if constexpr (has_next) {
+        if constexpr (PROF) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) pf_p23 += tc - pf_tb; }
+        if constexpr (has_next2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces above stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4_PIN(); mfma_run(1, 15, 1); W4_PIN();
+        __builtin_amdgcn_s_barrier();            // K-step t+1 has landed for everyone
+        if constexpr (PROF) { W4_PIN(); pf_tb = __builtin_readcyclecounter(); pf_w2 += pf_tb - tc; }
+      } else {
+        mfma_run(1, 15, 1);
+      }
+      W4_PIN();
+      // m 80..127: the 16 fragments of set 0 of K-step t+1 (one per 3 MFMAs), DMA pieces 8..15 (one per 6)
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) {
+        mfma_run(1, 16 + g2 * 3, 3);
+        W4_PIN();
+        if constexpr (has_next) read_frag(t + 1, 0, g2);
+        if constexpr (has_next2) { if (g2 & 1) { W4_PIN(); issue_piece(t + 2, 8 + (g2 >> 1)); } }
+        W4_PIN();
+      }
+      if constexpr (PROF && has_next) { pf_p4 += __builtin_readcyclecounter() - pf_tb; W4_PIN(); }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(0, q);
+    if (nt > 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) issue_piece(1, q);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    W4_PIN();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
+    W4_PIN();
+    {
+      unsigned long long l0 = 0, r0 = 0;
+      if constexpr (PROF) { l0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+      int t = 0;
+      for (; t + 2 < nt; ++t) tile_body(t, T_{}, T_{});
+      if (t + 1 < nt) { tile_body(t, T_{}, F_{}); ++t; }
+      tile_body(t, F_{}, F_{});
+      if constexpr (PROF) { pf_tb = __builtin_readcyclecounter(); pf_loop += pf_tb - l0; pf_rt += __builtin_amdgcn_s_memrealtime() - r0; pf_nt += nt; }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    W4_PIN();
+#undef W4_PIN
+    // D[i = n1][j = n2]: lane holds col n2 = lane & 15, rows n1 = (lane >> 4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v[4];
+        acc_read4(acc[i][j], v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          atomicAdd(p.C + (size_t)(n1_0 + wr * 128 + i * 16 + g * 4 + q) * p.ldc + n2_0 + wc * 128 + j * 16 + c, v[q] * p.alpha);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();      // the next run segment re-uses the stages
+    if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_epi += __builtin_readcyclecounter() - pf_tb; }
+  }
+  if constexpr (PROF) {
+    if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
+      unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
+      o[0] = pf_loop; o[1] = pf_w1; o[2] = pf_w2; o[3] = pf_rt; o[4] = pf_nt; o[5] = 0; o[6] = pf_epi; o[7] = 0; o[8] = 0; o[9] = blockIdx.x;
+      o[10] = pf_p1; o[11] = pf_p23; o[12] = pf_p4;
+    }
+  }
+}
+}  // namespace
+
 static int g_gemm_variant = 10;   // 0: register staging, 1: LDS-DMA 16x16x32, 2: LDS-DMA 32x32x16, 3: 3-stage ring 128x256, 4: LDS-DMA 16x16x32 + setprio, <=128 VGPR; 5-7: BK=32 experiments; 8/9: 256x256 ping-pong (16x16x32 / 32x32x16); 10 (default): auto 8|4
 static bool g_use_tr = true;
+static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
 static int g_tn_wide = 0;      // use_tr bit 2 set: wide (256 x 128 / 128 x 256) gemm_tn tiles — measured slower overall, see gemm_tn2_kernel
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
   opadpo_set_attn_dma((use_tr & 2) != 0);
   g_tn_wide = (use_tr & 4) != 0;
+  g_tn_w4 = (use_tr & 8) == 0;
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
@@ -2226,6 +2465,40 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
     const int max_splits = (a.M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+  }
+  if (g_tn_w4 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+      attr = true;
+    }
+    GemmTNArgs b = a;
+    const int tiles4 = (a.N1 / 256) * (a.N2 / 256), ksteps = (a.M + 63) / 64;
+    b.splits = (256 + tiles4 - 1) / tiles4;                      // K-chunks: about one run per CU and chunk-tile
+    if (b.splits > ksteps) b.splits = ksteps;
+    const long long total = (long long)b.splits * tiles4 * ((ksteps + b.splits - 1) / b.splits);
+    const dim3 gr((unsigned)(total < 256 ? total : 256));
+    static const bool prof = getenv("OPADPO_TN_PROF") != nullptr;
+    if (!prof) {
+      hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, b);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL(gemm_tn_w4_kernel<true>, gr, dim3(256), 2 * P_STAGE, st, b);      // diagnostic: stamps, summary on stderr
+    if (hipStreamSynchronize(st) != hipSuccess) return hipGetLastError();
+    const int nw = (int)gr.x * 4;
+    std::vector<unsigned long long> h((size_t)nw * W4_PROF_N);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w4_prof), h.size() * 8) != hipSuccess) return hipGetLastError();
+    double cyc = 0, w1 = 0, w2 = 0, rt = 0, nts = 0, epi = 0, p1 = 0, p23 = 0, p4 = 0;
+    for (int i = 0; i < nw; ++i) {
+      const unsigned long long* o = h.data() + (size_t)i * W4_PROF_N;
+      cyc += o[0]; w1 += o[1]; w2 += o[2]; rt += o[3]; nts += o[4]; epi += o[6]; p1 += o[10]; p23 += o[11]; p4 += o[12];
+    }
+    const double mhz = cyc / rt * 100.0;
+    fprintf(stderr, "[tn w4 prof] M=%d N1=%d N2=%d blocks=%d splits=%d clock %.0f MHz | per K-step %.0f cycles (MFMA floor 2048): P1 %.0f wait1 %.0f "
+            "P2+P3 %.0f wait2 %.0f P4 %.0f | per block: K-loops %.1f us, flush (atomics) %.1f us\n", a.M, a.N1, a.N2, (int)gr.x, b.splits, mhz,
+            cyc / nts, p1 / nts, w1 / nts, p23 / nts, w2 / nts, p4 / nts, cyc / nw / mhz, epi / nw / mhz);
+    return hipSuccess;
   }
   const dim3 grid(tiles, splits);
   if (bn2 == 256) {

@@ -207,10 +207,10 @@ def test_gemm_nt_grouped_a1(L, variant):
     assert relerr(out, want) < 6e-3
 
 
-@pytest.mark.parametrize("tr", [1, 0, 5])      # 5 = transposed reads + wide (256-spanning) tiles
+@pytest.mark.parametrize("tr", [1, 9, 0, 13])      # 1 = default (256x256 stream-K kernel where both dims allow), 9 = 128x128 kernel, 13 = wide tiles
 @pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0),
                                             (1100, 512, 256, 0), (1100, 256, 1024, 0), (1300, 768, 256, 3), (2100, 1024, 256, 2),
-                                            (999, 512, 384, 0), (70, 256, 256, 0)])
+                                            (999, 512, 384, 0), (70, 256, 256, 0), (20011, 2048, 256, 0), (9001, 512, 1024, 2)])
 def test_gemm_tn(L, tr, M, N1, N2, groups):
     L.set_flags(True, tr)
     p = rnd(M, N1, seed=1)

@@ -49,7 +49,13 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(smem + wave * 16384 + (q & 15) * 1024), 16, lane * 16, ((it * 16 + q) & 1023) * 1024, 0, 0);
           else if constexpr (KIND == 3)
             asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(lane * 16), "s"(rq), "s"(((it * 16 + q) & 1023) * 1024) : "memory");
-          else if constexpr (KIND == 1)
+          else if constexpr (KIND == 4) {
+            typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+            union { bf16x8_t v; s16x4_t h[2]; } u;
+            u.v = sink;
+            u.h[q & 1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + wave * 16384 + (q & 15) * 1024 + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 64 + (lane & 3) * 8));
+            sink = u.v;
+          } else if constexpr (KIND == 1)
             sink = *(const bf16x8_t*)(smem + wave * 16384 + (q & 15) * 1024 + lane * 16);
           else
             vs = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, ((it * 16 + q) & 1023) * 1024, 0));
@@ -98,6 +104,9 @@ int main() {
   run<0, 2, 3>("16x16x32 + LDS-DMA (M0 set 1 MFMA ahead) /2", src, out, B);
   run<0, 4, 2>("16x16x32 + buffer_load->VGPR every 4 (16)", src, out, B);
   run<1, 2, 2>("32x32x16 + buffer_load->VGPR every 2 (16)", src, out, B);
+  run<0, 1, 4>("16x16x32 + ds_read_b64_tr_b16 every 1 (64)", src, out, B);
+  run<0, 2, 4>("16x16x32 + ds_read_b64_tr_b16 every 2 (32)", src, out, B);
+  run<0, 1, 1>("16x16x32 + ds_read_b128 every 1 (64)", src, out, B);
   run<0, 2, 1>("16x16x32 + ds_read_b128 every 2 (32)", src, out, B);
   run<1, 1, 1>("32x32x16 + ds_read_b128 every 1 (32)", src, out, B);
   return 0;
