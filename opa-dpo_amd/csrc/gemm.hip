@@ -832,6 +832,28 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
   };
+  // EXP == 12: the DMA as two inline-asm halves - M0 (the LDS destination) is written one MFMA AHEAD of the buffer_load, which
+  // costs the MFMA stream 6.5 instead of 10.5 cycles per piece (tools/micro/mfma_dma.hip); nothing between the halves uses M0.
+  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+  auto mk_rsrc = [&](const void* base) {
+    const unsigned long long v = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)v); r[1] = __builtin_amdgcn_readfirstlane((int)((v >> 32) & 0xffffu));
+    r[2] = -1; r[3] = 0x00020000;
+    return r;
+  };
+  const i32x4_t qA1 = mk_rsrc(a1), qB1 = mk_rsrc(p.B1), qA2 = mk_rsrc(nt2 ? a2 : a1), qB2 = mk_rsrc(nt2 ? p.B2 : p.B1);
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
+  auto dma_m0 = [&](int t, int q) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
+    asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory");
+  };
+  auto dma_go = [&](int t, int q) {
+    const bool second = t >= nt1;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? (t - nt1) : t) * P_BK * 2);
+    const i32x4_t r = q < 8 ? (second ? qA2 : qA1) : (second ? qB2 : qB1);
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff) : "memory");
+  };
 
   // EXP == 11: operands staged through registers (buffer_load -> VGPR, ds_write_b128 later) instead of LDS-DMA
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4r_t;
@@ -928,8 +950,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
     unsigned long long ts = 0;
     if constexpr (EXP == 10) { ts = __builtin_readcyclecounter(); W4_PIN(); }
-    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10 || EXP == 7) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
-    constexpr bool WM = EXP != 7;            // one MFMA between each s_waitcnt and its s_barrier (EXP 7 = without, for A/B)
+    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10 || EXP == 7 || EXP == 12) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    constexpr bool WM = EXP != 7;
+    constexpr bool SPLIT = EXP == 12;        // M0 one MFMA ahead of each DMA            // one MFMA between each s_waitcnt and its s_barrier (EXP 7 = without, for A/B)
     // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -960,9 +983,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       for (int m = 0; m < NM - (WM ? 1 : 0); ++m) {
         const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
         mfma_run(gi >> 6, gi & 63, 1);
+        if constexpr (SPLIT && dma) {
+          if ((m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(t + 2, (m + 2) / DSTEP - 1); W4_PIN(); }
+        }
         if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
           W4_PIN();
-          if constexpr (dma) issue_piece(t + 2, (m + 1) / DSTEP - 1);
+          if constexpr (dma) { if constexpr (SPLIT) dma_go(t + 2, (m + 1) / DSTEP - 1); else issue_piece(t + 2, (m + 1) / DSTEP - 1); }
           W4_PIN();
         }
       }
@@ -986,11 +1012,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       mfma_run(1, 36 + g * 3, 2);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
+      if constexpr (SPLIT && dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, 13 + (g - 1) / 3); }
       W4_PIN();
       mfma_run(1, 36 + g * 3 + 2, 1);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) issue_piece(t + 2, 13 + (g - 1) / 3); }
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) { if constexpr (SPLIT) dma_go(t + 2, 13 + (g - 1) / 3); else issue_piece(t + 2, 13 + (g - 1) / 3); } }
       W4_PIN();
     }
     mfma_run(1, 60, 4);
@@ -2303,6 +2330,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
@@ -2332,7 +2360,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // (M = 32362: N = 512 -> 254 blocks, w4 1.10-1.18 PF/s vs 0.75-0.79 for the 128x128 kernel; N = 768 -> 381 blocks = 1.49
   // rounds, w4 1.10 vs 0.84; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
   const bool plain = !a.bias && !a.act;                 // the w4 kernels are instantiated for alpha-only epilogues
-  if (!plain && pp_tiles > 0 && (g_gemm_variant == 10 ? pp_tiles >= 320 : (g_gemm_variant == 16 || (g_gemm_variant >= 18 && g_gemm_variant <= 30 && g_gemm_variant != 17)))) {
+  if (!plain && pp_tiles > 0 && (g_gemm_variant == 10 ? pp_tiles >= 320 : (g_gemm_variant == 16 || (g_gemm_variant >= 18 && g_gemm_variant <= 31 && g_gemm_variant != 17)))) {
     hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
@@ -2377,6 +2405,10 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
             life / nw / 100.0, ngap ? gap / ngap / 100.0 : 0.0, (double)(t_last - t_first) / 100.0);
     return hipSuccess;
   }
+  if (g_gemm_variant == 31 && pp_tiles > 0) {      // long-lead w4 with M0 written one MFMA ahead of each DMA
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if (g_gemm_variant == 29 && pp_tiles > 0) {      // w4 geometry, 32x32x16 MFMA
     hipLaunchKernelGGL(gemm_nt_w4m_kernel<false>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
@@ -2414,8 +2446,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 4>), gr, bl, 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: 4 waves x 128x128, long-lead DMA schedule
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   if ((g_gemm_variant == 8 || g_gemm_variant == 9) && pp_tiles > 0) {

@@ -41,7 +41,7 @@ def maxabs(got, want):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("glds", [29, 28, 23, 17, 16, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize("glds", [31, 29, 28, 23, 17, 16, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize("M,N,K1,K2,groups", [(300, 256, 128, 0, 0), (1, 128, 64, 0, 0), (129, 384, 192, 128, 3),
                                               (1000, 1024, 512, 128, 2), (257, 128, 64, 64, 1), (515, 768, 64, 64, 3),
                                               (2, 256, 4096, 0, 0), (131, 512, 64 * 3, 64, 2), (700, 512, 64, 0, 0), (513, 256, 128, 128, 1)])
@@ -147,7 +147,7 @@ def test_gemm_nt_256_kernels_race_screen(L):
     a2, b2 = rnd(M, K2, seed=13), rnd(N, K2, scale=0.05, seed=14)
     outs = {}
     for rep in range(6):
-        for v in (8, 16, 17, 23, 28, 29, 10):
+        for v in (8, 16, 17, 23, 28, 29, 31, 10):
             L.set_flags(v, True)
             o = torch.empty(M, N, dtype=BF, device=dev())
             L.gemm_nt(a1, b1, o, a2=a2, b2=b2)
