@@ -1251,11 +1251,35 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int mb = m0 + wr * 128;
+      if ((unsigned long long)p.M * (unsigned)p.ldc * 2ull < 0xffffffffull) {
+        // rows through a descriptor that ends after row M-1: 32-bit offsets (one add per row group), no predicate, 8 reads then 8 stores
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(uni(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * 2u), 0x00020000);
+        const int row0 = lane >> 4, g = lane & 15;
+        const unsigned step = 4u * (unsigned)p.ldc * 2u;
+        unsigned vo = (unsigned)(mb + row0) * (unsigned)p.ldc * 2u + (unsigned)(ncol0 + g * 8) * 2u;
+        const char* src = stg + row0 * 256 + (g & 1) * 16;
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+          u32x4s_t o[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int ps = pg * 8 + u;                  // row = ps*4 + row0: row & 7 = (ps & 1)*4 + row0
+            o[u] = *(const u32x4s_t*)(src + ps * 1024 + (((g >> 1) ^ (((ps & 1) << 2) | row0)) << 5));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (!(diag & 1)) __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 0);
+            vo += step;
+          }
+        }
+      } else {
 #pragma unroll 8
-      for (int ps = 0; ps < 32; ++ps) {
-        const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mb + row;
-        const uint4 o = *(const uint4*)(stg + row * 256 + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16);
-        if (m < p.M && !(diag & 1)) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = o;
+        for (int ps = 0; ps < 32; ++ps) {
+          const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mb + row;
+          const uint4 o = *(const uint4*)(stg + row * 256 + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16);
+          if (m < p.M && !(diag & 1)) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = o;
+        }
       }
       return;
     }
