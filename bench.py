@@ -80,7 +80,7 @@ def main():
     # pair and pass (the reference stacks 2 x 1087).  22 pairs = 32362 rows = 127 M-tiles of 256: every big GEMM of the step
     # then covers (almost) a whole number of 256-CU rounds (N=4096: 2032 tiles = 7.94 rounds).  --no-pack: the reference's
     # layout, 15 pairs = 30 x 1087 = 32610 rows = 128 M-tiles.
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 0)), help="pairs per micro-batch per GPU (0: 22 packed / 15 stacked)")
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("OPADPO_BENCH_PAIRS", 0)), help="pairs per micro-batch per GPU (0: 22 packed / 15 stacked; 13b: 12 / 8)")
     ap.add_argument("--no-pack", action="store_true", help="stack chosen / rejected as separate sequences (reference layout)")
     ap.add_argument("--accum", type=int, default=int(os.environ.get("OPADPO_BENCH_ACCUM", 1)), help="micro-batches per optimizer step")
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
@@ -89,7 +89,7 @@ def main():
     args = ap.parse_args()
     pack = not args.no_pack
     if args.pairs <= 0:
-        args.pairs = 22 if pack else 15
+        args.pairs = (22 if pack else 15) if args.model != "13b" else (12 if pack else 8)      # 13B: activations of 12 packed pairs fit the 288 GB
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
