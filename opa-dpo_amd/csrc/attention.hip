@@ -457,17 +457,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     }
     // block-uniform: every (q, key) of this tile pair is visible -> no mask arithmetic
     const bool clean = keys_clean && q0 + 63 < L && (!p.causal || k0 + 63 <= q0) && q0 + 63 < kend_min;
+    if (clean) {          // straight-line: 16 independent exp chains the scheduler can interleave with the MFMAs
 #pragma unroll
-    for (int qf = 0; qf < 4; ++qf)
+      for (int qf = 0; qf < 4; ++qf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = qf * 16 + g * 4 + r;
-        const int qp = q0 + ql;
-        const bool ok = clean || (key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend);
-        const float pv = ok ? fast_exp2(sc[qf][r] * scale2 - lse_s[ql]) : 0.f;
-        sc[qf][r] = pv;
-        dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qf * 16 + g * 4 + r;
+          const float pv = fast_exp2(sc[qf][r] * scale2 - lse_s[ql]);
+          sc[qf][r] = pv;
+          dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
+        }
+    } else {              // masked pairs: exp2(-inf) = 0 through a select, not a branch per element
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = qf * 16 + g * 4 + r;
+          const int qp = q0 + ql;
+          const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend;
+          const float pv = fast_exp2(ok ? sc[qf][r] * scale2 - lse_s[ql] : -INFINITY);
+          sc[qf][r] = pv;
+          dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
+        }
+    }
     // dV^T[d][key] += dO^T . P ; dK^T[d][key] += Q^T . dS   (contraction over the 64 q rows)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           const int kl = kf * 16 + g * 4 + r;
           const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
-          const float pv = ok ? fast_exp2(sc[kf][r] * scale2 - lse2) : 0.f;
+          const float pv = fast_exp2(ok ? sc[kf][r] * scale2 - lse2 : -INFINITY);
           dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
         }
     }
