@@ -35,7 +35,8 @@ const char* opadpo_last_error(void);
 /* kernel-variant switches (diagnostics): use_glds = gemm_nt variant (0 register staging, 1 global_load_lds
  * staging + 16x16x32 MFMA, 2 global_load_lds + 32x32x16 MFMA, ..., 10 = auto (default)); use_tr bit 0 =
  * ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 = attention forward through a direct-to-LDS
- * double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks per CU), bit 2 = wide gemm_tn tiles. */
+ * double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks per CU), bit 2 = wide gemm_tn tiles,
+ * bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one. */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------

@@ -752,8 +752,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
 // stage released after the 16 set-1 reads, DMA of tile t+2 waited with vmcnt(13) three quarters into tile t+1) is the fastest
 // kernel here: 1.33-1.38 PF/s on 8192^3, 1.25-1.30 on the training shapes -> DEFAULT for large GEMMs.  SQ counters on the
 // cubes (quad-cycles per launch set): single-barrier w4 244 M (24 % parked in s_waitcnt / s_barrier), long lead 228 M (21 %),
-// p8 2 x 245 M, vendor asm kernel 165 M (5 %); removing any ONE of its waits (racy diagnostics 24-26) gives +4.5 % each.
-// Variant 16 = single-barrier schedule, 18-21 / 24-26 = timing diagnostics (wrong results / racy).
+// p8 2 x 245 M, vendor asm kernel 165 M (5 %); removing any ONE of its waits (racy diagnostics, since deleted) gave +4.5 % each, and
+// timing-only variants (no in-loop DMA / no fragment reads / every K-tile re-reading k = 0) gave the 1.56-1.68 and 1.40-1.46 figures above.
+// Variant 16 = single-barrier schedule, 23 / 24 = long lead with the builtin DMA (with / without the MFMA between wait and barrier).
 // ------------------------------------------------------------------------------------------
 // EXP == 10 (variant 27, diagnostic): the default schedule with s_memtime stamps around its two wait points; per wave
 // {cycles in the K-loop, cycles parked at wait 1 (lgkmcnt + barrier), at wait 2 (vmcnt + barrier), 100-MHz ticks, K-tiles}
@@ -761,7 +762,8 @@ constexpr int W4_PROF_MAX_WG = 4096;
 constexpr int W4_PROF_N = 13;
 __device__ unsigned long long g_w4_prof[W4_PROF_MAX_WG * 4 * W4_PROF_N];
 
-template <int EXP>   // EXP (diagnostics, wrong results): 1 = no DMA in the K-loop, 2 = no LDS fragment reads in the K-loop
+template <int EXP>   // 0: single-barrier schedule, 6: long lead (builtin DMA), 7: 6 without the MFMA between wait and barrier, 10: stamped 6 (variant 27),
+                     // 11: register-staged operands (variant 28), 12: long lead with the DMA as two asm halves (variant 31, DEFAULT)
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -820,15 +822,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   };
   auto issue_piece = [&](int t, int q) {
     const bool second = t >= nt1;
-    const int k0 = EXP == 4 ? 0 : (second ? (t - nt1) : t) * P_BK;
+    const int k0 = (second ? (t - nt1) : t) * P_BK;
     char* base = smem + (t & 1) * P_STAGE;
     const int piece = wave * 8 + (q & 7);
-    if constexpr (EXP == 3) {
-      if (t >= 2) {      // timing experiment: same 1 KiB for every piece -> L1 hits, only the issue cost remains
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB1, LDS_PTR(void, base + (q < 8 ? 0 : P_TILE) + piece * 1024), 16, lane * 16, 0, 0, 0);
-        return;
-      }
-    }
     if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
   };
@@ -913,8 +909,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     for (int g4 = 0; g4 < 16; ++g4) {
       mfma_run(0, g4 * 4, 4);
       W4_PIN();
-      if constexpr (EXP != 2) read_frag(t, 1, g4);
-      if constexpr (issue_b && EXP != 1) { if (g4 < 8) issue_piece(t + 1, 8 + g4); }
+      read_frag(t, 1, g4);
+      if constexpr (issue_b) { if (g4 < 8) issue_piece(t + 1, 8 + g4); }
       W4_PIN();
     }
     // ---- sub-step 1, first half
@@ -931,8 +927,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     for (int g4 = 0; g4 < 8; ++g4) {
       mfma_run(1, 32 + g4 * 4, 4);
       W4_PIN();
-      if constexpr (has_next && EXP != 2) { read_frag(t + 1, 0, 2 * g4); read_frag(t + 1, 0, 2 * g4 + 1); }
-      if constexpr (has_next2 && EXP != 1) issue_piece(t + 2, g4);
+      if constexpr (has_next) { read_frag(t + 1, 0, 2 * g4); read_frag(t + 1, 0, 2 * g4 + 1); }
+      if constexpr (has_next2) issue_piece(t + 2, g4);
       W4_PIN();
     }
   };
@@ -950,7 +946,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
     unsigned long long ts = 0;
     if constexpr (EXP == 10) { ts = __builtin_readcyclecounter(); W4_PIN(); }
-    constexpr int R1 = EXP == 8 ? 16 : ((EXP == 6 || EXP == 10 || EXP == 7 || EXP == 12) ? 32 : 24), B1 = EXP == 8 ? 32 : 40, DSTEP = EXP == 9 ? 3 : 4;
+    constexpr int R1 = 32, B1 = 40, DSTEP = 4;
     constexpr bool WM = EXP != 7;
     constexpr bool SPLIT = EXP == 12;        // M0 one MFMA ahead of each DMA            // one MFMA between each s_waitcnt and its s_barrier (EXP 7 = without, for A/B)
     // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
@@ -2344,14 +2340,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     PP_ATTR(false); PP_ATTR(true); PP_ATTR(false, false); PP_ATTR(false, true, false); PP_ATTR(false, true, true, 16); PP_ATTR(false, true, true, 4);
 #undef PP_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
@@ -2445,17 +2435,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (g_gemm_variant >= 24 && g_gemm_variant <= 26 && pp_tiles > 0) {      // timing diagnostics (racy): a wait / barrier removed
-    if (g_gemm_variant == 24) hipLaunchKernelGGL(gemm_nt_w4_kernel<7>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    else if (g_gemm_variant == 25) hipLaunchKernelGGL(gemm_nt_w4_kernel<8>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    else hipLaunchKernelGGL(gemm_nt_w4_kernel<9>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if ((g_gemm_variant >= 18 && g_gemm_variant <= 21) && pp_tiles > 0) {      // timing experiments only (wrong results)
-    if (g_gemm_variant == 21) { hipLaunchKernelGGL(gemm_nt_w4_kernel<4>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a); return hipGetLastError(); }
-    if (g_gemm_variant == 20) hipLaunchKernelGGL(gemm_nt_w4_kernel<3>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    else if (g_gemm_variant == 18) hipLaunchKernelGGL(gemm_nt_w4_kernel<1>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    else hipLaunchKernelGGL(gemm_nt_w4_kernel<2>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+  if (g_gemm_variant == 24 && pp_tiles > 0) {      // long-lead schedule without the MFMA between s_waitcnt and s_barrier (A/B)
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<7>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   if (g_gemm_variant == 16 && pp_tiles > 0) {
