@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
     args = ap.parse_args()
     pack = not args.no_pack
     if args.pairs <= 0:
@@ -105,7 +106,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from opadpo_amd import lib as L
-    from opadpo_amd.dims import LlavaDims, pair_flops, pair_flops_packed
+    from opadpo_amd.dims import LlavaDims, lora_param_count, pair_flops, pair_flops_packed
     from opadpo_amd.losses import DPOArgs, pair_loss
     from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
     from opadpo_amd.optim import FlatAdamW
@@ -121,6 +122,8 @@ def main():
     eng = LlavaEngine(base)
     pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
+    if not args.no_merge_ref:      # frozen adapter: s*B@A folded once into a second bf16 copy of the projections (PEFT-style merge)
+        ref_ad.merge_into_base(base)
     torch.cuda.empty_cache()
     policy = AutoregressivePolicy(eng, pol_ad, t_len, pack_responses=pack)
     ref_policy = AutoregressivePolicy(eng, ref_ad, t_len, pack_responses=pack)
@@ -167,7 +170,8 @@ def main():
     value = pairs_per_step * args.steps / dt
     if rank == 0:
         fl_ref = pair_flops(d, q_len, t_len)                      # reference formulation: 4 full sequences per pair
-        fl = pair_flops_packed(d, q_len, t_len, 2) if pack else fl_ref     # what this run executes
+        merged = not args.no_merge_ref
+        fl = pair_flops_packed(d, q_len, t_len, 2, ref_merged=merged) if pack else fl_ref - (2 * 2 * lora_param_count(d) * (q_len + t_len + d.n_patches - 1) if merged else 0)     # what this run executes
         roof = None
         if prof:
             tot_f = sum(p[0] for p in prof)
@@ -185,6 +189,8 @@ def main():
                           "response_layout": ("packed: chosen+rejected share one pass over the image+query prefix (segment-masked attention), "
                                               f"{q_len + d.n_patches - 1}+2x{t_len} positions per pair and pass" if pack else
                                               f"stacked: 2 x {q_len + t_len + d.n_patches - 1} positions per pair and pass (reference layout)"),
+                          "reference_adapter": ("frozen adapter merged into a second bf16 copy of the LLM projections at load (no LoRA GEMMs in the no-grad pass)"
+                                                if not args.no_merge_ref else "unmerged (K-concatenated LoRA in the no-grad pass)"),
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
                           "global_pairs_per_step": pairs_per_step, "seq_len": q_len + t_len,
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),

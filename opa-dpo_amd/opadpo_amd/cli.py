@@ -43,7 +43,7 @@ FLAGS = [
     ("base_model_name", str, "./base_models/llava-v1.5-7b"), ("vision_tower", str, "different"), ("mm_vision_select_layer", int, -2),
     ("mm_use_im_start_end", "st", None), ("mm_use_im_patch_token", "st", None), ("freeze_mm_mlp_adapter", "st", None),
     # additions of this build
-    ("optimizer_mode", str, "zero1"), ("synthetic", str, None),
+    ("optimizer_mode", str, "zero1"), ("synthetic", str, None), ("merge_ref_adapter", int, 1),
 ]
 
 
@@ -149,7 +149,10 @@ def main(argv: Optional[List[str]] = None) -> None:
     base = BaseWeights(d, state, dev, need_backward=True, vision_lora=vision_lora)
     engine = LlavaEngine(base)
     policy = AutoregressivePolicy(engine, LoraAdapter(d, adapter_sd, dev, True), args.response_len, args.temperature, "lora_policy")
-    ref_policy = AutoregressivePolicy(engine, LoraAdapter(d, ref_sd, dev, False), args.response_len, args.temperature, "lora_ref_policy")
+    ref_adapter = LoraAdapter(d, ref_sd, dev, False)
+    if args.merge_ref_adapter:      # frozen reference adapter folded into its own bf16 weight copy (model.LoraAdapter.merge_into_base)
+        ref_adapter.merge_into_base(base)
+    ref_policy = AutoregressivePolicy(engine, ref_adapter, args.response_len, args.temperature, "lora_ref_policy")
     trainer = DPOTrainer(args, policy, ref_policy, optimizer_mode=args.optimizer_mode)
     if args.synthetic:
         from .synth import synth_rollout_batches

@@ -120,10 +120,11 @@ def pair_flops(d: LlavaDims, q_len: int, t_len: int) -> float:
     return 4 * f_seq + 2 * dgrad + 2 * wgrad + f_img
 
 
-def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2) -> float:
+def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2, ref_merged: bool = False) -> float:
     """FLOPs EXECUTED for one preference pair when the K responses of a sample are packed on a shared image + query
     prefix (policy.pack_responses): one row of pfx + K*t_len positions per policy / reference pass instead of K rows of
-    pfx + t_len.  Same conventions as pair_flops (attention counted on the causal/segment-masked (q, k) pairs)."""
+    pfx + t_len.  Same conventions as pair_flops (attention counted on the causal/segment-masked (q, k) pairs).
+    ref_merged: the frozen reference adapter is folded into its weights (LoraAdapter.merge_into_base): no LoRA FLOPs in that pass."""
     H, F, V, nl, r = d.hidden, d.ffn, d.vocab, d.n_layers, d.lora_r
     pfx = q_len + d.n_patches - 1
     Lp = pfx + K * t_len
@@ -136,4 +137,4 @@ def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2) -> float
         + 2 * d.n_patches * (d.patch_k * vh + vh * H + H * H)
     dgrad = 2 * (p_lin + p_lora) * Lp + 2 * nl * 4 * H * pairs
     wgrad = 4 * p_lora * Lp
-    return 2 * f_row + dgrad + wgrad + f_img
+    return 2 * f_row + dgrad + wgrad + f_img - (2 * p_lora * Lp if ref_merged else 0)

@@ -177,6 +177,31 @@ class LoraAdapter:
             self.grad = None
             self.work = flat.to(device=device, dtype=BF)
             self.work_t = None
+        self.merged: Optional[List[Dict[str, torch.Tensor]]] = None      # frozen adapters only, see merge_into_base()
+
+    def merge_into_base(self, base: "BaseWeights") -> None:
+        """FROZEN adapter (the reference policy): fold s * B @ A into a second bf16 copy of the projection weights, once, at
+        load time (fp32 sum, one rounding to bf16) - PEFT's merge for an adapter that never changes.  The no-grad reference
+        forward then runs the bare-model path: no K-concatenated tail (6 % of each projection GEMM) and no r-wide x @ A^T
+        GEMMs (the least efficient shapes of the step); costs one extra copy of the LLM projections (13 GB at 7B).
+        Mathematically the same function; the rounding differs (weights rounded after the sum instead of t = s x A^T rounded
+        to bf16 before the tail): measured max |delta logp| in tests/test_parity_gpu.py::test_merged_reference_adapter."""
+        assert not self.trainable, "only a frozen adapter can be merged"
+        d, s = self.dims, self.dims.lora_scale
+        H, F, r = d.hidden, d.ffn, d.lora_r
+        out = []
+        for i in range(d.n_layers):
+            w = base.layers[i]
+            def add(wkey, b_name, a_name, groups, i=i, w=w):
+                W = w[wkey].float()
+                A, B = self.w(i, a_name).float(), self.w(i, b_name).float()      # A [G*r, in], B [G*out, r]
+                per = W.shape[0] // groups
+                for gi in range(groups):
+                    W[gi * per:(gi + 1) * per] += s * (B[gi * per:(gi + 1) * per] @ A[gi * r:(gi + 1) * r])
+                return W.to(BF)
+            out.append({"wqkv": add("wqkv", "b_qkv", "a_qkv", 3), "wo": add("wo", "b_o", "a_o", 1),
+                        "wgu": add("wgu", "b_gu", "a_gu", 2), "wd": add("wd", "b_d", "a_d", 1)})
+        self.merged = out
 
     def w(self, layer: int, name: str) -> torch.Tensor:
         off, rows, cols = self.offsets[layer][name]
@@ -361,6 +386,10 @@ class LlavaEngine:
         bare base model (the shipped rollout config has no LoRA: run/online_generate.sh POLICY_LORA_DIR=none).
         sv.<buf>[k] are the activation buffers; kv_hook(i, qkv) sees the post-RoPE q|k|v (KV-cache fill)."""
         d, w = self.d, self.base.layers[i]
+        mlp_adapter = adapter
+        if adapter is not None and adapter.merged is not None:      # frozen adapter folded into its own weight copy
+            w = dict(w, **adapter.merged[i])
+            adapter = None
         st = L.stream()
         H, F, r, nh, hd = d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim
         M = S * Lp
@@ -383,10 +412,13 @@ class LlavaEngine:
             L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
         else:
             L.gemm_nt(attn, w["wo"], h, residual=x)
-        self.mlp_fwd(i, adapter, h, xo, n2, t_gu, gu, act, t_d, sv.rstd2[k], M)
+        self.mlp_fwd(i, mlp_adapter, h, xo, n2, t_gu, gu, act, t_d, sv.rstd2[k], M)
 
     def mlp_fwd(self, i: int, adapter: Optional[LoraAdapter], h, xo, n2, t_gu, gu, act, t_d, rstd2, M: int) -> None:
         d, w = self.d, self.base.layers[i]
+        if adapter is not None and adapter.merged is not None:
+            w = dict(w, **adapter.merged[i])
+            adapter = None
         st = L.stream()
         H, F, r, s = d.hidden, d.ffn, d.lora_r, d.lora_scale
         L.call("opadpo_rmsnorm_fwd", L.ptr(h), int(h.dtype == torch.float32), L.ptr(w["ln2"]), L.ptr(n2), L.ptr(rstd2), M, H, d.rms_eps, st)

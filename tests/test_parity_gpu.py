@@ -708,3 +708,34 @@ def test_reference_recipe_length(setup):
     # key order on the batch dimension: swapping the kwargs order swaps nothing in the per-key outputs
     out2 = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, b_response=r2, a_response=r1)
     assert float((out2["a_response_logprobs"] - out["a_response_logprobs"]).abs().max()) < 2e-2
+
+
+def test_merged_reference_adapter():
+    """LoraAdapter.merge_into_base: the frozen reference adapter folded into a second bf16 weight copy gives the same log-probs
+    as the K-concatenated LoRA path up to bf16 rounding of the merged weights (same function, one rounding instead of two)."""
+    import torch
+    from opadpo_amd.dims import LlavaDims
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
+    from opadpo_amd.policy import AutoregressivePolicy
+    from opadpo_amd.synth import init_lora, init_weights, synth_pairs
+    dev = torch.device("cuda:0")
+    d = LlavaDims.tiny()
+    base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=False)
+    eng = LlavaEngine(base)
+    sd = init_lora(d, seed=2, b_std=0.05, device=dev)
+    plain, merged = LoraAdapter(d, sd, dev, False), LoraAdapter(d, sd, dev, False)
+    merged.merge_into_base(base)
+    bare = LoraAdapter(d, init_lora(d, seed=2, b_std=0.0, device=dev), dev, False)       # B = 0: what ignoring the adapter would give
+    b = synth_pairs(d, 3, 16, 24, seed=5, device=dev)
+    outs = []
+    for ad in (plain, merged, bare):
+        pol = AutoregressivePolicy(eng, ad, 24, pack_responses=True)
+        with torch.no_grad():
+            o = pol(images=b["images"], queries=b["queries"], queries_attn_masks=b["queries_attn_masks"],
+                    chosen_response=b["chosen"], rejected_response=b["rejected"])
+        outs.append(torch.cat([o["chosen_response_logprobs"].flatten(), o["rejected_response_logprobs"].flatten()]).float())
+    diff = (outs[0] - outs[1]).abs().max().item()
+    effect = (outs[0] - outs[2]).abs().max().item()
+    print(f"merged-reference check: max |delta logp| merged vs K-concatenated {diff:.3e}; adapter effect {effect:.3e}")
+    assert effect > 20 * diff, f"adapter effect {effect} vs merge error {diff}: the test would not see a dropped adapter"
+    assert diff < 3e-2, f"merged vs K-concatenated reference log-probs differ by {diff}"
