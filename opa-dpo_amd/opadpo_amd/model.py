@@ -193,12 +193,16 @@ class LoraAdapter:
         for i in range(d.n_layers):
             w = base.layers[i]
             def add(wkey, b_name, a_name, groups, i=i, w=w):
-                W = w[wkey].float()
-                A, B = self.w(i, a_name).float(), self.w(i, b_name).float()      # A [G*r, in], B [G*out, r]
+                # W'[g] = bf16(W[g] + s * B[g] @ A[g]) per fused group: one gemm_nt each (X = B[g] [out, r], Y = A[g]^T [in, r], fp32
+                # accumulation, alpha = s, bf16 residual = W[g], bf16 output -> a single rounding)
+                W = w[wkey]
+                A, B = self.w(i, a_name), self.w(i, b_name)                        # A [G*r, in], B [G*out, r]
+                Wm = torch.empty_like(W)
                 per = W.shape[0] // groups
                 for gi in range(groups):
-                    W[gi * per:(gi + 1) * per] += s * (B[gi * per:(gi + 1) * per] @ A[gi * r:(gi + 1) * r])
-                return W.to(BF)
+                    At = A[gi * r:(gi + 1) * r].t().contiguous()                   # [in, r]
+                    L.gemm_nt(B[gi * per:(gi + 1) * per], At, Wm[gi * per:(gi + 1) * per], residual=W[gi * per:(gi + 1) * per], alpha=s)
+                return Wm
             out.append({"wqkv": add("wqkv", "b_qkv", "a_qkv", 3), "wo": add("wo", "b_o", "a_o", 1),
                         "wgu": add("wgu", "b_gu", "a_gu", 2), "wd": add("wd", "b_d", "a_d", 1)})
         self.merged = out
