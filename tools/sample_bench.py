@@ -32,6 +32,8 @@ def main():
     eng = LlavaEngine(BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True))
     pol = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
+    if os.environ.get("SB_MERGE_REF", "1") == "1":
+        ref.merge_into_base(eng.base)
     args = SimpleNamespace(rollout_accumulation_steps=1, gradient_accumulation_steps=1, step_per_device_batch_size=B,
                            rollout_per_device_batch_size=B, rollout_batch_size=B, noptepochs=1, max_grad_norm=1.0,
                            learning_rate=1e-6, warmup_steps=0, total_epochs=1, max_step=1000, save_steps=10 ** 9,
