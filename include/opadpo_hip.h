@@ -27,6 +27,10 @@ extern "C" {
 #define OPADPO_ACT_NONE 0
 #define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
+#define OPADPO_ACT_SWIGLU_PAIR 3 /* gemm_nt only: B rows arranged per 128 as [64 gate | 64 up]; C gets N/2 columns
+                                 * silu(gate) * up (SwiGLU of modeling_llama.LlamaMLP fused into the gate|up projection; used
+                                 * for the merged, no-grad reference pass).  Needs M-by-N tiles of 256, bf16 C, no bias /
+                                 * residual, alpha = 1. */
 #define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
                                   * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
 

@@ -1247,6 +1247,25 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int mb = m0 + wr * 128;
+      if (p.act == OPADPO_ACT_SWIGLU_PAIR) {
+        // fused SwiGLU: the wave's 128 columns are [gate c0..c0+63 | up c0..c0+63] (weight rows permuted by the caller), the
+        // output has N/2 columns.  silu(gate) * up on the bf16-ROUNDED staged values, same formula as silu_mul_fwd_kernel ->
+        // bit-identical to the two-kernel path.  8 rows x 8 chunks per pass.
+        const int row0 = lane >> 3, g = lane & 7;
+        const int ocol = ncol0 / 2 + g * 8;
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+          const int row = ps * 8 + row0, m = mb + row;
+          const char* rp = stg + row * 256;
+          float gt[8], up[8], o[8];
+          unpack8(*(const uint4*)(rp + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), gt);
+          unpack8(*(const uint4*)(rp + ((((g + 8) >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), up);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = gt[e] / (1.0f + __expf(-gt[e])) * up[e];
+          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ocol) = pack8(o);
+        }
+        return;
+      }
       if ((unsigned long long)p.M * (unsigned)p.ldc * 2ull < 0xffffffffull) {
         // rows through a descriptor that ends after row M-1: 32-bit offsets (one add per row group), no predicate, 8 reads then 8 stores
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
@@ -2350,6 +2369,13 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
+  }
+  if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: only the 4-wave 256x256 kernel implements it
+    const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9;
+    if (a.bias || a.R || a.out_f32 || a.alpha != 1.0f || a.K2 != 0 || a.N % P_BN || !ok32) return hipErrorInvalidValue;
+    const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
   }
   // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
   if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15)) {

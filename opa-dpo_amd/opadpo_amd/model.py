@@ -203,8 +203,15 @@ class LoraAdapter:
                     At = A[gi * r:(gi + 1) * r].t().contiguous()                   # [in, r]
                     L.gemm_nt(B[gi * per:(gi + 1) * per], At, Wm[gi * per:(gi + 1) * per], residual=W[gi * per:(gi + 1) * per], alpha=s)
                 return Wm
-            out.append({"wqkv": add("wqkv", "b_qkv", "a_qkv", 3), "wo": add("wo", "b_o", "a_o", 1),
-                        "wgu": add("wgu", "b_gu", "a_gu", 2), "wd": add("wd", "b_d", "a_d", 1)})
+            wgu = add("wgu", "b_gu", "a_gu", 2)
+            m = {"wqkv": add("wqkv", "b_qkv", "a_qkv", 3), "wo": add("wo", "b_o", "a_o", 1), "wd": add("wd", "b_d", "a_d", 1)}
+            if F % 128 == 0:
+                # rows per 128: [64 gate | 64 up] -> the projection GEMM's epilogue applies SwiGLU (lib.ACT_SWIGLU_PAIR): the no-grad
+                # pass writes `act` directly, no [M, 2F] pre-activation tensor, no silu_mul kernel
+                m["wgu_sw"] = torch.stack([wgu[:F].view(F // 64, 64, H), wgu[F:].view(F // 64, 64, H)], dim=1).reshape(2 * F, H).contiguous()
+            else:
+                m["wgu"] = wgu
+            out.append(m)
         self.merged = out
 
     def w(self, layer: int, name: str) -> torch.Tensor:
@@ -429,9 +436,12 @@ class LlavaEngine:
         if adapter is not None:
             L.gemm_nt(n2, adapter.w(i, "a_gu"), t_gu, alpha=s)
             L.gemm_nt(n2, w["wgu"], gu, a2=t_gu, b2=adapter.w(i, "b_gu"), a2_group_n=F, a2_group_stride=r)
+        elif "wgu_sw" in w:                 # merged frozen adapter: SwiGLU fused into the projection's epilogue
+            L.gemm_nt(n2, w["wgu_sw"], act, act=L.ACT_SWIGLU_PAIR)
         else:
             L.gemm_nt(n2, w["wgu"], gu)
-        L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
+        if adapter is not None or "wgu_sw" not in w:
+            L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
         if adapter is not None:
             L.gemm_nt(act, adapter.w(i, "a_d"), t_d, alpha=s)
             L.gemm_nt(act, w["wd"], xo, a2=t_d, b2=adapter.w(i, "b_d"), residual=h)

@@ -791,3 +791,24 @@ def test_errors_are_loud(L):
     out = torch.empty(10, 100, dtype=BF, device=dev())
     with pytest.raises(L.OpadpoError):
         L.gemm_nt(a, b, out)
+
+
+@pytest.mark.parametrize("M,F,K", [(700, 256, 128), (3000, 1408, 192), (40, 128, 64)])
+def test_gemm_nt_swiglu_pair(L, M, F, K):
+    """ACT_SWIGLU_PAIR: weight rows arranged per 128 as [64 gate | 64 up]; the projection's epilogue writes silu(gate) * up
+    ([M, F]) - bit-identical to the projection followed by opadpo_silu_mul_fwd (same bf16 rounding of the pre-activations)."""
+    L.set_flags(10, True)
+    x = rnd(M, K, seed=1)
+    wgu = rnd(2 * F, K, scale=0.3, seed=2)                     # rows [0, F) gate, [F, 2F) up
+    gu = torch.empty(M, 2 * F, dtype=BF, device=dev())
+    L.gemm_nt(x, wgu, gu)
+    want = torch.empty(M, F, dtype=BF, device=dev())
+    L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(want), M, F, L.stream())
+    w_sw = torch.stack([wgu[:F].view(F // 64, 64, K), wgu[F:].view(F // 64, 64, K)], dim=1).reshape(2 * F, K).contiguous()
+    got = torch.full((M + 2, F), 7.0, dtype=BF, device=dev())
+    L.gemm_nt(x, w_sw, got[:M], act=L.ACT_SWIGLU_PAIR)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:M], want)
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    ref = torch.nn.functional.silu(x.float() @ wgu[:F].float().t()) * (x.float() @ wgu[F:].float().t())
+    assert relerr(got[:M], ref) < 2e-2
