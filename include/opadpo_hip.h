@@ -58,6 +58,17 @@ int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, i
                    void* C, int ldc, int out_f32, const void* R, int ldr, int res_f32, const uint16_t* bias,
                    int M, int N, float alpha, int act, void* stream);
 
+/* The fused q|k|v projection with the rotary embedding applied in its epilogue (modeling_llama.LlamaAttention: q_proj / k_proj /
+ * v_proj followed by apply_rotary_pos_emb on q and k): C[M,N] bf16 = A1 B1^T (+ A2[:, group] B2^T), then columns [0, rope_cols)
+ * - heads of 128 - are rotated with the position of their row: pos = row % L, and with seg_len > 0 every response of a packed
+ * row restarts at seg_prefix (same convention as opadpo_rope / opadpo_attn_fwd); cos_tab / sin_tab [>= L][64] fp32.  The
+ * rotation reads the bf16-rounded projection, as opadpo_rope does on the stored tensor.  N % 256 == 0; alpha = 1, no bias,
+ * residual or activation. */
+int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                        const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
+                        uint16_t* C, int ldc, int M, int N, const float* cos_tab, const float* sin_tab, int L, int rope_cols,
+                        int seg_prefix, int seg_len, void* stream);
+
 /* LoRA weight gradients: C[N1,N2] (fp32) += alpha * sum_m P[m,N1] * Q[m,N2]   (dB = dY^T t,
  * dA = dT^T x; autograd of peft lora_A / lora_B, rl_trainer.py:162).  Q column offset for output
  * row n1 is (n1 / q_group_n1) * q_group_stride.  N1 % 128 == 0, N2 % 128 == 0. splits<=0: auto. */

@@ -48,6 +48,27 @@ int opadpo_gemm_nt(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, i
   return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt");
 }
 
+int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                        const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
+                        uint16_t* C, int ldc, int M, int N, const float* cos_tab, const float* sin_tab, int L, int rope_cols,
+                        int seg_prefix, int seg_len, void* stream) {
+  if (M < 0 || N <= 0 || N % 256) return bad("opadpo_gemm_nt_rope", "N must be a positive multiple of 256");
+  if (K1 <= 0 || K2 < 0 || K1 % 64 || K2 % 64) return bad("opadpo_gemm_nt_rope", "K1/K2 must be multiples of 64");
+  if (!A1 || !B1 || (K2 && (!A2 || !B2)) || !C || !cos_tab || !sin_tab) return bad("opadpo_gemm_nt_rope", "null operand");
+  if (lda1 % 8 || ldb1 % 8 || (K2 && (lda2 % 8 || ldb2 % 8)) || ldc % 8) return bad("opadpo_gemm_nt_rope", "leading dimensions must keep 16-byte alignment");
+  if (a2_group_n && a2_group_n % 256) return bad("opadpo_gemm_nt_rope", "group width must be a multiple of the 256-column tile");
+  if (L < 4 || rope_cols < 0 || rope_cols > N || rope_cols % 128 || seg_prefix < 0 || seg_len < 0 || (seg_len > 0 && seg_len < 4))
+    return bad("opadpo_gemm_nt_rope", "rope_cols must be whole heads of 128 within N; L >= 4; seg_len 0 or >= 4");
+  GemmNTArgs a;
+  a.A1 = A1; a.B1 = B1; a.A2 = A2; a.B2 = B2; a.C = C; a.R = nullptr; a.bias = nullptr;
+  a.M = M; a.N = N; a.K1 = K1; a.K2 = K2;
+  a.lda1 = lda1; a.ldb1 = ldb1; a.lda2 = lda2; a.ldb2 = ldb2; a.ldc = ldc; a.ldr = 0;
+  a.a2_group_n = a2_group_n; a.a2_group_stride = a2_group_stride; a.a1_group_n = 0; a.a1_group_stride = 0;
+  a.alpha = 1.0f; a.act = 0; a.out_f32 = 0; a.r_f32 = 0;
+  a.rope_cos = cos_tab; a.rope_sin = sin_tab; a.rope_L = L; a.rope_cols = rope_cols; a.rope_seg_prefix = seg_prefix; a.rope_seg_len = seg_len;
+  return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt_rope");
+}
+
 int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float* C, int ldc,
                    int M, int N1, int N2, int q_group_n1, int q_group_stride, float alpha, int splits,
                    void* stream) {

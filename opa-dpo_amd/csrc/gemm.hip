@@ -1266,6 +1266,37 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
         }
         return;
       }
+      if (p.rope_cos && ncol0 < p.rope_cols) {
+        // fused rotary embedding: the wave's 128 columns are one head; out[d] = x[d] cos - x[d+64] sin, out[d+64] = x[d+64] cos + x[d] sin
+        // on the bf16-ROUNDED staged values (what rope_kernel reads back from HBM), position = row % L with the packed-response restart
+        const int row0 = lane >> 4, g = lane & 15, gh = g & 7;
+        const float sign = g < 8 ? -1.0f : 1.0f;
+        int pos = (mb + row0) % p.rope_L;
+        const int lim = p.rope_seg_prefix + p.rope_seg_len;
+        int rem = (p.rope_seg_len > 0 && pos >= p.rope_seg_prefix) ? (pos - p.rope_seg_prefix) % p.rope_seg_len : 0;
+#pragma unroll 4
+        for (int ps = 0; ps < 32; ++ps) {
+          const int row = ps * 4 + row0, m = mb + row;
+          const int p2 = (p.rope_seg_len > 0 && pos >= lim) ? p.rope_seg_prefix + rem : pos;
+          const char* rp = stg + row * 256;
+          float xs[8], xp[8], o[8];
+          unpack8(*(const uint4*)(rp + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xs);
+          unpack8(*(const uint4*)(rp + ((((g ^ 8) >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xp);
+          const float4 c0 = *(const float4*)(p.rope_cos + (size_t)p2 * 64 + gh * 8), c1 = *(const float4*)(p.rope_cos + (size_t)p2 * 64 + gh * 8 + 4);
+          const float4 s0 = *(const float4*)(p.rope_sin + (size_t)p2 * 64 + gh * 8), s1 = *(const float4*)(p.rope_sin + (size_t)p2 * 64 + gh * 8 + 4);
+          const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = xs[e] * cs[e] + sign * (xp[e] * sn[e]);
+          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = pack8(o);
+          pos += 4; rem += 4;
+          if (pos >= p.rope_L) { pos -= p.rope_L; rem = (p.rope_seg_len > 0 && pos >= p.rope_seg_prefix) ? (pos - p.rope_seg_prefix) % p.rope_seg_len : 0; }
+          else if (p.rope_seg_len > 0) {
+            if (pos >= p.rope_seg_prefix && pos - 4 < p.rope_seg_prefix) rem = pos - p.rope_seg_prefix;
+            while (rem >= p.rope_seg_len) rem -= p.rope_seg_len;
+          }
+        }
+        return;
+      }
       if ((unsigned long long)p.M * (unsigned)p.ldc * 2ull < 0xffffffffull) {
         // rows through a descriptor that ends after row M-1: 32-bit offsets (one add per row group), no predicate, 8 reads then 8 stores
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
@@ -2369,6 +2400,15 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
+  }
+  if (a.rope_cos) {      // fused rotary embedding: only the 4-wave 256x256 kernel implements it (bf16 out, alpha-only epilogue)
+    const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
+                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));
+    if (a.bias || a.act || a.R || a.out_f32 || a.N % P_BN || !ok32 || a.rope_L < 4 || a.rope_cols % 128 ||
+        (a.rope_seg_len > 0 && a.rope_seg_len < 4)) return hipErrorInvalidValue;
+    const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
   }
   if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: only the 4-wave 256x256 kernel implements it
     const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9;

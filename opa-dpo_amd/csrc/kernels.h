@@ -20,6 +20,11 @@ struct GemmNTArgs {
   int act;
   int out_f32;
   int r_f32;
+  // fused rotary embedding (opadpo_gemm_nt_rope): columns [0, rope_cols) are heads of 128, rotated with the position of the
+  // output row (row % rope_L, packed responses restart at rope_seg_prefix); tables [pos][64] fp32.  Null = off.
+  const float* rope_cos = nullptr;
+  const float* rope_sin = nullptr;
+  int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
 };
 
 struct GemmTNArgs {

@@ -25,6 +25,7 @@ _u64 = C.c_uint64
 # name -> argtypes (restype is int unless noted).  Must list EVERY symbol of include/opadpo_hip.h.
 SIGNATURES = {
     "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
+    "opadpo_gemm_nt_rope": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
@@ -184,6 +185,32 @@ def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Option
          a2_group_n, a2_group_stride, a1_group_n, a1_group_stride, ptr(out), out.stride(0), int(out_f32),
          ptr(residual), residual.stride(0) if residual is not None else 0, int(res_f32), ptr(bias), M, N, float(alpha),
          act | (GEMM_STREAM if _stream_weights else 0), stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((2.0 * M * N * (K1 + K2), e0, e1))
+    return out
+
+
+def gemm_nt_rope(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, L: int, rope_cols: int,
+                 seg=(0, 0), *, a2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, a2_group_n: int = 0,
+                 a2_group_stride: int = 0) -> torch.Tensor:
+    """out[M,N] (bf16) = a1 @ b1^T (+ a2[:, group] @ b2^T), columns [0, rope_cols) rotated per head of 128 with the position of
+    their row (row % L; seg = (prefix, seg_len): packed responses restart at the prefix) - opadpo_gemm_nt_rope."""
+    _chk(a1, torch.bfloat16, "a1"); _chk(b1, torch.bfloat16, "b1"); _chk(out, torch.bfloat16, "out")
+    _chk(cos, torch.float32, "cos"); _chk(sin, torch.float32, "sin")
+    M, K1, N = a1.shape[0], a1.shape[1], b1.shape[0]
+    assert b1.shape[1] == K1 and out.shape[0] == M and out.shape[1] == N and cos.shape[0] >= min(L, seg[0] + seg[1] if seg[1] else L)
+    K2 = 0
+    if a2 is not None:
+        _chk(a2, torch.bfloat16, "a2"); _chk(b2, torch.bfloat16, "b2")
+        K2 = b2.shape[1]
+        assert b2.shape[0] == N and a2.shape[0] == M
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("opadpo_gemm_nt_rope", ptr(a1), a1.stride(0), ptr(b1), b1.stride(0), K1,
+         ptr(a2), a2.stride(0) if a2 is not None else 0, ptr(b2), b2.stride(0) if b2 is not None else 0, K2,
+         a2_group_n, a2_group_stride, ptr(out), out.stride(0), M, N, ptr(cos), ptr(sin), int(L), int(rope_cols), int(seg[0]), int(seg[1]), stream())
     if PROFILE is not None:
         e1.record()
         PROFILE.append((2.0 * M * N * (K1 + K2), e0, e1))

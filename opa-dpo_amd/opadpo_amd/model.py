@@ -20,6 +20,7 @@ Layout decisions (MI355X, 288 GB HBM3E):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -30,6 +31,9 @@ from .dims import (IMAGE_TOKEN_INDEX, LLM_LINEARS, LLM_PREFIX, PEFT_PREFIX, VIS_
                    llm_linear_shape)
 
 BF = torch.bfloat16
+
+
+_FUSE_ROPE = os.environ.get("OPADPO_FUSE_ROPE", "0") == "1"
 
 
 def _dev(t: torch.Tensor, device, dtype=BF) -> torch.Tensor:
@@ -408,12 +412,22 @@ class LlavaEngine:
         n1, qkv, t_qkv, attn, t_o, h, n2, t_gu, gu, act, t_d = (sv.n1[k], sv.qkv[k], sv.t_qkv[k], sv.attn[k], sv.t_o[k],
                                                                  sv.h[k], sv.n2[k], sv.t_gu[k], sv.gu[k], sv.act[k], sv.t_d[k])
         L.call("opadpo_rmsnorm_fwd", L.ptr(x), int(x.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
+        # rotary embedding fused into the projection's epilogue (each 128-column block of q and k is one head): OPT-IN
+        # (OPADPO_FUSE_ROPE=1).  Measured neutral at the bench shape: the epilogue pays 7.7 us per block for the fp32 cos / sin rows
+        # (8 B of table per 2 B of output, latency-bound inside a one-block-per-CU kernel) - as much as the in-place kernel it saves.
+        fuse_rope = _FUSE_ROPE and hd == 128 and H % 256 == 0 and (seg[1] == 0 or seg[1] >= 4) and Lp >= 4
         if adapter is not None:
             L.gemm_nt(n1, adapter.w(i, "a_qkv"), t_qkv, alpha=s)
-            L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
+            if fuse_rope:
+                L.gemm_nt_rope(n1, w["wqkv"], qkv, cos, sin, Lp, 2 * H, seg, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
+            else:
+                L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=adapter.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
+        elif fuse_rope:
+            L.gemm_nt_rope(n1, w["wqkv"], qkv, cos, sin, Lp, 2 * H, seg)
         else:
             L.gemm_nt(n1, w["wqkv"], qkv)
-        L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, seg[0], seg[1], st)
+        if not fuse_rope:
+            L.call("opadpo_rope", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, seg[0], seg[1], st)
         if kv_hook is not None:
             kv_hook(i, qkv)
         L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,

@@ -812,3 +812,34 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert float((got[M:].float() - 7.0).abs().max()) == 0.0
     ref = torch.nn.functional.silu(x.float() @ wgu[:F].float().t()) * (x.float() @ wgu[F:].float().t())
     assert relerr(got[:M], ref) < 2e-2
+
+
+@pytest.mark.parametrize("S,Lp,seg", [(3, 150, (0, 0)), (2, 200, (120, 40)), (1, 700, (300, 100)), (5, 37, (17, 10))])
+@pytest.mark.parametrize("lora", [False, True])
+def test_gemm_nt_rope(L, S, Lp, seg, lora):
+    """opadpo_gemm_nt_rope: q|k|v projection with the rotary embedding in its epilogue == projection followed by opadpo_rope on the
+    stored tensor (both rotate the bf16-rounded projection; fp32 contraction order may differ by one bf16 ulp on a few elements)."""
+    L.set_flags(10, True)
+    nh, hd, K, r = 2, 128, 192, 64
+    H = nh * hd
+    M = S * Lp
+    x, w = rnd(M, K, seed=1), rnd(3 * H, K, scale=0.3, seed=2)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    f = torch.outer(torch.arange(Lp, dtype=torch.float32), inv)
+    cos, sin = f.cos().to(dev()).contiguous(), f.sin().to(dev()).contiguous()
+    kw = {}
+    if lora:
+        kw = dict(a2=rnd(M, 3 * r, seed=3), b2=rnd(3 * H, r, scale=0.3, seed=4), a2_group_n=H, a2_group_stride=r)
+    want = torch.empty(M, 3 * H, dtype=BF, device=dev())
+    L.gemm_nt(x, w, want, **kw)
+    v_before = want[:, 2 * H:].clone()
+    L.call("opadpo_rope", L.ptr(want), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 0, None, seg[0], seg[1], L.stream())
+    got = torch.full((M + 1, 3 * H), 7.0, dtype=BF, device=dev())
+    L.gemm_nt_rope(x, w, got[:M], cos, sin, Lp, 2 * H, seg, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:M, 2 * H:], v_before)                      # v columns: untouched by the rotation
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    d = (got[:M].float() - want.float()).abs()
+    tol = 2.0 ** -7 * want.float().abs() + 1e-6                         # one bf16 ulp
+    assert bool((d <= tol).all()), f"max excess {(d - tol).max().item()}"
+    assert float((d > 0).float().mean()) < 0.02                        # and almost everywhere identical
