@@ -281,12 +281,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
           mx = fmaxf(mx, sc[kf][r]);
         }
     } else {
+      const bool nc = !p.causal;
+      uint32_t mw[4];                     // the lane's 4 mask bytes per key block as one word
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) mw[kf] = *(const uint32_t*)(Ms + kf * 16 + g * 4);
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kl = kf * 16 + g * 4 + r;
-          const bool ok = Ms[kl] && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
+          // bitwise, not short-circuit: a chain of && on per-lane values compiles to a saveexec / branch per term and element
+          const bool ok = ((mw[kf] >> (8 * r)) & 0xffu) != 0 & (nc | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
           sc[kf][r] = ok ? sc[kf][r] * scale2 : -INFINITY;      // exp2(-inf - m) = 0 (m stays finite: NEG_BIG floor)
           mx = fmaxf(mx, sc[kf][r]);
         }
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           const int ql = qf * 16 + g * 4 + r;
           const int qp = q0 + ql;
-          const bool ok = key_ok && qp < L && (!p.causal || kpos <= qp) && qp < kend;
+          const bool ok = key_ok & (qp < L) & (!p.causal | (kpos <= qp)) & (qp < kend);      // bitwise: no branch per term
           const float pv = fast_exp2(ok ? sc[qf][r] * scale2 - lse_s[ql] : -INFINITY);
           sc[qf][r] = pv;
           dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
@@ -584,12 +589,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
           dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
         }
     } else {
+      uint32_t mw[4];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) mw[kf] = *(const uint32_t*)(Ms + kf * 16 + g * 4);
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kl = kf * 16 + g * 4 + r;
-          const bool ok = Ms[kl] && qpos < L && (!p.causal || (k0 + kl) <= qpos) && ((k0 + kl) < xlo || (k0 + kl) >= xhi);
+          const bool ok = ((mw[kf] >> (8 * r)) & 0xffu) != 0 & (qpos < L) & (!p.causal | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
           const float pv = fast_exp2(ok ? sc[kf][r] * scale2 - lse2 : -INFINITY);
           dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
         }
