@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           const int kl = kf * 16 + g * 4 + r;
           // bitwise, not short-circuit: a chain of && on per-lane values compiles to a saveexec / branch per term and element
-          const bool ok = ((mw[kf] >> (8 * r)) & 0xffu) != 0 & (nc | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
+          const bool ok = (((mw[kf] >> (8 * r)) & 0xffu) != 0) & (nc | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
           sc[kf][r] = ok ? sc[kf][r] * scale2 : -INFINITY;      // exp2(-inf - m) = 0 (m stays finite: NEG_BIG floor)
           mx = fmaxf(mx, sc[kf][r]);
         }
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kl = kf * 16 + g * 4 + r;
-          const bool ok = ((mw[kf] >> (8 * r)) & 0xffu) != 0 & (qpos < L) & (!p.causal | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
+          const bool ok = (((mw[kf] >> (8 * r)) & 0xffu) != 0) & (qpos < L) & (!p.causal | ((k0 + kl) <= qpos)) & (((k0 + kl) < xlo) | ((k0 + kl) >= xhi));
           const float pv = fast_exp2(ok ? sc[kf][r] * scale2 - lse2 : -INFINITY);
           dp[kf][r] = pv * (dp[kf][r] - dlt) * p.scale;
         }
