@@ -36,8 +36,8 @@ extern "C" {
 
 int opadpo_abi_version(void);
 const char* opadpo_last_error(void);
-/* kernel-variant switches (diagnostics): use_glds = gemm_nt variant (0 register staging, 1 global_load_lds
- * staging + 16x16x32 MFMA, 2 global_load_lds + 32x32x16 MFMA, ..., 10 = auto (default)); use_tr bit 0 =
+/* kernel-variant switches (diagnostics): use_glds = gemm_nt variant (10 = auto (default), 4 = 128x128 kernel, 8 / 17 = 8-wave
+ * 256x256 kernels, 16 / 23 / 24 / 28 / 29 / 31 = 4-wave 256x256 family, 27 / 30 = stamped diagnostics); use_tr bit 0 =
  * ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 = attention forward through a direct-to-LDS
  * double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks per CU), bit 2 = wide gemm_tn tiles,
  * bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one. */

@@ -118,301 +118,10 @@ __device__ __forceinline__ void epilogue4(const GemmNTArgs& p, int m, int n, flo
   }
 }
 
-// GLDS: stage through global_load_lds (LDS-DMA) instead of registers.  MF32: 32x32x16 MFMA fragments
-// (2x2 per wave) instead of 16x16x32 (4x4 per wave).
-template <bool GLDS, bool MF32>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
-  const bf16_t* a2 = p.A2;
-  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
-  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
-
-  // staging coordinates of this lane inside a 1-KiB (8 rows x 128 B) chunk
-  const int srow = lane >> 3, spos = lane & 7;
-
-  uint4 regs[8];  // register-staging fallback only
-
-  auto stage_issue = [&](int buf, int t) {
-    const bf16_t *Ab, *Bb;
-    int lda, ldb, k0;
-    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * BK; }
-    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * BK; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int chunk = wave * 4 + i;
-      const int r = chunk * 8 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
-      const int gr = min(m0 + r, p.M - 1);
-      const bf16_t* srcA = Ab + (size_t)gr * lda + k0 + c * 8;
-      const bf16_t* srcB = Bb + (size_t)(n0 + r) * ldb + k0 + c * 8;
-      char* dA = smem + buf * STAGE_BYTES + chunk * 1024;
-      char* dB = dA + TILE_BYTES;
-      if constexpr (GLDS) {
-        __builtin_amdgcn_global_load_lds(GLB_PTR(srcA), LDS_PTR(void, dA), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(srcB), LDS_PTR(void, dB), 16, 0, 0);
-      } else {
-        regs[i] = *(const uint4*)srcA;
-        regs[4 + i] = *(const uint4*)srcB;
-      }
-    }
-  };
-  auto stage_commit = [&](int buf) {
-    if constexpr (!GLDS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int chunk = wave * 4 + i;
-        char* dA = smem + buf * STAGE_BYTES + chunk * 1024 + lane * 16;
-        *(uint4*)dA = regs[i];
-        *(uint4*)(dA + TILE_BYTES) = regs[4 + i];
-      }
-    }
-  };
-
-  const int wm = wave >> 1, wn = wave & 1;
-  stage_issue(0, 0);
-  stage_commit(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  if constexpr (!MF32) {
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fchk = lane >> 4;
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
-      const char* As = smem + cur * STAGE_BYTES;
-      const char* Bs = As + TILE_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8_t af[4], bfr[4];
-        const int c = kk * 4 + fchk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wm * 64 + i * 16 + frow;
-          af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wn * 64 + j * 16 + frow;
-          bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            // operands swapped (B-tile rows as the MFMA "A" side): the lane ends up holding 4
-            // consecutive output columns of one output row -> 8/16-byte stores.
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      if (t + 1 < nt) stage_commit(cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
-    }
-    // lane holds C[m][n..n+3], m = m_base + i*16 + (lane&15), n = n_base + j*16 + (lane>>4)*4
-    epi_dispatch(p, [&](auto MD_) {
-      constexpr int md = decltype(MD_)::value;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          epilogue4<md>(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    });
-  } else {
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    const int frow = lane & 31, fchk = lane >> 5;
-    int cur = 0;
-    for (int t = 0; t < nt; ++t) {
-      if (t + 1 < nt) stage_issue(cur ^ 1, t + 1);
-      const char* As = smem + cur * STAGE_BYTES;
-      const char* Bs = As + TILE_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8_t af[2], bfr[2];
-        const int c = kk * 2 + fchk;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = wm * 64 + i * 32 + frow;
-          af[i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int row = wn * 64 + j * 32 + frow;
-          bfr[j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      if (t + 1 < nt) stage_commit(cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
-    }
-    // D[i' = n][j' = m]: lane holds m = m_base + i*32 + (lane&31); n = n_base + j*32 + 8*q + 4*(lane>>5) + (reg&3)
-    epi_dispatch(p, [&](auto MD_) {
-      constexpr int md = decltype(MD_)::value;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            epilogue4<md>(p, m, n0 + wn * 64 + j * 32 + q * 8 + fchk * 4, acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1],
-                      acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-      }
-    });
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// gemm_nt "ring" variant: 128x256 block tile, 4 waves x (128x64), BK = 32, THREE LDS stages fed by
-// LDS-DMA with a COUNTED s_waitcnt vmcnt (loads for K-tiles t+1 and t+2 stay in flight across the
-// single raw s_barrier per K-step; never drained to 0 in the main loop).  72 KiB LDS -> 2 blocks
-// per CU, so each SIMD hosts two waves of DIFFERENT blocks whose barriers are independent (natural
-// stagger: one computes while the other waits).  Per K-step and wave: 12 ds_read_b128 + 6 LDS-DMA
-// pieces feed 32 MFMAs (vs 16 + 8 in the 128x128 kernel).
-// LDS image: 64-byte rows (32 bf16), 16 rows per 1-KiB DMA piece; conflict-free swizzle
-// chunk ^= F((row >> 2) & 3), F = {0,2,3,1}, applied to the DMA source address and the read address.
-// ------------------------------------------------------------------------------------------
-constexpr int R_BM = 128, R_BN = 256, R_BK = 32, R_STAGES = 3;
-constexpr int R_A_BYTES = R_BM * R_BK * 2, R_B_BYTES = R_BN * R_BK * 2, R_ST_BYTES = R_A_BYTES + R_B_BYTES;
-
-__device__ __forceinline__ int swz64(int row) {
-  const int q = (row >> 2) & 3;
-  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_nt_ring_kernel(GemmNTArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int tiles_m = (p.M + R_BM - 1) / R_BM, tiles_n = p.N / R_BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
-  const int m0 = tm * R_BM, n0 = tn * R_BN;
-
-  const int nt1 = p.K1 / R_BK, nt2 = p.K2 / R_BK, nt = nt1 + nt2;
-  const bf16_t* a2 = p.A2;
-  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
-  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
-
-  const int srow = lane >> 2, spos = lane & 3;   // 16 rows x 4 chunks per DMA piece
-
-  auto issue = [&](int stage, int t) {
-    const bf16_t *Ab, *Bb;
-    int lda, ldb, k0;
-    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * R_BK; }
-    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * R_BK; }
-    char* base = smem + stage * R_ST_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {              // A: 8 pieces, 2 per wave
-      const int piece = wave * 2 + i;
-      const int r = piece * 16 + srow;
-      const int c = spos ^ swz64(r);
-      const int gr = min(m0 + r, p.M - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, base + piece * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {              // B: 16 pieces, 4 per wave
-      const int piece = wave * 4 + i;
-      const int r = piece * 16 + srow;
-      const int c = spos ^ swz64(r);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8),
-                                       LDS_PTR(void, base + R_A_BYTES + piece * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  issue(0, 0);
-  if (nt > 1) issue(1, 1);
-
-  const int frow = lane & 15, fchk = lane >> 4;
-  int stage = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + 2 < nt) issue(stage == 0 ? 2 : stage - 1, t + 2);   // (stage + 2) % 3
-    const char* As = smem + stage * R_ST_BYTES;
-    const char* Bs = As + R_A_BYTES;
-    bf16x8_t af[8], bfr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wave * 64 + j * 16 + frow;
-      bfr[j] = *(const bf16x8_t*)(Bs + row * 64 + ((fchk ^ swz64(row)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = i * 16 + frow;
-      af[i] = *(const bf16x8_t*)(As + row * 64 + ((fchk ^ swz64(row)) << 4));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    stage = (stage == 2) ? 0 : stage + 1;
-  }
-  epi_dispatch(p, [&](auto MD_) {
-    constexpr int md = decltype(MD_)::value;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + i * 16 + frow;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        epilogue4<md>(p, m, n0 + wave * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    }
-  });
-}
-
-// ------------------------------------------------------------------------------------------
-// Experimental knobs on the 128x128 kernel (A/B-tested in tools/gemm_bench.py): K-step 64 or 32
-// (32 -> 32 KiB LDS per block -> more co-resident blocks) and s_setprio around the MFMA cluster.
+// gemm_nt 128x128 kernel (small / skinny-N problems): 4 waves x 64x64, two LDS stages filled by global_load_lds, s_setprio around
+// the MFMA cluster.  Instantiated with K-step 64, two blocks per CU (K-step 32 with 3-4 blocks, the register-staged and 32x32x16
+// forms and a three-stage 128x256 ring were measured slower and are gone; DESIGN.md §6 keeps their numbers).
 // ------------------------------------------------------------------------------------------
 template <int BKX, bool PRIO, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
@@ -435,7 +144,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
   if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
   const int srow = lane / CPR, spos = lane % CPR;
-  auto fsw = [](int r) { return BKX == 64 ? ((r >> 1) & 7) : swz64(r); };
+  static_assert(BKX == 64, "the 128-byte-row swizzle below is for K-step 64");
+  auto fsw = [](int r) { return (r >> 1) & 7; };
 
   auto issue = [&](int buf, int t) {
     const bf16_t *Ab, *Bb;
@@ -2361,7 +2071,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
 }
 }  // namespace
 
-static int g_gemm_variant = 10;   // 0: register staging, 1: LDS-DMA 16x16x32, 2: LDS-DMA 32x32x16, 3: 3-stage ring 128x256, 4: LDS-DMA 16x16x32 + setprio, <=128 VGPR; 5-7: BK=32 experiments; 8/9: 256x256 ping-pong (16x16x32 / 32x32x16); 10 (default): auto 8|4
+static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 8: 8-wave ping-pong; 15: M <= 64 streaming; 16/23/24/27/28/29/30/31: w4 family; 17: 8-wave 4-phase
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
 static int g_tn_wide = 0;      // use_tr bit 2 set: wide (256 x 128 / 128 x 256) gemm_tn tiles — measured slower overall, see gemm_tn2_kernel
@@ -2382,12 +2092,9 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
 #define PP_ATTR(...) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE)
-    PP_ATTR(false); PP_ATTR(true); PP_ATTR(false, false); PP_ATTR(false, true, false); PP_ATTR(false, true, true, 16); PP_ATTR(false, true, true, 4);
+    PP_ATTR(false);
 #undef PP_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
@@ -2398,7 +2105,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R_STAGES * R_ST_BYTES);
     attr_set = true;
   }
   if (a.rope_cos) {      // fused rotary embedding: only the 4-wave 256x256 kernel implements it (bf16 out, alpha-only epilogue)
@@ -2509,45 +2215,16 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<0>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (g_gemm_variant >= 11 && g_gemm_variant <= 14 && pp_tiles > 0) {      // schedule experiments
-    const dim3 gr(pp_tiles), bl(512);
-    if (g_gemm_variant == 11) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, false>), gr, bl, 2 * P_STAGE, st, a);
-    else if (g_gemm_variant == 12) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, false>), gr, bl, 2 * P_STAGE, st, a);
-    else if (g_gemm_variant == 13) hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 16>), gr, bl, 2 * P_STAGE, st, a);
-    else hipLaunchKernelGGL((gemm_nt_pp_kernel<false, true, true, 4>), gr, bl, 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
   if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
     hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if ((g_gemm_variant == 8 || g_gemm_variant == 9) && pp_tiles > 0) {
-    const int pt = pp_tiles;
-    if (g_gemm_variant != 9) hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
-    else hipLaunchKernelGGL(gemm_nt_pp_kernel<true>, dim3(pt), dim3(512), 2 * P_STAGE, st, a);
+  if (g_gemm_variant == 8 && pp_tiles > 0) {      // 8-wave ping-pong kernel
+    hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (g_gemm_variant >= 4) {
-    const int tiles_x = ((a.M + BM - 1) / BM) * (a.N / BN);
-    if (g_gemm_variant == 4) hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
-    else if (g_gemm_variant == 5) hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
-    else if (g_gemm_variant == 6) hipLaunchKernelGGL((gemm_nt_kernel_x<32, true, 3>), dim3(tiles_x), dim3(256), 32768, st, a);
-    else if (g_gemm_variant == 7) hipLaunchKernelGGL((gemm_nt_kernel_x<32, false, 4>), dim3(tiles_x), dim3(256), 32768, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 3 && a.N % R_BN == 0) {
-    const int rt = ((a.M + R_BM - 1) / R_BM) * (a.N / R_BN);
-    hipLaunchKernelGGL(gemm_nt_ring_kernel, dim3(rt), dim3(256), R_STAGES * R_ST_BYTES, st, a);
-    return hipGetLastError();
-  }
-  const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-  if (g_gemm_variant == 2)
-    hipLaunchKernelGGL((gemm_nt_kernel<true, true>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
-  else if (g_gemm_variant == 1)
-    hipLaunchKernelGGL((gemm_nt_kernel<true, false>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<false, false>), dim3(tiles), dim3(256), 2 * STAGE_BYTES, st, a);
+  const int tiles_x = ((a.M + BM - 1) / BM) * (a.N / BN);      // everything else (and variant 4): the 128x128 kernel
+  hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(tiles_x), dim3(256), 65536, st, a);
   return hipGetLastError();
 }
 

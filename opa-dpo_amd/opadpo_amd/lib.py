@@ -96,8 +96,7 @@ def load() -> C.CDLL:
 def set_flags(use_glds=10, use_tr: bool = True) -> None:
     """gemm_nt variant: 10 (default) auto = 4-wave 256x256 long-lead kernel (w4<12>) from 320 blocks or when one round fills
     >= 88 % of the CUs, 128x128 kernel otherwise (bias / activation problems: 8-wave kernel from 320 blocks);
-    0-9 earlier kernels (0 register staging, 1/2 LDS-DMA 16x16x32 / 32x32x16, 3 three-stage ring, 4 128x128 + s_setprio,
-    5-7 BK=32, 8/9 256x256 ping-pong), 11-14 ping-pong schedule experiments, 15 force the M <= 64 streaming kernel,
+    4 the 128x128 kernel everywhere, 8 the 8-wave ping-pong kernel, 15 force the M <= 64 streaming kernel,
     16 w4 single-barrier schedule, 17 8-wave 4-phase kernel (p8), 23 / 24 long lead with the builtin DMA (with / without an MFMA
     between wait and barrier), 27 stamped diagnostic (summary on stderr, synchronous), 28 register-staged operands,
     29 32x32x16 MFMA, 31 = the default large-GEMM kernel forced.  True -> default.

@@ -41,7 +41,7 @@ def maxabs(got, want):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("glds", [31, 29, 28, 23, 17, 16, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize("glds", [31, 29, 28, 24, 23, 17, 16, 10, 8, 4])
 @pytest.mark.parametrize("M,N,K1,K2,groups", [(300, 256, 128, 0, 0), (1, 128, 64, 0, 0), (129, 384, 192, 128, 3),
                                               (1000, 1024, 512, 128, 2), (257, 128, 64, 64, 1), (515, 768, 64, 64, 3),
                                               (2, 256, 4096, 0, 0), (131, 512, 64 * 3, 64, 2), (700, 512, 64, 0, 0), (513, 256, 128, 128, 1)])
@@ -162,7 +162,7 @@ def test_gemm_nt_256_kernels_race_screen(L):
     assert relerr(outs[17], want) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 8, 9, 16, 17, 23, 10])
+@pytest.mark.parametrize("variant", [4, 8, 16, 17, 23, 10])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):
     L.set_flags(variant, True)

@@ -135,7 +135,7 @@ def main():
         json.dump(res, open(os.path.join(REPO, "gpurun_out", "gemm_skinny.json"), "w"), indent=1)
         return
     if only == "pmc":      # few launches of the two big shapes, default variant only (PMC passes serialize kernels)
-        L.set_flags(int(os.environ.get("GB_VARIANT", 1)), True)
+        L.set_flags(int(os.environ.get("GB_VARIANT", 10)), True)
         for name, N, K1, K2, grp in shapes[:2]:
             a1 = torch.randn(M, K1, device=dev).to(BF)
             b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
@@ -148,7 +148,7 @@ def main():
         torch.cuda.synchronize()
         return
     vlist = [int(v) for v in os.environ["GB_VARIANTS"].split(",")] if (only == "gemm" and os.environ.get("GB_VARIANTS")) else None
-    for glds in (vlist if vlist else ((8, 4, 3, 2, 1, 0) if not only else ((9, 8, 4) if only == "gemm" else ((8, 9, 8, 9) if only == "pp" else ())))):
+    for glds in (vlist if vlist else ((31, 17, 8, 4) if not only else ((31, 17, 8, 4) if only == "gemm" else ((8, 17, 8, 17) if only == "pp" else ())))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
