@@ -345,25 +345,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-// delta[s,h,pos] = sum_d dO * O
+// delta[s,h,pos] = sum_d dO * O.  HD/8 lanes per (row, head), 16 bytes of dO and of O per lane (a wave covers 64 / (HD/8) heads of
+// one row: 512 contiguous bytes per operand at HD = 128), shuffle reduction inside the lane group.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (row, head)
+  constexpr int LPH = HD / 8;                               // lanes per head: 16 (hd 128) or 8 (hd 64)
+  constexpr int HPW = 64 / LPH;                             // heads per wave
   const int lane = threadIdx.x & 63;
-  const int total = p.S * p.L * p.nh;
-  if (idx >= total) return;
-  const int row = idx / p.nh, h = idx % p.nh;
+  const size_t unit = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HPW + lane / LPH;      // (row, head) index
+  const size_t total = (size_t)p.S * p.L * p.nh;
+  const bool live = unit < total;
+  const size_t row = live ? unit / p.nh : 0;
+  const int h = live ? (int)(unit % p.nh) : 0, i0 = (lane % LPH) * 8;
   float acc = 0.f;
-  if (lane < HD / 2) {
-    const uint32_t a = *(const uint32_t*)(p.dout + (size_t)row * p.ldo + h * HD + lane * 2);
-    const uint32_t b = *(const uint32_t*)(p.o + (size_t)row * p.ldo + h * HD + lane * 2);
-    acc = __uint_as_float(a << 16) * __uint_as_float(b << 16) +
-          __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+  if (live) {
+    float a[8], b[8];
+    unpack8(*(const uint4*)(p.dout + row * p.ldo + h * HD + i0), a);
+    unpack8(*(const uint4*)(p.o + row * p.ldo + h * HD + i0), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a[j] * b[j];
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    const int s = row / p.L, pos = row % p.L;
-    p.delta[((size_t)s * p.nh + h) * p.L + pos] = acc;
+#pragma unroll
+  for (int off = LPH / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (live && lane % LPH == 0) {
+    const size_t sq = row / p.L, pos = row % p.L;
+    p.delta[(sq * p.nh + h) * p.L + pos] = acc;
   }
 }
 
@@ -676,7 +682,7 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   }
   if ((double)a.L * a.ld * 2 >= 2.0e9 || (double)a.L * a.ldo * 2 >= 2.0e9) return hipErrorInvalidValue;   // 32-bit buffer extents
 #define LAUNCH_BWD(HD_, TR_)                                                                              \
-  hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((total + 3) / 4), dim3(256), 0, st, a);               \
+  hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((unsigned)((total + 4 * (512 / HD_) - 1) / (4 * (512 / HD_)))), dim3(256), 0, st, a); \
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 4 * 64 * HD_ * 2 + 1024 + 80, st, a); \
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
   if (a.hd == 128) {
