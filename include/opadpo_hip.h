@@ -134,6 +134,9 @@ int opadpo_scatter_rows(const uint16_t* src, const int32_t* rows_idx, uint16_t* 
 /* dst[rows_idx[r], :H] += src[r, :H] (fp32; duplicate indices accumulate) */
 int opadpo_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, void* stream);
 int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream);
+/* n_jobs transposes in one launch: jobs[j] = {src offset, dst offset, rows, cols} (elements, device memory, int64); max_tiles =
+ * max over jobs of ceil(rows/64)*ceil(cols/64).  Used for the K-major copies of all LoRA blocks after an optimizer step. */
+int opadpo_transpose_batched(const uint16_t* src, uint16_t* dst, const int64_t* jobs, int n_jobs, int max_tiles, void* stream);
 int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream);
 int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream);
 

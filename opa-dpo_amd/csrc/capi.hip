@@ -172,6 +172,10 @@ int opadpo_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float
 int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stream) {
   return done(launch_transpose(in, out, R, C, S(stream)), "opadpo_transpose");
 }
+int opadpo_transpose_batched(const uint16_t* src, uint16_t* dst, const int64_t* jobs, int n_jobs, int max_tiles, void* stream) {
+  if (n_jobs > 0 && (!src || !dst || !jobs)) return bad("opadpo_transpose_batched", "null operand");
+  return done(launch_transpose_batched(src, dst, (const long long*)jobs, n_jobs, max_tiles, S(stream)), "opadpo_transpose_batched");
+}
 int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream) {
   return done(launch_f32_to_bf16(in, out, n, S(stream)), "opadpo_f32_to_bf16");
 }

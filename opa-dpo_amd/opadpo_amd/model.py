@@ -175,13 +175,15 @@ class LoraAdapter:
             self.grad = torch.zeros_like(self.master)
             self.work = self.master.to(BF)
             self.work_t = torch.empty_like(self.work)
-            self.refresh_transposed()
+            self._tjobs = None
         else:
             self.master = None
             self.grad = None
             self.work = flat.to(device=device, dtype=BF)
             self.work_t = None
         self.merged: Optional[List[Dict[str, torch.Tensor]]] = None      # frozen adapters only, see merge_into_base()
+        if trainable:
+            self.refresh_transposed()
 
     def merge_into_base(self, base: "BaseWeights") -> None:
         """FROZEN adapter (the reference policy): fold s * B @ A into a second bf16 copy of the projection weights, once, at
@@ -237,21 +239,19 @@ class LoraAdapter:
         return self.work_t[off: off + rows * cols].view(groups, r, rows // groups)
 
     def refresh_transposed(self) -> None:
-        """Re-derive the transposed bf16 copies after an optimizer step (HIP transpose kernel)."""
-        st = L.stream()
-        for lo in self.offsets:
-            for name, (off, rows, cols) in lo.items():
-                src = self.work[off: off + rows * cols]
-                dst = self.work_t[off: off + rows * cols]
-                if name.startswith("a_"):
-                    L.call("opadpo_transpose", L.ptr(src), L.ptr(dst), rows, cols, st)
-                else:
-                    groups = {"b_qkv": 3, "b_gu": 2}.get(name, 1)
+        """Re-derive the transposed bf16 copies after an optimizer step: ONE batched launch over all blocks of all layers."""
+        if self._tjobs is None:
+            jobs, mt = [], 0
+            for lo in self.offsets:
+                for name, (off, rows, cols) in lo.items():
+                    groups = 1 if name.startswith("a_") else {"b_qkv": 3, "b_gu": 2}.get(name, 1)
                     per = rows // groups
                     for gi in range(groups):
-                        s_ = src[gi * per * cols: (gi + 1) * per * cols]
-                        d_ = dst[gi * per * cols: (gi + 1) * per * cols]
-                        L.call("opadpo_transpose", L.ptr(s_), L.ptr(d_), per, cols, st)
+                        jobs.append([off + gi * per * cols, off + gi * per * cols, per, cols])
+                        mt = max(mt, ((per + 63) // 64) * ((cols + 63) // 64))
+            self._tjobs = (torch.tensor(jobs, dtype=torch.int64, device=self.device), len(jobs), mt)
+        tj, n, mt = self._tjobs
+        L.call("opadpo_transpose_batched", L.ptr(self.work), L.ptr(self.work_t), L.ptr(tj), n, mt, L.stream())
 
     def to_peft_state(self) -> Dict[str, torch.Tensor]:
         """PEFT-0.5 key layout, bf16 like the reference's saved adapters."""
