@@ -188,6 +188,24 @@ struct SegSkip {       // block-uniform: K/V tiles [lo, hi) are excluded for eve
 // ------------------------------------------------------------------------------------------------
 // DMA: K/V tiles land in a double-buffered LDS ring through direct-to-LDS loads, one barrier per tile (the tile of the
 // next iteration is in flight while this one is consumed); !DMA: register-staged single buffer, two barriers per tile.
+// 1-D grid -> (tile, head, sequence).  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): with the plain
+// (tile, head, sequence) order the tiles of one (sequence, head) land on all 8 XCDs and its K / V (or Q / dO) stream is pulled into
+// 8 L2s.  Here the j-th block of an XCD walks the tiles of ONE (sequence, head) pair before the next pair: every pair is read by
+// one L2.  Needs nh * S to be a multiple of 8 (else the plain order).
+__device__ __forceinline__ void attn_block_map(const AttnArgs& p, int n_tiles, int& tile, int& h, int& s) {
+  const int b = blockIdx.x, pairs = p.nh * p.S;
+  int pair, t;
+  if (pairs % 8 == 0) {
+    const int xcd = b & 7, j = b >> 3;
+    pair = xcd + 8 * (j / n_tiles);
+    t = j % n_tiles;
+  } else {
+    pair = b / n_tiles;
+    t = b % n_tiles;
+  }
+  tile = t; h = pair % p.nh; s = pair / p.nh;
+}
+
 template <int HD, bool TR, bool DMA>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,8 +214,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   constexpr int KK = HD / 32, DF = HD / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int s = blockIdx.z, h = blockIdx.y;
-  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;   // heavier (later) causal tiles first
+  const int n_qt = (p.L + 63) / 64;
+  int s, h, qi;
+  attn_block_map(p, n_qt, qi, h, s);
+  const int qt = n_qt - 1 - qi;   // heavier (later) causal tiles first
   const int q0 = qt * 64;
   const int L = p.L;
   const int qpos = q0 + w * 16 + c;
@@ -385,7 +405,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   uint8_t* Ms = (uint8_t*)(ls_base + 256);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int s = blockIdx.z, h = blockIdx.y, kt = blockIdx.x;
+  int s, h, kt;
+  attn_block_map(p, (p.L + 63) / 64, kt, h, s);
   const int L = p.L;
   const int k0 = kt * 64;
   const int kpos = k0 + w * 16 + c;          // this lane's key (as fragment row / output row)
@@ -528,8 +549,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   constexpr int KK = HD / 32, DF = HD / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int s = blockIdx.z, h = blockIdx.y;
-  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int n_qt = (p.L + 63) / 64;
+  int s, h, qi;
+  attn_block_map(p, n_qt, qi, h, s);
+  const int qt = n_qt - 1 - qi;
   const int q0 = qt * 64;
   const int L = p.L;
   const int qpos = q0 + w * 16 + c;
@@ -647,7 +670,7 @@ void opadpo_set_attn_dma(bool on) { g_attn_dma = on; }
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
-  const dim3 grid((a.L + 63) / 64, a.nh, a.S);
+  const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
   const bool tr = opadpo_flag_tr();
   const bool dma = g_attn_dma && (double)a.L * a.ld * 2 < 2.0e9;     // per-sequence extent must fit the 32-bit descriptor
   static bool attr_set = false;
@@ -672,7 +695,7 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   const int total = a.S * a.L * a.nh;
-  const dim3 grid((a.L + 63) / 64, a.nh, a.S);
+  const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
   const bool tr = opadpo_flag_tr();
   static bool attr_set = false;
   if (!attr_set) {
