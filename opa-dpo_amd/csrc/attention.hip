@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
           const int ql = qf * 16 + g * 4 + r;
           const int qp = q0 + ql;
           const bool ok = key_ok & (qp < L) & (!p.causal | (kpos <= qp)) & (qp < kend);      // bitwise: no branch per term
-          const float pv = fast_exp2(ok ? sc[qf][r] * scale2 - lse_s[ql] : -INFINITY);
+          const float arg = sc[qf][r] * scale2 - lse_s[ql];                                   // LDS read outside the select: no branch
+          const float pv = fast_exp2(ok ? arg : -INFINITY);
           sc[qf][r] = pv;
           dp[qf][r] = pv * (dp[qf][r] - dlt_s[ql]) * p.scale;
         }
