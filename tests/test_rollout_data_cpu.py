@@ -1,0 +1,97 @@
+"""Rollout query construction - host logic on the toy tokenizer.  The template / placeholder tokenisation
+are restated from the absent third-party `llava` package (parity unpinned, see the module header); these tests pin the layout
+the reference's own files state: the hard-coded template of utils/data_utils_dpo.py:291-292 and the padding / filtering rules of
+utils/data_utils_online_gpt4v.py:41-173."""
+import io
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "opa-dpo_amd"))
+sys.path.insert(0, os.path.dirname(__file__))
+from opadpo_amd import rollout_data as rd          # noqa: E402
+from opadpo_amd.data import QUERY_TEMPLATE_HEAD, QUERY_TEMPLATE_TAIL      # noqa: E402
+from toy_tokenizer import ToyTokenizer            # noqa: E402
+
+
+def _png(color):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.new("RGB", (6, 4), color).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def _rows():
+    return [
+        {"question": "what is on the mat ?", "chosen": "a cat sits there", "image": {"bytes": _png((255, 0, 0)), "path": "a.png"}},
+        {"question": "describe <image> the scene in detail please now", "chosen": "two dogs", "image": {"bytes": _png((0, 255, 0)), "path": "b.png"}},
+        {"question": " ".join(["long"] * 80), "chosen": "too long", "image": {"bytes": _png((0, 0, 255)), "path": "c.png"}},
+        {"question": "last one ?", "chosen": "yes it is the last one indeed", "image": {"bytes": _png((9, 9, 9)), "path": "d.png"}},
+    ]
+
+
+def test_template_matches_the_reference_hard_coded_copy():
+    # data_utils_dpo.py:291-292 spells the same template out as '<s> ' + system + ' USER: ' ... ' ASSISTANT: '
+    conv = [{"from": "human", "value": "Q"}, {"from": "gpt", "value": None}]
+    assert "<s> " + rd.render_prompt(conv) == QUERY_TEMPLATE_HEAD + "Q" + QUERY_TEMPLATE_TAIL.rstrip(" ")
+    full = rd.render_prompt(rd.form_conversation("Q", "A"))
+    assert full == rd.SYSTEM + " USER: <image>\nQ ASSISTANT: A</s>"
+    with pytest.raises(AssertionError):
+        rd.render_prompt([{"from": "human", "value": "x"}, {"from": "human", "value": "y"}])
+    # a leading non-human turn is skipped
+    assert rd.render_prompt([{"from": "gpt", "value": "hi"}] + rd.form_conversation("Q", "A")) == full
+
+
+def test_placeholder_moves_to_the_front_and_tokenises_once():
+    conv = rd.move_image_placeholder_first(rd.form_conversation("describe <image> the scene", "ok"))
+    assert conv[0]["value"] == "<image>\ndescribe  the scene"          # both placeholders removed, one re-added in front
+    assert conv[0]["value"].count("<image>") == 1 and conv[0]["value"].startswith("<image>\n")
+    tok = ToyTokenizer()
+    ids = rd.tokenize_with_image("a b <image> c d", tok)
+    assert ids[0] == tok.bos_token_id and ids.count(tok.bos_token_id) == 1
+    assert ids.count(rd.IMAGE_TOKEN_INDEX) == 1 and ids.index(rd.IMAGE_TOKEN_INDEX) == 3
+    assert ids == tok._encode("a b") + [rd.IMAGE_TOKEN_INDEX] + tok._encode("c d")[1:]
+    assert rd.tokenize_with_image("no image here", tok) == tok._encode("no image here")
+
+
+def test_dataset_layout_filter_and_padding():
+    tok = ToyTokenizer()
+    logs = []
+    ds = rd.QueryResponseDataset(_rows(), tok, query_len=48, image_size=8, log=logs.append)
+    assert len(ds) == 3 and any("Filtered out 1 instances out of 4" in m for m in logs)
+    assert ds.queries.shape == (3, 48) and ds.query_attn_masks.dtype == torch.long
+    for i, src in enumerate([0, 1, 3]):
+        q = rd.build_query_ids(_rows()[src]["question"], _rows()[src]["chosen"], tok)
+        n = q.numel()
+        assert torch.equal(ds.queries[i, -n:], q) and bool((ds.queries[i, :-n] == tok.pad_token_id).all())      # left padded
+        assert int(ds.query_attn_masks[i].sum()) == n
+        assert int((ds.queries[i] == rd.IMAGE_TOKEN_INDEX).sum()) == 1
+        r = torch.tensor(tok._encode(_rows()[src]["chosen"])[1:] + [tok.eos_token_id])
+        assert torch.equal(ds.standard_responses[i, :r.numel()], r)                                               # no BOS, EOS appended
+        assert bool((ds.standard_responses[i, r.numel():] == tok.pad_token_id).all())                             # right padded
+    assert ds.standard_responses.shape[1] == 8          # longest answer (7 words) + EOS
+    # the prompt ends where the answer starts: the full templated prompt minus its last three tokens
+    conv = rd.move_image_placeholder_first(rd.form_conversation("what is on the mat ?", "x"))
+    conv[-1]["value"] = "\n"
+    full = rd.tokenize_with_image(rd.render_prompt(conv), tok)
+    assert rd.build_query_ids("what is on the mat ?", "x", tok).tolist() == full[:-3]
+    with pytest.raises(ValueError):
+        rd.QueryResponseDataset(_rows()[2:3], tok, query_len=48, log=lambda *_: None)
+
+
+def test_items_and_collation():
+    tok = ToyTokenizer()
+    mod = rd.make_rollout_data_module(tok, data_path="", query_len=48, image_size=8, rows=_rows())
+    ds, collate = mod["train_dataset"], mod["data_collator"]
+    assert mod["eval_dataset"] is None
+    batch = collate([ds[0], ds[1]])
+    assert batch["queries"].shape == (2, 48) and batch["images"].shape == (2, 3, 8, 8)
+    assert batch["images_path"] == ["a.png", "b.png"] and batch["images_bytes"][0] == _rows()[0]["image"]["bytes"]
+    assert batch["images_url"][1].startswith("data:image/jpeg;base64,")
+    # quirk kept (data_utils_online_gpt4v.py:127): records are not filtered, index 2 still points at the dropped row's image
+    assert ds[2]["images_path"] == "c.png"
+    with pytest.raises(ValueError):
+        bad = _rows(); bad[0]["image"]["bytes"] = b"not an image"
+        rd.QueryResponseDataset(bad, tok, query_len=48, image_size=8, log=lambda *_: None)[0]
