@@ -306,6 +306,33 @@ def test_eval_generation_from_checkpoint(setup, tmp_path):
                 assert all(t == 0 for t in row[row.index(2) + 1:])
 
 
+def test_online_rollout_step_on_the_decode_kernels(setup):
+    """online_generate.rollout_step over the HIP sampler: the response column is the decoded, EOS-cut output of Generator.rollout
+    for the same seed (first batch -> seed + 1), one record per prompt, standard responses decoded without specials."""
+    s = setup
+    from opadpo_amd import online_generate as og
+    from opadpo_amd.generate import Generator
+    d = s["d"]
+    images, queries, qmask, resp = make_inputs(d, 2, 12, 9, seed=55)
+
+    class Tok:
+        pad_token_id, eos_token_id, bos_token_id = 0, 2, 1
+
+        def batch_decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=True):
+            return [" ".join(str(int(t)) for t in row if int(t) > 2) for row in ids]
+
+    batch = dict(queries=queries, query_attn_masks=qmask.long(), images=images.to(BF), standard_responses=resp["standard_response"],
+                 images_path=["p0", "p1"], images_url=["data:image/jpeg;base64,AA==", "data:image/jpeg;base64,AQ=="], images_bytes=[b"\0", b"\1"])
+    gen = Generator(s["eng"], s["ref"])
+    out = og.rollout_step([batch], Tok(), og.generator_sampler(gen, response_len=8, temperature=0.8, top_k=10, top_p=0.9, seed=6))
+    want = gen.rollout(queries.to(s["dev"]), qmask.to(s["dev"]), images.to(BF).to(s["dev"]), response_len=8, temperature=0.8, top_k=10,
+                       top_p=0.9, seed=7, additional_stop_ids=og.QUESTION_MARK_IDS).cpu()
+    assert out["original_generate_response"] == Tok().batch_decode(want)
+    assert out["standard_response"] == Tok().batch_decode(resp["standard_response"])
+    assert out["image_id"] == ["p0", "p1"] and out["image_bytes"] == [b"\0", b"\1"] and out["AI_json_report"] == ["", ""]
+    assert all(len(v) == 2 for v in out.values())
+
+
 def test_vision_projector_lora_backward(setup):
     """OPA LoRA-SFT groundwork: CLIP + mm_projector with TRAINABLE LoRA (unmerged), forward features and the gradients of
     every vision / projector LoRA block against fp32 autograd through the oracle."""

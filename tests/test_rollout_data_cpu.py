@@ -95,3 +95,45 @@ def test_items_and_collation():
     with pytest.raises(ValueError):
         bad = _rows(); bad[0]["image"]["bytes"] = b"not an image"
         rd.QueryResponseDataset(bad, tok, query_len=48, image_size=8, log=lambda *_: None)[0]
+
+
+def test_rollout_step_columns_and_dataset_round_trip(tmp_path):
+    """rollout_step -> write_rollout_json -> build_rows: the eight columns of online_generator.py:352-362 survive the wire."""
+    from opadpo_amd import online_generate as og
+    from opadpo_amd.dataset_build import build_rows, write_rollout_json
+    assert og.query_text("SYS USER:  \nwhat is it ? ASSISTANT:") == "what is it ?"
+    assert og.query_text("no markers") == "no markers"[7:-1]                       # str.find == -1 on both sides, like the reference
+    tok = ToyTokenizer()
+    ds = rd.QueryResponseDataset(_rows(), tok, query_len=48, image_size=8, log=lambda *_: None)
+    batches = [rd.collate_query_response([ds[0], ds[1]]), rd.collate_query_response([ds[2]])]
+    canned = ["the cat is red . it sleeps .", "two dogs run .", "yes ."]
+    seen = []
+
+    def sample(q, m, img):
+        assert q.shape[1] == 48 and img.shape[1:] == (3, 8, 8) and torch.equal(m, q.ne(0).long())
+        rows = [tok._encode(canned[len(seen) + i])[1:] + [tok.eos_token_id] for i in range(q.shape[0])]
+        seen.extend(rows)
+        w = max(len(r) for r in rows)
+        return torch.tensor([r + [0] * (w - len(r)) for r in rows])
+
+    def feedback(urls, queries, responses, standard):
+        assert all(u.startswith("data:image/jpeg;base64,") for u in urls)
+        return {"Pseudo_response": [r + " (fixed)" for r in responses], "Generated_response": list(responses),
+                "report_json": [{"Sentence 1": {"score": 4}} for _ in responses]}
+
+    out = og.rollout_step(batches, tok, sample, feedback)
+    assert list(out) == ["query", "image_id", "standard_response", "original_generate_response", "AI_generate_response",
+                         "AI_pseudo_response", "AI_json_report", "image_bytes"]
+    assert all(len(v) == 3 for v in out.values())
+    assert out["original_generate_response"] == canned and out["standard_response"][0] == "a cat sits there"
+    assert out["image_id"] == ["a.png", "b.png", "c.png"] and all(q.startswith("<image>\n") for q in out["query"])
+    path = write_rollout_json(str(tmp_path), 0, out, rank=0)
+    rows = build_rows([os.path.dirname(path)], log=lambda *_: None)
+    assert len(rows) == 3 and rows[1]["AI_pseudo_response"] == "two dogs run . (fixed)"
+    # without a feedback model every record is dropped by the builder's first filter
+    out2 = og.rollout_step(batches[:1], tok, lambda q, m, i: torch.tensor([[5, 2], [6, 2]]))
+    p2 = write_rollout_json(str(tmp_path / "nofb"), 0, out2, rank=0)
+    assert build_rows([os.path.dirname(p2)], log=lambda *_: None) == []
+    with pytest.raises(ValueError):
+        og.rollout_step(batches[:1], tok, lambda q, m, i: torch.tensor([[5, 2], [6, 2]]),
+                        lambda *a: {"Pseudo_response": [""], "Generated_response": [""], "report_json": [""]})

@@ -25,6 +25,11 @@ class ToyTokenizer:
             ids.append(self.vocab[w])
         return ids
 
+    def batch_decode(self, ids, skip_special_tokens=True, clean_up_tokenization_spaces=True):
+        words = {v: k for k, v in self.vocab.items()}
+        special = {self.pad_token_id, self.eos_token_id, self.bos_token_id} if skip_special_tokens else set()
+        return [" ".join(words.get(int(t), f"<{int(t)}>") for t in row if int(t) not in special) for row in ids]
+
     def __call__(self, text, padding=None, truncation=False, max_length=None, return_tensors=None):
         single = isinstance(text, str)
         rows = [self._encode(t) for t in ([text] if single else text)]
