@@ -39,3 +39,58 @@ def generate_from_checkpoint(engine: LlavaEngine, checkpoint: Optional[str], que
     else:
         out = gen.generate(queries, query_attn_masks, images, max_new_tokens=max_new_tokens, temperature=1.0, top_k=1, top_p=1.0, seed=seed)
     return truncate_after_eos_with_padding(out, EOS_ID, PAD_ID)
+
+
+# ---- question file -> answers file (the text side of eval_llava_rlhf_coco/model_vqa.py:33-44,143-262) -----------------------
+DEFAULT_TEST_PROMPT = "\nAnswer the question using a single word or phrase."
+
+
+def question_chunk(questions: list, num_chunks: int, chunk_idx: int) -> list:
+    """Chunk k of n, chunks of ceil(len / n) questions (model_vqa.py:33-42; an index past the last chunk raises IndexError)."""
+    size = -(-len(questions) // num_chunks)
+    return [questions[i:i + size] for i in range(0, len(questions), size)][chunk_idx]
+
+
+def eval_prompt(question: str, test_prompt: Optional[str] = DEFAULT_TEST_PROMPT) -> str:
+    """'<image>\\n' + question (+ test prompt) as the USER turn, ASSISTANT turn left open (model_vqa.py:153-170)."""
+    from .rollout_data import IMAGE_PLACEHOLDER, render_prompt
+    text = IMAGE_PLACEHOLDER + "\n" + question + (test_prompt or "")
+    return render_prompt([{"from": "human", "value": text}, {"from": "gpt", "value": None}])
+
+
+def answer_questions(engine: LlavaEngine, tokenizer, questions: list, image_folder: str, answers_file: str, *,
+                     checkpoint: Optional[str] = None, adapter: Optional[LoraAdapter] = None, model_id: str = "opadpo-hip",
+                     temperature: float = 0.0, top_p: Optional[float] = None, short_eval: bool = False, max_new_tokens: Optional[int] = None,
+                     test_prompt: Optional[str] = DEFAULT_TEST_PROMPT, image_size: int = 336, pad_to_square: bool = True, seed: int = 0) -> int:
+    """One JSON line per question: question_id, prompt (the bare question), text (stripped answer, a trailing '</s>' removed),
+    answer_id, model_id, metadata (model_vqa.py:143-262).  Refuses to overwrite an existing answers file like the script's
+    __main__.  max_new_tokens defaults to 64 (`short_eval`) or 1024."""
+    import json
+    import uuid
+    from PIL import Image
+    from .data import preprocess_image
+    from .rollout_data import SEP2, tokenize_with_image
+    if os.path.exists(answers_file):
+        raise FileExistsError(f"{answers_file} already exists. Please delete it first.")
+    if adapter is None and checkpoint is not None:
+        adapter = LoraAdapter(engine.d, load_adapter(adapter_dir_of(checkpoint)), engine.dev, trainable=False)
+    n_new = max_new_tokens or (64 if short_eval else 1024)
+    parent = os.path.dirname(answers_file)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    n = 0
+    with open(answers_file, "w") as f:
+        for line in questions:
+            ids = torch.tensor([tokenize_with_image(eval_prompt(line["text"], test_prompt), tokenizer)], dtype=torch.long)
+            pil = Image.open(os.path.join(image_folder, line["image"])).convert("RGB")
+            image = preprocess_image(pil, image_size, pad_to_square)[None].to(engine.dev)
+            out = generate_from_checkpoint(engine, None, ids.to(engine.dev), torch.ones_like(ids).to(engine.dev), image, max_new_tokens=n_new,
+                                           temperature=temperature, top_p=1.0 if top_p is None else top_p, seed=seed + n, adapter=adapter)
+            text = tokenizer.batch_decode(out.cpu(), skip_special_tokens=True)[0].strip()
+            if text.endswith(SEP2):
+                text = text[:-len(SEP2)]
+            f.write(json.dumps({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(),
+                                "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}}) + "\n")
+            f.flush()
+            n += 1
+    return n

@@ -333,6 +333,43 @@ def test_online_rollout_step_on_the_decode_kernels(setup):
     assert all(len(v) == 2 for v in out.values())
 
 
+def test_eval_question_file_to_answers_file(setup, tmp_path):
+    """answer_questions (model_vqa.py:143-262): one answer line per question, text = decoded greedy generation of the same
+    prompt ids through generate_from_checkpoint, existing answers file refused."""
+    s = setup
+    from PIL import Image
+    from opadpo_amd import eval_generate as eg
+    from opadpo_amd.data import preprocess_image
+    from opadpo_amd.rollout_data import tokenize_with_image
+    d = s["d"]
+
+    class Tok:
+        pad_token_id, eos_token_id, bos_token_id = 0, 2, 1
+
+        def __call__(self, text):
+            return {"input_ids": [1] + [3 + sum(ord(c) * (i + 1) for i, c in enumerate(w)) % (d.vocab - 3) for w in text.split()]}
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(f"w{int(t)}" for t in row if int(t) > 2) for row in ids]
+
+    Image.new("RGB", (10, 6), (200, 30, 30)).save(tmp_path / "a.png")
+    Image.new("RGB", (5, 9), (10, 200, 30)).save(tmp_path / "b.png")
+    qs = [{"question_id": 7, "image": "a.png", "text": "what colour is it ?"}, {"question_id": 9, "image": "b.png", "text": "is it tall ?"}]
+    ans = tmp_path / "out" / "answers.jsonl"
+    n = eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans), adapter=s["pol"], max_new_tokens=6, image_size=d.image_size)
+    lines = [json.loads(x) for x in open(ans)]
+    assert n == 2 and [x["question_id"] for x in lines] == [7, 9] and lines[0]["prompt"] == qs[0]["text"]
+    assert set(lines[0]) == {"question_id", "prompt", "text", "answer_id", "model_id", "metadata"} and lines[0]["answer_id"] != lines[1]["answer_id"]
+    for q, line in zip(qs, lines):
+        ids = torch.tensor([tokenize_with_image(eg.eval_prompt(q["text"]), Tok())])
+        assert int((ids == -200).sum()) == 1
+        img = preprocess_image(Image.open(tmp_path / q["image"]).convert("RGB"), d.image_size, True)[None].to(s["dev"])
+        want = eg.generate_from_checkpoint(s["eng"], None, ids.to(s["dev"]), torch.ones_like(ids).to(s["dev"]), img, max_new_tokens=6, adapter=s["pol"])
+        assert line["text"] == Tok().batch_decode(want.cpu())[0].strip()
+    with pytest.raises(FileExistsError):
+        eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans), adapter=s["pol"], max_new_tokens=6, image_size=d.image_size)
+
+
 def test_vision_projector_lora_backward(setup):
     """OPA LoRA-SFT groundwork: CLIP + mm_projector with TRAINABLE LoRA (unmerged), forward features and the gradients of
     every vision / projector LoRA block against fp32 autograd through the oracle."""

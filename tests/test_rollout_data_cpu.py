@@ -137,3 +137,16 @@ def test_rollout_step_columns_and_dataset_round_trip(tmp_path):
     with pytest.raises(ValueError):
         og.rollout_step(batches[:1], tok, lambda q, m, i: torch.tensor([[5, 2], [6, 2]]),
                         lambda *a: {"Pseudo_response": [""], "Generated_response": [""], "report_json": [""]})
+
+
+def test_eval_prompt_and_question_chunks():
+    """Text side of eval_llava_rlhf_coco/model_vqa.py:33-44,153-170 (no GPU: the module is imported, nothing is launched)."""
+    from opadpo_amd import eval_generate as eg
+    p = eg.eval_prompt("is there a dog ?")
+    assert p == rd.SYSTEM + " USER: <image>\nis there a dog ?\nAnswer the question using a single word or phrase. ASSISTANT:"
+    assert eg.eval_prompt("Q", None).endswith("USER: <image>\nQ ASSISTANT:")
+    qs = list(range(10))
+    assert eg.question_chunk(qs, 3, 0) == [0, 1, 2, 3] and eg.question_chunk(qs, 3, 2) == [8, 9] and eg.question_chunk(qs, 1, 0) == qs
+    assert sum((eg.question_chunk(qs, 4, k) for k in range(4)), []) == qs
+    with pytest.raises(IndexError):
+        eg.question_chunk(list(range(4)), 3, 2)          # ceil(4/3) = 2 -> only two chunks exist
