@@ -1539,12 +1539,17 @@ constexpr int TK = 64;  // rows (m) per LDS stage
 //   * the 8 partial accumulators meet in LDS (NR*MF KiB per wave), one barrier.
 // The LoRA tail ([x|t].[W|B]^T) is a second K segment, split over the waves the same way.
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-template <int MF, int NR, int U>
+// SW (fused SwiGLU, OPADPO_ACT_SWIGLU_PAIR): the weight rows come in groups of 128 = [64 gate | 64 up]; a workgroup takes 16
+// gate rows and the 16 up rows 64 further (NR = 2), so after the reduction a lane holds gate and up of the same 4 output
+// columns: act = silu(gate) * up on the bf16-rounded values (same formula as silu_mul_fwd_kernel), N/2 output columns.
+template <int MF, int NR, int U, bool SW = false>
 __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
+  static_assert(!SW || NR == 2, "SwiGLU pairs: one gate + one up fragment per workgroup");
   __shared__ __attribute__((aligned(16))) float red[8][NR * MF][64][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * (16 * NR);
+  const int n0 = SW ? (blockIdx.x >> 2) * 128 + (blockIdx.x & 3) * 16 : blockIdx.x * (16 * NR);
+  constexpr int RSTEP = SW ? 64 : 16;          // weight rows between the fragments of a workgroup
   const int r = lane & 15, c = lane >> 4;
 
   const bf16_t* a1 = p.A1;
@@ -1565,7 +1570,7 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
     const bf16_t* wp[NR];
     const bf16_t* xp[MF];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) wp[i] = B + (size_t)(n0 + i * 16 + r) * ldb + c * 8;
+    for (int i = 0; i < NR; ++i) wp[i] = B + (size_t)(n0 + i * RSTEP + r) * ldb + c * 8;
 #pragma unroll
     for (int f = 0; f < MF; ++f) xp[f] = A + (size_t)min(f * 16 + r, p.M - 1) * lda + c * 8;
     for (int s = sb; s < se; s += U) {
@@ -1602,6 +1607,26 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
 #pragma unroll
     for (int f = 0; f < MF; ++f) *(f32x4_t*)red[wave][i * MF + f][lane] = acc[i][f];
   __syncthreads();
+  if constexpr (SW) {
+    for (int f = wave; f < MF; f += 8) {
+      f32x4_t g = *(const f32x4_t*)red[0][f][lane], u = *(const f32x4_t*)red[0][MF + f][lane];
+#pragma unroll
+      for (int w2 = 1; w2 < 8; ++w2) { g += *(const f32x4_t*)red[w2][f][lane]; u += *(const f32x4_t*)red[w2][MF + f][lane]; }
+      const int m = f * 16 + r;
+      if (m >= p.M) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gt = bf2f(f2bf(g[e])), up = bf2f(f2bf(u[e]));
+        o[e] = gt / (1.0f + __expf(-gt)) * up;
+      }
+      uint2 st;
+      st.x = pack_bf2(o[0], o[1]);
+      st.y = pack_bf2(o[2], o[3]);
+      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + (blockIdx.x >> 2) * 64 + (blockIdx.x & 3) * 16 + c * 4) = st;
+    }
+    return;
+  }
   for (int idx = wave; idx < NR * MF; idx += 8) {
     f32x4_t v = *(const f32x4_t*)red[0][idx][lane];
 #pragma unroll
@@ -2116,9 +2141,18 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
-  if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: only the 4-wave 256x256 kernel implements it
+  if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: the 4-wave 256x256 kernel, or the weight-streaming kernel for decode
     const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9;
     if (a.bias || a.R || a.out_f32 || a.alpha != 1.0f || a.K2 != 0 || a.N % P_BN || !ok32) return hipErrorInvalidValue;
+    if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15) && a.a1_group_n <= 0 && a.K1 % 32 == 0) {
+      const int mf = (a.M + 15) / 16;
+      const dim3 bl(512), gr(a.N / 32);
+      if (mf == 1) hipLaunchKernelGGL((gemm_nt_skinny_kernel<1, 2, 8, true>), gr, bl, 0, st, a);
+      else if (mf == 2) hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 2, 4, true>), gr, bl, 0, st, a);
+      else if (mf == 3) hipLaunchKernelGGL((gemm_nt_skinny_kernel<3, 2, 2, true>), gr, bl, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nt_skinny_kernel<4, 2, 2, true>), gr, bl, 0, st, a);
+      return hipGetLastError();
+    }
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
     hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();

@@ -36,8 +36,13 @@ def truncate_after_eos_with_padding(completions: torch.Tensor, eos_token_id: int
 
 
 class Generator:
-    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True):
+    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True, merge_adapter: bool = False):
+        """merge_adapter: fold a FROZEN adapter into its own bf16 copy of the projections (LoraAdapter.merge_into_base) - the
+        rollout / evaluation policy does not change while it generates, so the 4 LoRA down-projections and the K-concatenated
+        tails of every layer and step disappear (13 -> 8 launches per layer; the gate|up projection fuses SwiGLU)."""
         self.engine, self.adapter, self.use_graph = engine, adapter, use_graph
+        if merge_adapter and adapter is not None and not adapter.trainable and adapter.merged is None:
+            adapter.merge_into_base(engine.base)
 
     @torch.no_grad()
     def generate(self, queries: torch.Tensor, query_attn_masks: torch.Tensor, images: Optional[torch.Tensor] = None, *,
@@ -124,6 +129,9 @@ class Generator:
             cur, nx = emb, x
             for i in range(d.n_layers):
                 w = b.layers[i]
+                ad = self.adapter
+                if ad is not None and ad.merged is not None:      # frozen adapter folded into its own weight copy
+                    w, ad = dict(w, **ad.merged[i]), None
                 L.call("opadpo_rmsnorm_fwd", L.ptr(cur), int(cur.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(rstd), B, H, d.rms_eps, st)
                 if ad is not None:
                     L.gemm_nt(n1, ad.w(i, "a_qkv"), t_qkv, alpha=s)
@@ -139,7 +147,7 @@ class Generator:
                     L.gemm_nt(att, w["wo"], hb, a2=t_o, b2=ad.w(i, "b_o"), residual=cur)
                 else:
                     L.gemm_nt(att, w["wo"], hb, residual=cur)
-                eng.mlp_fwd(i, ad, hb, nx, n2, t_gu, gu, act, t_d, rstd, B)
+                eng.mlp_fwd(i, self.adapter, hb, nx, n2, t_gu, gu, act, t_d, rstd, B)
                 cur, nx = nx, (x2 if nx is x else x)
             head(cur)
 

@@ -814,6 +814,29 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert relerr(got[:M], ref) < 2e-2
 
 
+@pytest.mark.parametrize("M", [1, 4, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008 // 32 * 32)])
+def test_gemm_nt_swiglu_pair_decode(L, M, F, K):
+    """The same fused SwiGLU epilogue in the weight-streaming (decode, M <= 64) kernel: bit-identical to the streaming projection
+    followed by opadpo_silu_mul_fwd; rows >= M untouched."""
+    L.set_flags(10, True)
+    x = rnd(M, K, seed=3)
+    wgu = rnd(2 * F, K, scale=0.3, seed=4)
+    w_sw = torch.stack([wgu[:F].view(F // 64, 64, K), wgu[F:].view(F // 64, 64, K)], dim=1).reshape(2 * F, K).contiguous()
+    gu = torch.empty(M, 2 * F, dtype=BF, device=dev())
+    want = torch.empty(M, F, dtype=BF, device=dev())
+    got = torch.full((M + 2, F), 7.0, dtype=BF, device=dev())
+    with L.decode_schedule():
+        L.gemm_nt(x, wgu, gu)
+        L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(want), M, F, L.stream())
+        L.gemm_nt(x, w_sw, got[:M], act=L.ACT_SWIGLU_PAIR)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:M], want)
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    ref = torch.nn.functional.silu(x.float() @ wgu[:F].float().t()) * (x.float() @ wgu[F:].float().t())
+    assert relerr(got[:M], ref) < 2e-2
+
+
 @pytest.mark.parametrize("S,Lp,seg", [(3, 150, (0, 0)), (2, 200, (120, 40)), (1, 700, (300, 100)), (5, 37, (17, 10))])
 @pytest.mark.parametrize("lora", [False, True])
 def test_gemm_nt_rope(L, S, Lp, seg, lora):

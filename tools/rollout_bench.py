@@ -28,7 +28,13 @@ def main():
     Q = 128 if model == "7b" else 16
     eng = LlavaEngine(BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=False))
     p = synth_pairs(d, B, Q, 8, seed=0, device=dev)
-    gen = Generator(eng, None)
+    lora = int(os.environ.get("RB_LORA", 0))       # 0: no adapter (the shipped rollout config), 1: frozen adapter, 2: frozen adapter merged
+    ad = None
+    if lora:
+        from opadpo_amd.model import LoraAdapter
+        from opadpo_amd.synth import init_lora
+        ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
+    gen = Generator(eng, ad, merge_adapter=lora == 2)
     feats = eng.encode_images(p["images"])
     res = {}
     for n in (1, steps):
@@ -42,12 +48,12 @@ def main():
     prefill = res[1]
     per_step = (res[steps] - res[1]) / (steps - 1)
     wbytes = 2 * (d.n_layers * (4 * d.hidden ** 2 + 3 * d.hidden * d.ffn) + d.vocab * d.hidden)
-    out = {"model": model, "batch": B, "prefill_ms": prefill * 1e3, "decode_ms_per_step": per_step * 1e3,
+    out = {"model": model, "batch": B, "adapter": ["none", "lora", "lora merged"][lora], "prefill_ms": prefill * 1e3, "decode_ms_per_step": per_step * 1e3,
            "decode_tokens_per_s": B / per_step, "weight_bytes_per_step_GB": wbytes / 1e9,
            "decode_hbm_frac": wbytes / per_step / 8e12}
     print(json.dumps(out))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(REPO, "gpurun_out", f"rollout_bench_b{B}.json"), "w"))
+    json.dump(out, open(os.path.join(REPO, "gpurun_out", f"rollout_bench_b{B}_l{lora}.json"), "w"))
 
 
 if __name__ == "__main__":
