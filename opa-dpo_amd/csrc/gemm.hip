@@ -1573,8 +1573,7 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
     for (int i = 0; i < NR; ++i) wp[i] = B + (size_t)(n0 + i * RSTEP + r) * ldb + c * 8;
 #pragma unroll
     for (int f = 0; f < MF; ++f) xp[f] = A + (size_t)min(f * 16 + r, p.M - 1) * lda + c * 8;
-    for (int s = sb; s < se; s += U) {
-      u32x4_t w[U][NR], x[U][MF];
+    auto load = [&](u32x4_t (&w)[U][NR], u32x4_t (&x)[U][MF], int s) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool live = s + u < se;
@@ -1590,6 +1589,8 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
           if (live && f * 16 + r < p.M) x[u][f] = *(const u32x4_t*)(xp[f] + k);
         }
       }
+    };
+    auto compute = [&](const u32x4_t (&w)[U][NR], const u32x4_t (&x)[U][MF]) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1597,6 +1598,11 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
 #pragma unroll
           for (int f = 0; f < MF; ++f)
             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&w[u][i], *(const bf16x8_t*)&x[u][f], acc[i][f], 0, 0, 0);
+    };
+    for (int s = sb; s < se; s += U) {
+      u32x4_t w[U][NR], x[U][MF];
+      load(w, x, s);
+      compute(w, x);
     }
   };
   segment(a1, p.lda1, p.B1, p.ldb1, p.K1);
@@ -1634,6 +1640,116 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNTArgs p) {
     const int i = idx / MF, f = idx % MF;
     const int m = f * 16 + r;
     if (m < p.M) epi_dispatch(p, [&](auto MD_) { epilogue4<decltype(MD_)::value>(p, m, n0 + i * 16 + c * 4, v[0], v[1], v[2], v[3]); });
+  }
+}
+
+
+// M <= 16 form of the weight-streaming kernel (the shipped rollout runs 4 sequences per device): the 16x16x32 MFMA is used as TWO
+// 8x8x32 products so that one wave load covers 8 weight rows x 128 CONTIGUOUS bytes (whole cache lines) instead of 16 rows x 64 B
+// (measured at M = 8: q|k|v 3.9 -> 4.9 TB/s, gate|up 3.4 -> 4.2, down 3.5 -> 4.5, lm_head 3.7 -> 4.6).
+// Operand rows 0..7 = weight rows with the k-chunks 0..3 of a 64-element k-step, rows 8..15 = the same weight rows with the
+// chunks 4..7; the activation operand is split the same way (columns 0..7 = 8 tokens with chunks 0..3, 8..15 = the same tokens
+// with chunks 4..7; MF8 operands of 8 tokens).  The diagonal 8x8 blocks of the 16x16 result are the two partial sums (lanes l
+// and l + 40), the off-diagonal blocks are ignored - the matrix pipe is idle in this kernel anyway.  Everything else as in
+// gemm_nt_skinny_kernel: K split over the 8 waves, partials meet in LDS, fused epilogue (SW: SwiGLU pairs, 8 gate + 8 up rows).
+template <int MF8, int NR, int U, bool SW = false>
+__global__ __launch_bounds__(512) void gemm_nt_skinny8_kernel(GemmNTArgs p) {
+  static_assert(!SW || NR == 2, "SwiGLU pairs: one gate + one up fragment per workgroup");
+  __shared__ __attribute__((aligned(16))) float red[8][NR * MF8][64][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = SW ? (blockIdx.x >> 3) * 128 + (blockIdx.x & 7) * 8 : blockIdx.x * (8 * NR);
+  constexpr int RSTEP = SW ? 64 : 8;
+  const int r = lane & 15, c = lane >> 4;
+  const int r8 = r & 7, kc = ((r >> 3) * 4 + c) * 8;        // row / token within the 8, first element of the lane's k-chunk
+
+  const bf16_t* a1 = p.A1;
+  const bf16_t* a2 = p.A2;
+  if (p.a1_group_n > 0) a1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+
+  f32x4_t acc[NR][MF8];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int f = 0; f < MF8; ++f) acc[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto segment = [&](const bf16_t* A, int lda, const bf16_t* B, int ldb, int K) {
+    const int ns = K >> 6;                       // 64-element k-steps
+    const int per = (ns + 7) >> 3;
+    const int sb = wave * per, se = min(ns, sb + per);
+    const bf16_t* wp[NR];
+    const bf16_t* xp[MF8];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) wp[i] = B + (size_t)(n0 + i * RSTEP + r8) * ldb + kc;
+#pragma unroll
+    for (int f = 0; f < MF8; ++f) xp[f] = A + (size_t)min(f * 8 + r8, p.M - 1) * lda + kc;
+    for (int s = sb; s < se; s += U) {
+      u32x4_t w[U][NR], x[U][MF8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = s + u < se;
+        const int k = (s + u) << 6;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          w[u][i] = u32x4_t{0, 0, 0, 0};
+          if (live) w[u][i] = __builtin_nontemporal_load((const u32x4_t*)(wp[i] + k));
+        }
+#pragma unroll
+        for (int f = 0; f < MF8; ++f) {
+          x[u][f] = u32x4_t{0, 0, 0, 0};
+          if (live && f * 8 + r8 < p.M) x[u][f] = *(const u32x4_t*)(xp[f] + k);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+          for (int f = 0; f < MF8; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&w[u][i], *(const bf16x8_t*)&x[u][f], acc[i][f], 0, 0, 0);
+    }
+  };
+  segment(a1, p.lda1, p.B1, p.ldb1, p.K1);
+  if (p.K2 > 0) segment(a2, p.lda2, p.B2, p.ldb2, p.K2);
+
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int f = 0; f < MF8; ++f) *(f32x4_t*)red[wave][i * MF8 + f][lane] = acc[i][f];
+  __syncthreads();
+  // lane (r < 8, c < 2): token f*8 + r, weight rows c*4 .. c*4+3 of the fragment = low-half partial; lane + 40 holds the high half
+  if (c >= 2 || r >= 8) return;
+  auto total = [&](int idx) {
+    f32x4_t v = *(const f32x4_t*)red[0][idx][lane] + *(const f32x4_t*)red[0][idx][lane + 40];
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) v += *(const f32x4_t*)red[w2][idx][lane] + *(const f32x4_t*)red[w2][idx][lane + 40];
+    return v;
+  };
+  if constexpr (SW) {
+    for (int f = wave; f < MF8; f += 8) {
+      const int m = f * 8 + r;
+      if (m >= p.M) continue;
+      const f32x4_t g = total(f), u = total(MF8 + f);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gt = bf2f(f2bf(g[e])), up = bf2f(f2bf(u[e]));
+        o[e] = gt / (1.0f + __expf(-gt)) * up;
+      }
+      uint2 st;
+      st.x = pack_bf2(o[0], o[1]);
+      st.y = pack_bf2(o[2], o[3]);
+      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + (blockIdx.x >> 3) * 64 + (blockIdx.x & 7) * 8 + c * 4) = st;
+    }
+  } else {
+    for (int idx = wave; idx < NR * MF8; idx += 8) {
+      const int i = idx / MF8, f = idx % MF8;
+      const int m = f * 8 + r;
+      if (m >= p.M) continue;
+      const f32x4_t v = total(idx);
+      epi_dispatch(p, [&](auto MD_) { epilogue4<decltype(MD_)::value>(p, m, n0 + i * 8 + c * 4, v[0], v[1], v[2], v[3]); });
+    }
   }
 }
 
@@ -2096,6 +2212,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
 }
 }  // namespace
 
+static bool g_skinny8 = true;       // M <= 16 decode GEMMs: whole-cache-line form of the streaming kernel
 static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 8: 8-wave ping-pong; 15: M <= 64 streaming; 16/23/24/27/28/29/30/31: w4 family; 17: 8-wave 4-phase
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
@@ -2106,6 +2223,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   opadpo_set_attn_dma((use_tr & 2) != 0);
   g_tn_wide = (use_tr & 4) != 0;
   g_tn_w4 = (use_tr & 8) == 0;
+  g_skinny8 = (use_tr & 16) == 0;
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
@@ -2147,6 +2265,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15) && a.a1_group_n <= 0 && a.K1 % 32 == 0) {
       const int mf = (a.M + 15) / 16;
       const dim3 bl(512), gr(a.N / 32);
+      if (g_skinny8 && a.M <= 16) {
+        if (a.M <= 8) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<1, 2, 8, true>), dim3(a.N / 16), bl, 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_skinny8_kernel<2, 2, 4, true>), dim3(a.N / 16), bl, 0, st, a);
+        return hipGetLastError();
+      }
       if (mf == 1) hipLaunchKernelGGL((gemm_nt_skinny_kernel<1, 2, 8, true>), gr, bl, 0, st, a);
       else if (mf == 2) hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 2, 4, true>), gr, bl, 0, st, a);
       else if (mf == 3) hipLaunchKernelGGL((gemm_nt_skinny_kernel<3, 2, 2, true>), gr, bl, 0, st, a);
@@ -2166,6 +2289,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                       (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
     const dim3 bl(512), gr(wide ? a.N / 32 : a.N / 16);
 #define SK(MF_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<MF_, NR_, U_>), gr, bl, 0, st, a)
+    if (g_skinny8 && a.M <= 16 && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) && (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0)) {
+      const bool wide8 = a.N % 32 == 0 && a.N / 32 >= 512;          // 32 weight rows per workgroup while >= 2 rounds of blocks remain
+#define SK8(MF8_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<MF8_, NR_, U_>), dim3(a.N / (8 * NR_)), bl, 0, st, a)
+      if (a.M <= 8) { if (wide8) SK8(1, 4, 4); else SK8(1, 2, 8); }
+      else          { if (wide8) SK8(2, 4, 2); else SK8(2, 2, 4); }
+#undef SK8
+      return hipGetLastError();
+    }
     if (wide) { if (mf == 1) SK(1, 2, 8); else if (mf == 2) SK(2, 2, 4); else if (mf == 3) SK(3, 2, 2); else SK(4, 2, 2); }
     else      { if (mf == 1) SK(1, 1, 8); else if (mf == 2) SK(2, 1, 4); else if (mf == 3) SK(3, 1, 4); else SK(4, 1, 4); }
 #undef SK

@@ -69,13 +69,14 @@ def test_gemm_nt(L, glds, M, N, K1, K2, groups):
     assert e < 6e-3, f"gemm_nt rel err {e}"   # bf16 output rounding ~ 2^-9
 
 
-@pytest.mark.parametrize("M", [1, 8, 16, 17, 40, 64])
+@pytest.mark.parametrize("M,tr", [(1, 1), (3, 1), (8, 1), (9, 1), (16, 1), (17, 1), (40, 1), (64, 1), (1, 17), (8, 17), (16, 17)])
 @pytest.mark.parametrize("N,K1,K2,groups", [(256, 4096, 0, 0), (384, 192, 128, 3), (16384, 128, 64, 2), (128, 2752, 256, 1),
                                             (22016, 64, 128, 2)])
-def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
-    """decode-sized GEMMs (M <= 64) take the weight-streaming kernel: in-workgroup split-K, LoRA tail as a second K
-    segment, grouped tail columns, fused epilogue (alpha / bias / residual, bf16 and fp32 outputs)."""
-    L.set_flags(15, True)          # 15 = force the streaming kernel (product: OPADPO_GEMM_STREAM hint per call)
+def test_gemm_nt_skinny(L, M, tr, N, K1, K2, groups):
+    """decode-sized GEMMs (M <= 64) take the weight-streaming kernels: in-workgroup split-K, LoRA tail as a second K
+    segment, grouped tail columns, fused epilogue (alpha / bias / residual, bf16 and fp32 outputs).  M <= 16: the whole-cache-line
+    form (two 8x8x32 products per MFMA); tr = 17 (bit 4) switches it off so the 16-row form is covered at those sizes too."""
+    L.set_flags(15, tr)            # 15 = force the streaming kernel (product: OPADPO_GEMM_STREAM hint per call)
     a1, b1 = rnd(M, K1, scale=0.5, seed=1), rnd(N, K1, scale=0.5, seed=2)
     want = a1.float() @ b1.float().t()
     kw = {}
@@ -102,11 +103,12 @@ def test_gemm_nt_skinny(L, M, N, K1, K2, groups):
     L.set_flags(4, True)
     o4 = torch.empty(M, N, device=dev())
     L.gemm_nt(a1, b1, o4, bias=bias, residual=res32, alpha=0.25, **kw)
-    L.set_flags(10, True)
+    L.set_flags(10, tr)
     assert relerr(o32, o4) < 1e-5
     with L.decode_schedule():      # the per-call hint selects the same kernel: identical bits
         o5 = torch.empty(M, N, device=dev())
         L.gemm_nt(a1, b1, o5, bias=bias, residual=res32, alpha=0.25, **kw)
+    L.set_flags(10, True)
     assert torch.equal(o5, o32)
 
 
@@ -814,12 +816,12 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert relerr(got[:M], ref) < 2e-2
 
 
-@pytest.mark.parametrize("M", [1, 4, 8, 16, 17, 40, 64])
-@pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008 // 32 * 32)])
-def test_gemm_nt_swiglu_pair_decode(L, M, F, K):
+@pytest.mark.parametrize("M,tr", [(1, 1), (4, 1), (8, 1), (9, 1), (16, 1), (17, 1), (40, 1), (64, 1), (4, 17), (16, 17)])
+@pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008)])
+def test_gemm_nt_swiglu_pair_decode(L, M, tr, F, K):
     """The same fused SwiGLU epilogue in the weight-streaming (decode, M <= 64) kernel: bit-identical to the streaming projection
     followed by opadpo_silu_mul_fwd; rows >= M untouched."""
-    L.set_flags(10, True)
+    L.set_flags(10, tr)
     x = rnd(M, K, seed=3)
     wgu = rnd(2 * F, K, scale=0.3, seed=4)
     w_sw = torch.stack([wgu[:F].view(F // 64, 64, K), wgu[F:].view(F // 64, 64, K)], dim=1).reshape(2 * F, K).contiguous()
@@ -831,6 +833,7 @@ def test_gemm_nt_swiglu_pair_decode(L, M, F, K):
         L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(want), M, F, L.stream())
         L.gemm_nt(x, w_sw, got[:M], act=L.ACT_SWIGLU_PAIR)
     torch.cuda.synchronize()
+    L.set_flags(10, True)
     assert torch.equal(got[:M], want)
     assert float((got[M:].float() - 7.0).abs().max()) == 0.0
     ref = torch.nn.functional.silu(x.float() @ wgu[:F].float().t()) * (x.float() @ wgu[F:].float().t())

@@ -104,7 +104,7 @@ def main():
         print("total ms per layer", tot * 1e3)
         return
     if only == "skinny":   # decode-sized GEMMs: weight streaming rate; weights rotated over > 512 MB so MALL cannot hold them
-        for M_ in (8, 16, 32, 64):
+        for M_ in [int(v) for v in os.environ.get("GB_MS", "8,16,32,64").split(",")]:
             for name, N, K1, K2, grp in shapes:
                 if name == "lora_t":
                     continue
@@ -112,9 +112,9 @@ def main():
                 ws = [(torch.randn(N, K1, device=dev) * 0.02).to(BF) for _ in range(copies)]
                 a1 = torch.randn(M_, K1, device=dev).to(BF)
                 out = torch.empty(M_, N, dtype=BF, device=dev)
-                for label, variant in (("skinny", 10), ("tile128", 4), ("hipBLASLt", -1)):
+                for label, variant, tr in (("skinny", 10, 1), ("skinny16", 10, 17), ("tile128", 4, 1), ("hipBLASLt", -1, 1)):
                     if variant >= 0:
-                        L.set_flags(variant, True)
+                        L.set_flags(variant, tr)
                     it = [0]
 
                     def fn():
