@@ -29,8 +29,8 @@ extern "C" {
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
 #define OPADPO_ACT_SWIGLU_PAIR 3 /* gemm_nt only: B rows arranged per 128 as [64 gate | 64 up]; C gets N/2 columns
                                  * silu(gate) * up (SwiGLU of modeling_llama.LlamaMLP fused into the gate|up projection; used
-                                 * for the merged, no-grad reference pass).  Needs M-by-N tiles of 256, bf16 C, no bias /
-                                 * residual, alpha = 1. */
+                                 * for the merged, no-grad reference pass and, with OPADPO_GEMM_STREAM, for decode with a
+                                 * merged adapter).  Needs N % 256 == 0, bf16 C, no bias / residual / LoRA tail, alpha = 1. */
 #define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
                                   * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
 
@@ -40,7 +40,8 @@ const char* opadpo_last_error(void);
  * 256x256 kernels, 16 / 23 / 24 / 28 / 29 / 31 = 4-wave 256x256 family, 27 / 30 = stamped diagnostics); use_tr bit 0 =
  * ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 = attention forward through a direct-to-LDS
  * double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks per CU), bit 2 = wide gemm_tn tiles,
- * bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one. */
+ * bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
+ * M <= 16 (default there: the whole-cache-line 8-row form). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------

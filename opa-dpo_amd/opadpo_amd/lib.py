@@ -103,7 +103,7 @@ def set_flags(use_glds=10, use_tr: bool = True) -> None:
     29 32x32x16 MFMA, 31 = the default large-GEMM kernel forced.  True -> default.
     use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V ring
     (default: register-staged single buffer, 3 blocks per CU), bit 2 = wide gemm_tn tiles, bit 3 = 128x128 gemm_tn kernel
-    instead of the default 256x256 gemm_tn_w4_kernel."""
+    instead of the default 256x256 gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel)."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 
