@@ -28,11 +28,13 @@ def adapter_dir_of(checkpoint: str) -> str:
 @torch.no_grad()
 def generate_from_checkpoint(engine: LlavaEngine, checkpoint: Optional[str], queries: torch.Tensor, query_attn_masks: torch.Tensor,
                              images: torch.Tensor, *, max_new_tokens: int = 64, temperature: float = 0.0, top_p: float = 1.0,
-                             top_k: int = 0, seed: int = 0, adapter: Optional[LoraAdapter] = None) -> torch.Tensor:
-    """-> [B, max_new_tokens] int64, pad after EOS.  temperature == 0 -> greedy (the reference passes do_sample=False then)."""
+                             top_k: int = 0, seed: int = 0, adapter: Optional[LoraAdapter] = None,
+                             merge_adapter: bool = False) -> torch.Tensor:
+    """-> [B, max_new_tokens] int64, pad after EOS.  temperature == 0 -> greedy (the reference passes do_sample=False then).
+    merge_adapter: fold the (frozen) adapter into its own copy of the projections first (generate.Generator)."""
     if adapter is None and checkpoint is not None:
         adapter = LoraAdapter(engine.d, load_adapter(adapter_dir_of(checkpoint)), engine.dev, trainable=False)
-    gen = Generator(engine, adapter)
+    gen = Generator(engine, adapter, merge_adapter=merge_adapter)
     if temperature and temperature > 0:
         out = gen.generate(queries, query_attn_masks, images, max_new_tokens=max_new_tokens, temperature=temperature, top_k=top_k,
                            top_p=top_p, seed=seed)
@@ -61,10 +63,12 @@ def eval_prompt(question: str, test_prompt: Optional[str] = DEFAULT_TEST_PROMPT)
 def answer_questions(engine: LlavaEngine, tokenizer, questions: list, image_folder: str, answers_file: str, *,
                      checkpoint: Optional[str] = None, adapter: Optional[LoraAdapter] = None, model_id: str = "opadpo-hip",
                      temperature: float = 0.0, top_p: Optional[float] = None, short_eval: bool = False, max_new_tokens: Optional[int] = None,
-                     test_prompt: Optional[str] = DEFAULT_TEST_PROMPT, image_size: int = 336, pad_to_square: bool = True, seed: int = 0) -> int:
+                     test_prompt: Optional[str] = DEFAULT_TEST_PROMPT, image_size: int = 336, pad_to_square: bool = True, seed: int = 0,
+                     merge_adapter: bool = False) -> int:
     """One JSON line per question: question_id, prompt (the bare question), text (stripped answer, a trailing '</s>' removed),
     answer_id, model_id, metadata (model_vqa.py:143-262).  Refuses to overwrite an existing answers file like the script's
-    __main__.  max_new_tokens defaults to 64 (`short_eval`) or 1024."""
+    __main__.  max_new_tokens defaults to 64 (`short_eval`) or 1024.  merge_adapter: merge the frozen checkpoint adapter once (PEFT
+    `merge_and_unload` equivalent; bf16 rounding of the merged weights) - every question then decodes without LoRA launches."""
     import json
     import uuid
     from PIL import Image
@@ -85,7 +89,8 @@ def answer_questions(engine: LlavaEngine, tokenizer, questions: list, image_fold
             pil = Image.open(os.path.join(image_folder, line["image"])).convert("RGB")
             image = preprocess_image(pil, image_size, pad_to_square)[None].to(engine.dev)
             out = generate_from_checkpoint(engine, None, ids.to(engine.dev), torch.ones_like(ids).to(engine.dev), image, max_new_tokens=n_new,
-                                           temperature=temperature, top_p=1.0 if top_p is None else top_p, seed=seed + n, adapter=adapter)
+                                           temperature=temperature, top_p=1.0 if top_p is None else top_p, seed=seed + n, adapter=adapter,
+                                           merge_adapter=merge_adapter)
             text = tokenizer.batch_decode(out.cpu(), skip_special_tokens=True)[0].strip()
             if text.endswith(SEP2):
                 text = text[:-len(SEP2)]

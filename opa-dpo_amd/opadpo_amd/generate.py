@@ -11,6 +11,7 @@ the new token of every row sits at the same position: one RoPE position and one 
 """
 from __future__ import annotations
 
+import types
 from typing import List, Optional, Sequence
 
 import torch
@@ -36,13 +37,23 @@ def truncate_after_eos_with_padding(completions: torch.Tensor, eos_token_id: int
 
 
 class Generator:
-    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True, merge_adapter: bool = False):
+    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True, merge_adapter: bool = False,
+                 fuse_swiglu: bool = False):
         """merge_adapter: fold a FROZEN adapter into its own bf16 copy of the projections (LoraAdapter.merge_into_base) - the
         rollout / evaluation policy does not change while it generates, so the 4 LoRA down-projections and the K-concatenated
         tails of every layer and step disappear (13 -> 8 launches per layer; the gate|up projection fuses SwiGLU)."""
         self.engine, self.adapter, self.use_graph = engine, adapter, use_graph
         if merge_adapter and adapter is not None and not adapter.trainable and adapter.merged is None:
             adapter.merge_into_base(engine.base)
+        d = engine.d
+        if adapter is None and fuse_swiglu and d.ffn % 128 == 0:
+            # adapter-free rollout (the shipped config): a second copy of gate|up with its rows arranged per 128 as [64 gate | 64 up]
+            # lets the projection's epilogue apply SwiGLU (lib.ACT_SWIGLU_PAIR) - one launch and one [B, 2F] round trip less per
+            # layer and step.  Carried like a merged adapter (weights only, nothing trainable).
+            F, H = d.ffn, d.hidden
+            sw = [{"wgu_sw": torch.stack([w["wgu"][:F].view(F // 64, 64, H), w["wgu"][F:].view(F // 64, 64, H)], dim=1)
+                   .reshape(2 * F, H).contiguous()} for w in engine.base.layers]
+            self.adapter = types.SimpleNamespace(merged=sw, trainable=False)
 
     @torch.no_grad()
     def generate(self, queries: torch.Tensor, query_attn_masks: torch.Tensor, images: Optional[torch.Tensor] = None, *,

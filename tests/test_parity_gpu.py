@@ -266,10 +266,12 @@ def test_generation_kv_cache_against_oracle(setup):
     vis_only = {k: v for k, v in s["lora_ref"].items() if "vision_tower" in k or "mm_projector" in k}
     from opadpo_amd.model import LoraAdapter
     frozen = LoraAdapter(s["d"], s["lora_ref"], s["dev"], trainable=False)       # merged into its own weight copy by the Generator
-    for adapter, lora, use_graph, merge in ((s["ref"], s["lora_ref"], True, False), (None, vis_only, True, False),
-                                            (s["ref"], s["lora_ref"], False, False), (frozen, s["lora_ref"], True, True)):
-        gen = Generator(s["eng"], adapter, use_graph=use_graph, merge_adapter=merge)
+    for adapter, lora, use_graph, merge, fuse in ((s["ref"], s["lora_ref"], True, False, False), (None, vis_only, True, False, False),
+                                                  (s["ref"], s["lora_ref"], False, False, False), (frozen, s["lora_ref"], True, True, False),
+                                                  (None, vis_only, True, False, True)):
+        gen = Generator(s["eng"], adapter, use_graph=use_graph, merge_adapter=merge, fuse_swiglu=fuse)
         assert (adapter is not None and adapter.merged is not None) == merge
+        assert (adapter is None and gen.adapter is not None) == (fuse and s["d"].ffn % 128 == 0)
         out = gen.generate(queries, qmask, images.to(s["dev"]), max_new_tokens=N, temperature=1.0, top_k=1, top_p=1.0, seed=1)
         torch.cuda.synchronize()
         out = out.cpu()
@@ -372,6 +374,14 @@ def test_eval_question_file_to_answers_file(setup, tmp_path):
         assert line["text"] == Tok().batch_decode(want.cpu())[0].strip()
     with pytest.raises(FileExistsError):
         eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans), adapter=s["pol"], max_new_tokens=6, image_size=d.image_size)
+    # checkpoint on disk + merged adapter: same file format, adapter folded once
+    from opadpo_amd.trainer import save_adapter
+    ckpt = tmp_path / "checkpoint-1"
+    save_adapter(s["pol"], str(ckpt / "adapter_model" / "lora_policy"), d)
+    ans2 = tmp_path / "answers_merged.jsonl"
+    assert eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans2), checkpoint=str(ckpt), max_new_tokens=6, image_size=d.image_size,
+                               merge_adapter=True) == 2
+    assert [json.loads(x)["question_id"] for x in open(ans2)] == [7, 9]
 
 
 def test_vision_projector_lora_backward(setup):

@@ -34,7 +34,7 @@ def main():
         from opadpo_amd.model import LoraAdapter
         from opadpo_amd.synth import init_lora
         ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
-    gen = Generator(eng, ad, merge_adapter=lora == 2)
+    gen = Generator(eng, ad, merge_adapter=lora == 2, fuse_swiglu=os.environ.get("RB_FUSE", "1") == "1")
     feats = eng.encode_images(p["images"])
     res = {}
     for n in (1, steps):
@@ -48,7 +48,7 @@ def main():
     prefill = res[1]
     per_step = (res[steps] - res[1]) / (steps - 1)
     wbytes = 2 * (d.n_layers * (4 * d.hidden ** 2 + 3 * d.hidden * d.ffn) + d.vocab * d.hidden)
-    out = {"model": model, "batch": B, "adapter": ["none", "lora", "lora merged"][lora], "prefill_ms": prefill * 1e3, "decode_ms_per_step": per_step * 1e3,
+    out = {"model": model, "batch": B, "adapter": ["none", "lora", "lora merged"][lora], "fused_swiglu": gen.adapter is not None and getattr(gen.adapter, "merged", None) is not None, "prefill_ms": prefill * 1e3, "decode_ms_per_step": per_step * 1e3,
            "decode_tokens_per_s": B / per_step, "weight_bytes_per_step_GB": wbytes / 1e9,
            "decode_hbm_frac": wbytes / per_step / 8e12}
     print(json.dumps(out))
