@@ -174,6 +174,12 @@ size_t opadpo_attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx);
  * q is rotated in place, the rotated k and the v are appended to the caches at [b, h, pos, :]. */
 int opadpo_rope_kv_append(uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
                           int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, void* stream);
+/* rope_kv_append + attn_decode in ONE launch (decode step of the generator): qkv rows [q|k|v] of the new token as the
+ * projection wrote them (not modified); q and k are rotated at position pos_ptr[0] inside the kernel, k and v appended to the
+ * caches at [b, h, pos, :], attention over keys 0..pos (key_mask as above).  Same rounding points as the two calls. */
+int opadpo_attn_decode_fused(const uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
+                             uint16_t* o, const uint8_t* key_mask, int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, float scale,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* temperature -> top-k -> top-p -> multinomial (HF logits processors order); one draw per row from
  * a counter-based generator keyed on (seed, step, row).  finished rows emit pad_id; a row that draws eos_id (>= 0) is
  * marked finished.  step_ptr (device int32, nullable) overrides `step`; history (nullable) [steps, rows] receives the

@@ -217,6 +217,15 @@ int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, cons
 size_t opadpo_attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx) {
   return (B > 0 && nh > 0) ? attn_decode_workspace_bytes(B, nh, hd, max_ctx) : 0;
 }
+int opadpo_attn_decode_fused(const uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
+                             uint16_t* o, const uint8_t* key_mask, int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, float scale,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (!pos_ptr) return bad("opadpo_attn_decode_fused", "pos_ptr is required");
+  if (ld % 8 || ld < 3 * nh * hd) return bad("opadpo_attn_decode_fused", "qkv rows must hold [q|k|v] with an aligned leading dimension");
+  return done(launch_attn_decode_fused(qkv, ld, cos_tab, sin_tab, k_cache, v_cache, o, key_mask, B, nh, hd, pos_ptr, max_ctx, scale,
+                                       workspace, workspace_bytes, S(stream)),
+              "opadpo_attn_decode_fused");
+}
 int opadpo_rope_kv_append(uint16_t* qkv, int ld, const float* cos_tab, const float* sin_tab, uint16_t* k_cache, uint16_t* v_cache,
                           int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, void* stream) {
   return done(launch_rope_kv_append(qkv, ld, cos_tab, sin_tab, k_cache, v_cache, B, nh, hd, pos_ptr, max_ctx, S(stream)),

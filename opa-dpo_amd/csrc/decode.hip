@@ -17,10 +17,18 @@ namespace {
 // splits > 1 (B*nh < 256): the key range is cut into pieces, every block writes (max, sum, out[HD]) to the workspace
 // and attn_decode_merge_kernel combines them (a kernel boundary is the cheapest device-wide release/acquire here: a
 // per-block agent-scope fence costs an L2 write-back per block on a multi-XCD part).
-template <int HD, int NW>
+// FUSE (decode step of the generator): q points at the [q|k|v] rows of the NEW token straight out of the projection.  Every
+// block rotates its q chunk itself (RoPE at position pos = ctx_ptr[0]; a lane fetches its 8 elements and the 8 of its
+// rotation partner 64 columns away); the block whose key range contains pos also rotates the new k, appends k and v to the
+// caches and folds that key into its online softmax from registers (the loop skips slot pos, so there is no
+// write -> read dependence through memory inside the launch).  Replaces rope_kv_append + attn_decode: one launch less per
+// layer and step.  Rounding points are those of the two-kernel path (rotated q and k rounded to bf16 before use).
+template <int HD, int NW, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, int ldq, const bf16_t* kc, const bf16_t* vc,
                                                                bf16_t* o, const uint8_t* key_mask, int nh, int ctx_arg,
-                                                               const int32_t* ctx_ptr, int max_ctx, float scale_log2e, float* ws_part) {
+                                                               const int32_t* ctx_ptr, int max_ctx, float scale_log2e, float* ws_part,
+                                                               const float* cosb = nullptr, const float* sinb = nullptr,
+                                                               bf16_t* kc_w = nullptr, bf16_t* vc_w = nullptr) {
   constexpr int LPK = HD / 8;            // lanes per key
   constexpr int KPW = 64 / LPK;          // keys per wave step
   constexpr int NG = NW * KPW;           // lane groups (= keys per block step)
@@ -35,7 +43,24 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
   const int s0 = split * per, s1 = min(ctx, s0 + per);
 
   float qf[8];
-  unpack8(*(const uint4*)(q + (size_t)b * ldq + h * HD + d * 8), qf);
+  const int pos = FUSE ? ctx - 1 : -1;                 // slot of the token this step appends
+  // rotate 8 elements of a head row: own chunk d*8.. and the partner chunk 64 columns away (first half: x1 c - x2 s, second: x2 c + x1 s)
+  auto rope8 = [&](const bf16_t* row, float (&out)[8]) {
+    constexpr int half = HD / 2;
+    const bool lo = d * 8 < half;
+    const int i0 = lo ? d * 8 : d * 8 - half;
+    float own[8], oth[8];
+    unpack8(*(const uint4*)(row + d * 8), own);
+    unpack8(*(const uint4*)(row + (lo ? d * 8 + half : d * 8 - half)), oth);
+    const float* cp = cosb + (size_t)pos * half + i0;
+    const float* sp = sinb + (size_t)pos * half + i0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = lo ? own[e] * cp[e] - oth[e] * sp[e] : own[e] * cp[e] + oth[e] * sp[e];
+    const uint4 rb = pack8(out);                       // the two-kernel path stores the rotated row as bf16
+    unpack8(rb, out);
+  };
+  if constexpr (FUSE) rope8(q + (size_t)b * ldq + h * HD, qf);
+  else unpack8(*(const uint4*)(q + (size_t)b * ldq + h * HD + d * 8), qf);
 #pragma unroll
   for (int e = 0; e < 8; ++e) qf[e] *= scale_log2e;
   const size_t seq = ((size_t)b * nh + h) * max_ctx;
@@ -52,10 +77,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = jb + u * NG + g;
-      ok[u] = j < s1 && (!km || km[j]);
+      ok[u] = j < s1 && (!km || km[j]) && j != pos;
       kk[u] = make_uint4(0, 0, 0, 0);
       vv[u] = make_uint4(0, 0, 0, 0);
-      if (j < s1) {                      // slots >= ctx are never read (uninitialised memory may hold NaN bit patterns)
+      if (j < s1 && j != pos) {          // slots >= ctx are never read (uninitialised memory may hold NaN bit patterns)
         kk[u] = *(const uint4*)(kb + (size_t)j * HD);
         vv[u] = *(const uint4*)(vb + (size_t)j * HD);
       }
@@ -87,6 +112,31 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
       l += pj;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += pj * vf[e];
+    }
+  }
+  if constexpr (FUSE) {
+    if (pos >= s0 && pos < s1 && wave == 0 && g == 0) {          // the new token's key: one lane group, from registers
+      const size_t H = (size_t)nh * HD;
+      const bf16_t* krow = q + (size_t)b * ldq + H + h * HD;
+      float kf[8], vf[8];
+      rope8(krow, kf);
+      const uint4 vraw = *(const uint4*)(krow + H + d * 8);
+      unpack8(vraw, vf);
+      *(uint4*)(kc_w + (seq + pos) * HD + d * 8) = pack8(kf);
+      *(uint4*)(vc_w + (seq + pos) * HD + d * 8) = vraw;
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += kf[e] * qf[e];
+#pragma unroll
+      for (int off = 1; off < LPK; off <<= 1) a += __shfl_xor(a, off, 64);
+      if (!km || km[pos]) {
+        const float mn = fmaxf(m, a);
+        const float alpha = fast_exp2(m - mn), pj = fast_exp2(a - mn);
+        m = mn;
+        l = l * alpha + pj;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * alpha + pj * vf[e];
+      }
     }
   }
   const int grp = wave * KPW + g;
@@ -505,6 +555,25 @@ static int attn_decode_splits(int B, int nh, int max_ctx) {
 size_t attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx) {
   const int splits = attn_decode_splits(B, nh, max_ctx);
   return splits == 1 ? 0 : (size_t)B * nh * splits * (hd + 2) * 4;
+}
+
+hipError_t launch_attn_decode_fused(const bf16_t* qkv, int ld, const float* cosb, const float* sinb, bf16_t* kc, bf16_t* vc, bf16_t* o,
+                                    const uint8_t* key_mask, int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, float scale,
+                                    void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  if ((hd != 64 && hd != 128) || !pos_ptr || ld % 8) return hipErrorInvalidValue;
+  int splits = attn_decode_splits(B, nh, max_ctx);
+  if (splits > 1 && (!workspace || workspace_bytes < attn_decode_workspace_bytes(B, nh, hd, max_ctx))) splits = 1;
+  float* part = (float*)workspace;
+  const float sl2 = scale * 1.4426950408889634f;
+  const bool fat = B * nh * splits < 1024;
+  const dim3 gr(nh, B, splits);
+#define ADF(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, true>), gr, dim3(NW_ * 64), 0, st, qkv, ld, kc, vc, o, key_mask, nh, 0, pos_ptr, max_ctx, sl2, part, cosb, sinb, kc, vc)
+  if (hd == 128) { if (fat) ADF(128, 16); else ADF(128, 4); }
+  else           { if (fat) ADF(64, 16); else ADF(64, 4); }
+#undef ADF
+  if (splits > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(B * nh), dim3(hd), 0, st, part, o, splits, hd);
+  return hipGetLastError();
 }
 
 hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* vc, bf16_t* o, const uint8_t* key_mask,

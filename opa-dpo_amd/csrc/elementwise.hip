@@ -25,6 +25,34 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* x, const b
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   float ss = 0.f;
+  if (H <= 256 * 8 * 3) {
+    // row held in registers between the two passes, norm weight fetched before the reduction: two dependent memory round
+    // trips instead of four (decode: 8 rows per launch, the kernel is nothing but latency; training: x is read once)
+    float f[3][8], g[3][8];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int i = threadIdx.x * 8 + it * 2048;
+      if (i < H) {
+        load8<XF>(x, row * H + i, f[it]);
+        unpack8(*(const uint4*)(w + i), g[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[it][j] * f[it][j];
+      }
+    }
+    ss = block_sum_256(ss, red);
+    const float r = rsqrtf(ss / H + eps);
+    if (rstd && threadIdx.x == 0) rstd[row] = r;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int i = threadIdx.x * 8 + it * 2048;
+      if (i < H) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[it][j] = f[it][j] * r * g[it][j];
+        *(uint4*)(y + row * H + i) = pack8(f[it]);
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8];
     load8<XF>(x, row * H + i, f);

@@ -107,5 +107,8 @@ hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* v
                               int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx, int ldq, float scale,
                               void* workspace, size_t workspace_bytes, hipStream_t st);
 size_t attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx);
+hipError_t launch_attn_decode_fused(const bf16_t* qkv, int ld, const float* cosb, const float* sinb, bf16_t* kc, bf16_t* vc, bf16_t* o,
+                                    const uint8_t* key_mask, int B, int nh, int hd, const int32_t* pos_ptr, int max_ctx, float scale,
+                                    void* workspace, size_t workspace_bytes, hipStream_t st);
 hipError_t launch_rope_kv_append(bf16_t* qkv, int ld, const float* cosb, const float* sinb, bf16_t* kc, bf16_t* vc, int B, int nh,
                                  int hd, const int32_t* pos_ptr, int max_ctx, hipStream_t st);

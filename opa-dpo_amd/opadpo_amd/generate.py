@@ -149,10 +149,9 @@ class Generator:
                     L.gemm_nt(n1, w["wqkv"], qkv, a2=t_qkv, b2=ad.w(i, "b_qkv"), a2_group_n=H, a2_group_stride=r)
                 else:
                     L.gemm_nt(n1, w["wqkv"], qkv)
-                L.call("opadpo_rope_kv_append", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), L.ptr(kc[i]), L.ptr(vc[i]), B, nh, hd,
-                       L.ptr(pos_d), max_ctx, st)
-                L.call("opadpo_attn_decode", L.ptr(qkv), 3 * H, L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(att), L.ptr(key_mask), B, nh, hd,
-                       0, L.ptr(pos_d), max_ctx, hd ** -0.5, L.ptr(ws), ws_bytes, st)
+                # RoPE of q / k at the device-resident position, KV append and attention over keys 0..pos: one launch
+                L.call("opadpo_attn_decode_fused", L.ptr(qkv), 3 * H, L.ptr(cos), L.ptr(sin), L.ptr(kc[i]), L.ptr(vc[i]), L.ptr(att),
+                       L.ptr(key_mask), B, nh, hd, L.ptr(pos_d), max_ctx, hd ** -0.5, L.ptr(ws), ws_bytes, st)
                 if ad is not None:
                     L.gemm_nt(att, ad.w(i, "a_o"), t_o, alpha=s)
                     L.gemm_nt(att, w["wo"], hb, a2=t_o, b2=ad.w(i, "b_o"), residual=cur)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "opadpo_adamw": [_p, _p, _p, _p, _p, _sz, _d, _d, _d, _d, _d, _i, _p, _d, _d, _p],
     "opadpo_attn_decode": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _f, _p, _sz, _p],
     "opadpo_rope_kv_append": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p],
+    "opadpo_attn_decode_fused": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _f, _p, _sz, _p],
     "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _p, _i, _i, _p, _p, _p],
 }
 OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes"]

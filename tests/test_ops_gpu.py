@@ -713,6 +713,47 @@ def test_rope_kv_append(L):
     assert float(kc.abs().max()) == 0.0 and float(vc.abs().max()) == 0.0     # nothing else touched
 
 
+@pytest.mark.parametrize("B,nh,hd,pos,max_ctx", [(2, 4, 128, 29, 48), (3, 2, 64, 0, 16), (1, 8, 128, 700, 1024), (5, 32, 128, 301, 512),
+                                                 (64, 32, 128, 130, 256), (4, 32, 128, 751, 800)])
+def test_attn_decode_fused(L, B, nh, hd, pos, max_ctx):
+    """opadpo_attn_decode_fused == opadpo_rope_kv_append followed by opadpo_attn_decode: identical cache contents (bits), attention
+    output equal up to the order in which the newest key enters the online softmax; qkv is not modified; slots > pos never read."""
+    H = nh * hd
+    qkv = rnd(B, 3 * H, seed=1)
+    half = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, device=dev()).float() / half))
+    ang = torch.arange(max_ctx, device=dev()).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    posd = torch.tensor([pos], dtype=torch.int32, device=dev())
+    kc0, vc0 = rnd(B, nh, max_ctx, hd, seed=2), rnd(B, nh, max_ctx, hd, seed=3)
+    kc0[:, :, pos:] = float("nan")                     # the slot being appended and everything after it: uninitialised
+    vc0[:, :, pos:] = float("nan")
+    km = torch.ones(B, max_ctx, dtype=torch.uint8, device=dev())
+    if pos > 6:
+        km[0, :4] = 0
+    ws_bytes = int(L.load().opadpo_attn_decode_workspace_bytes(B, nh, hd, max_ctx))
+    ws = torch.zeros(max(ws_bytes, 4), dtype=torch.uint8, device=dev())
+    # two launches
+    q1, kc1, vc1 = qkv.clone(), kc0.clone(), vc0.clone()
+    o1 = torch.empty(B, H, dtype=BF, device=dev())
+    L.call("opadpo_rope_kv_append", q1.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), B, nh, hd,
+           posd.data_ptr(), max_ctx, L.stream())
+    L.call("opadpo_attn_decode", q1.data_ptr(), 3 * H, kc1.data_ptr(), vc1.data_ptr(), o1.data_ptr(), km.data_ptr(), B, nh, hd, 0,
+           posd.data_ptr(), max_ctx, hd ** -0.5, ws.data_ptr(), ws_bytes, L.stream())
+    # one launch, with and without the split-KV workspace
+    for wsp, wsb in ((ws.data_ptr(), ws_bytes), (None, 0)):
+        q2, kc2, vc2 = qkv.clone(), kc0.clone(), vc0.clone()
+        o2 = torch.empty(B, H, dtype=BF, device=dev())
+        L.call("opadpo_attn_decode_fused", q2.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), kc2.data_ptr(), vc2.data_ptr(), o2.data_ptr(),
+               km.data_ptr(), B, nh, hd, posd.data_ptr(), max_ctx, hd ** -0.5, wsp, wsb, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(q2, qkv)
+        assert torch.equal(kc2[:, :, :pos + 1], kc1[:, :, :pos + 1]) and torch.equal(vc2[:, :, :pos + 1], vc1[:, :, :pos + 1])
+        assert bool(torch.isnan(kc2[:, :, pos + 1:].float()).all()) and bool(torch.isnan(vc2[:, :, pos + 1:].float()).all())
+        assert not bool(torch.isnan(o2.float()).any())
+        assert relerr(o2, o1.float()) < 4e-3
+
+
 def test_sampler_distribution(L):
     V, rows = 512, 4000
     torch.manual_seed(3)
