@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rollout (config 5 of BASELINE.json) micro-benchmark on one MI355X: LLaVA-1.5-7B prefill (Q=128 -> L=703) + KV-cache
-sampling decode (top-k 30, top-p 0.95), random-init weights, no LoRA (the shipped rollout config).  Reports prefill
-ms, decode ms/step and tokens/s; the decode roofline is HBM: >= 13.2 GB of bf16 weights per step."""
+sampling decode (top-k 30, top-p 0.95), random-init weights, no LoRA (the shipped rollout config; RB_LORA=1 / 2 adds a frozen
+adapter unmerged / merged, RB_FUSE=0 switches the fused SwiGLU gate|up projection off, RB_BATCH = sequences per device, shipped: 4).
+Reports prefill ms, decode ms/step and tokens/s; the decode roofline is HBM: >= 13.2 GB of bf16 weights per step."""
 import json
 import os
 import sys
