@@ -2265,9 +2265,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     if (a.M <= 64 && ((stream_hint && g_gemm_variant == 10) || g_gemm_variant == 15) && a.a1_group_n <= 0 && a.K1 % 32 == 0) {
       const int mf = (a.M + 15) / 16;
       const dim3 bl(512), gr(a.N / 32);
-      if (g_skinny8 && a.M <= 16) {
+      if (g_skinny8 && (a.M <= 16 || (a.M <= 32 && a.N / 32 < 512))) {       // same kernel family as the plain projection of this size
         if (a.M <= 8) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<1, 2, 8, true>), dim3(a.N / 16), bl, 0, st, a);
-        else hipLaunchKernelGGL((gemm_nt_skinny8_kernel<2, 2, 4, true>), dim3(a.N / 16), bl, 0, st, a);
+        else if (a.M <= 16) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<2, 2, 4, true>), dim3(a.N / 16), bl, 0, st, a);
+        else if (a.M <= 24) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<3, 2, 2, true>), dim3(a.N / 16), bl, 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_skinny8_kernel<4, 2, 2, true>), dim3(a.N / 16), bl, 0, st, a);
         return hipGetLastError();
       }
       if (mf == 1) hipLaunchKernelGGL((gemm_nt_skinny_kernel<1, 2, 8, true>), gr, bl, 0, st, a);
@@ -2289,6 +2291,13 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                       (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0);
     const dim3 bl(512), gr(wide ? a.N / 32 : a.N / 16);
 #define SK(MF_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny_kernel<MF_, NR_, U_>), gr, bl, 0, st, a)
+    if (g_skinny8 && a.M > 16 && a.M <= 32 && !wide && (a.a1_group_n <= 0 || a.a1_group_n % 16 == 0) && (a.a2_group_n <= 0 || a.a2_group_n % 16 == 0)) {
+      // 17..32 tokens, narrow N (q|k|v, o, down at 7B): the whole-cache-line form still wins (M = 24: 37 -> 31, 15 -> 13, 37 -> 28 us);
+      // the 32-row form above keeps the wide projections (activation re-reads from L2 dominate there)
+      if (a.M <= 24) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<3, 2, 2>), dim3(a.N / 16), bl, 0, st, a);
+      else hipLaunchKernelGGL((gemm_nt_skinny8_kernel<4, 2, 2>), dim3(a.N / 16), bl, 0, st, a);
+      return hipGetLastError();
+    }
     if (g_skinny8 && a.M <= 16 && (a.a1_group_n <= 0 || a.a1_group_n % 32 == 0) && (a.a2_group_n <= 0 || a.a2_group_n % 32 == 0)) {
       const bool wide8 = a.N % 32 == 0 && a.N / 32 >= 512;          // 32 weight rows per workgroup while >= 2 rounds of blocks remain
 #define SK8(MF8_, NR_, U_) hipLaunchKernelGGL((gemm_nt_skinny8_kernel<MF8_, NR_, U_>), dim3(a.N / (8 * NR_)), bl, 0, st, a)

@@ -69,7 +69,8 @@ def test_gemm_nt(L, glds, M, N, K1, K2, groups):
     assert e < 6e-3, f"gemm_nt rel err {e}"   # bf16 output rounding ~ 2^-9
 
 
-@pytest.mark.parametrize("M,tr", [(1, 1), (3, 1), (8, 1), (9, 1), (16, 1), (17, 1), (40, 1), (64, 1), (1, 17), (8, 17), (16, 17)])
+@pytest.mark.parametrize("M,tr", [(1, 1), (3, 1), (8, 1), (9, 1), (16, 1), (17, 1), (24, 1), (25, 1), (32, 1), (40, 1), (64, 1), (1, 17), (8, 17),
+                                  (16, 17), (24, 17)])
 @pytest.mark.parametrize("N,K1,K2,groups", [(256, 4096, 0, 0), (384, 192, 128, 3), (16384, 128, 64, 2), (128, 2752, 256, 1),
                                             (22016, 64, 128, 2)])
 def test_gemm_nt_skinny(L, M, tr, N, K1, K2, groups):
@@ -857,8 +858,8 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert relerr(got[:M], ref) < 2e-2
 
 
-@pytest.mark.parametrize("M,tr", [(1, 1), (4, 1), (8, 1), (9, 1), (16, 1), (17, 1), (40, 1), (64, 1), (4, 17), (16, 17)])
-@pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008)])
+@pytest.mark.parametrize("M,tr", [(1, 1), (4, 1), (8, 1), (9, 1), (16, 1), (17, 1), (24, 1), (32, 1), (40, 1), (64, 1), (4, 17), (16, 17), (24, 17)])
+@pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008), (11008, 256)])
 def test_gemm_nt_swiglu_pair_decode(L, M, tr, F, K):
     """The same fused SwiGLU epilogue in the weight-streaming (decode, M <= 64) kernel: bit-identical to the streaming projection
     followed by opadpo_silu_mul_fwd; rows >= M untouched."""
