@@ -64,11 +64,14 @@ def answer_questions(engine: LlavaEngine, tokenizer, questions: list, image_fold
                      checkpoint: Optional[str] = None, adapter: Optional[LoraAdapter] = None, model_id: str = "opadpo-hip",
                      temperature: float = 0.0, top_p: Optional[float] = None, short_eval: bool = False, max_new_tokens: Optional[int] = None,
                      test_prompt: Optional[str] = DEFAULT_TEST_PROMPT, image_size: int = 336, pad_to_square: bool = True, seed: int = 0,
-                     merge_adapter: bool = False) -> int:
+                     merge_adapter: bool = False, batch_size: int = 1) -> int:
     """One JSON line per question: question_id, prompt (the bare question), text (stripped answer, a trailing '</s>' removed),
     answer_id, model_id, metadata (model_vqa.py:143-262).  Refuses to overwrite an existing answers file like the script's
     __main__.  max_new_tokens defaults to 64 (`short_eval`) or 1024.  merge_adapter: merge the frozen checkpoint adapter once (PEFT
-    `merge_and_unload` equivalent; bf16 rounding of the merged weights) - every question then decodes without LoRA launches."""
+    `merge_and_unload` equivalent; bf16 rounding of the merged weights) - every question then decodes without LoRA launches.
+    batch_size > 1: that many questions share one generation (prompts left-padded to a common length, pads masked; rotary
+    attention only sees position differences, so a row's answer does not depend on its padding) - the decode step streams the
+    weights once per BATCH: 16 questions cost about 1.5x the time of one.  The reference script runs one question at a time."""
     import json
     import uuid
     from PIL import Image
@@ -83,19 +86,25 @@ def answer_questions(engine: LlavaEngine, tokenizer, questions: list, image_fold
     if parent:
         os.makedirs(parent, exist_ok=True)
     n = 0
+    pad = tokenizer.pad_token_id
     with open(answers_file, "w") as f:
-        for line in questions:
-            ids = torch.tensor([tokenize_with_image(eval_prompt(line["text"], test_prompt), tokenizer)], dtype=torch.long)
-            pil = Image.open(os.path.join(image_folder, line["image"])).convert("RGB")
-            image = preprocess_image(pil, image_size, pad_to_square)[None].to(engine.dev)
-            out = generate_from_checkpoint(engine, None, ids.to(engine.dev), torch.ones_like(ids).to(engine.dev), image, max_new_tokens=n_new,
+        for c0 in range(0, len(questions), max(1, batch_size)):
+            chunk = questions[c0:c0 + max(1, batch_size)]
+            rows = [tokenize_with_image(eval_prompt(line["text"], test_prompt), tokenizer) for line in chunk]
+            width = max(len(r) for r in rows)
+            ids = torch.tensor([[pad] * (width - len(r)) + r for r in rows], dtype=torch.long)
+            mask = torch.tensor([[0] * (width - len(r)) + [1] * len(r) for r in rows], dtype=torch.long)
+            images = torch.stack([preprocess_image(Image.open(os.path.join(image_folder, line["image"])).convert("RGB"), image_size, pad_to_square)
+                                  for line in chunk]).to(engine.dev)
+            out = generate_from_checkpoint(engine, None, ids.to(engine.dev), mask.to(engine.dev), images, max_new_tokens=n_new,
                                            temperature=temperature, top_p=1.0 if top_p is None else top_p, seed=seed + n, adapter=adapter,
                                            merge_adapter=merge_adapter)
-            text = tokenizer.batch_decode(out.cpu(), skip_special_tokens=True)[0].strip()
-            if text.endswith(SEP2):
-                text = text[:-len(SEP2)]
-            f.write(json.dumps({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(),
-                                "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}}) + "\n")
+            for line, text in zip(chunk, tokenizer.batch_decode(out.cpu(), skip_special_tokens=True)):
+                text = text.strip()
+                if text.endswith(SEP2):
+                    text = text[:-len(SEP2)]
+                f.write(json.dumps({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(),
+                                    "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}}) + "\n")
+                n += 1
             f.flush()
-            n += 1
     return n

@@ -374,6 +374,20 @@ def test_eval_question_file_to_answers_file(setup, tmp_path):
         assert line["text"] == Tok().batch_decode(want.cpu())[0].strip()
     with pytest.raises(FileExistsError):
         eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans), adapter=s["pol"], max_new_tokens=6, image_size=d.image_size)
+    # several questions per generation: prompts left-padded to a common length; same plumbing as one batched generate call
+    ans3 = tmp_path / "answers_batched.jsonl"
+    assert eg.answer_questions(s["eng"], Tok(), qs, str(tmp_path), str(ans3), adapter=s["pol"], max_new_tokens=6, image_size=d.image_size,
+                               batch_size=2) == 2
+    rows = [tokenize_with_image(eg.eval_prompt(q["text"]), Tok()) for q in qs]
+    width = max(len(r) for r in rows)
+    assert len(rows[0]) != len(rows[1])
+    bids = torch.tensor([[0] * (width - len(r)) + r for r in rows])
+    bmask = torch.tensor([[0] * (width - len(r)) + [1] * len(r) for r in rows])
+    bimg = torch.stack([preprocess_image(Image.open(tmp_path / q["image"]).convert("RGB"), d.image_size, True) for q in qs]).to(s["dev"])
+    want = eg.generate_from_checkpoint(s["eng"], None, bids.to(s["dev"]), bmask.to(s["dev"]), bimg, max_new_tokens=6, adapter=s["pol"])
+    got3 = [json.loads(x) for x in open(ans3)]
+    assert [x["question_id"] for x in got3] == [7, 9]
+    assert [x["text"] for x in got3] == [t.strip() for t in Tok().batch_decode(want.cpu())]
     # checkpoint on disk + merged adapter: same file format, adapter folded once
     from opadpo_amd.trainer import save_adapter
     ckpt = tmp_path / "checkpoint-1"
