@@ -123,3 +123,40 @@ def synth_rollout_batches(d: LlavaDims, args, seed: int = 0):
             batch[k + "_image_relations"] = torch.tensor([1.0, 3.0])[torch.randint(0, 2, (B, T), generator=g)] * m
         yield batch
         step += 1
+
+
+class SyntheticTokenizer:
+    """Whitespace word-hash tokenizer for the --synthetic launch modes (no sentencepiece model offline): BOS 1, EOS 2, pad 0, words
+    hashed into [3, vocab).  `batch_decode` renders ids as 'w<id>' words; special tokens are dropped on request."""
+    pad_token_id, eos_token_id, bos_token_id = 0, 2, 1
+
+    def __init__(self, vocab: int):
+        self.vocab = int(vocab)
+
+    def _ids(self, text: str):
+        return [self.bos_token_id] + [3 + sum(ord(c) * (i + 1) for i, c in enumerate(w)) % (self.vocab - 3) for w in text.split()]
+
+    def __call__(self, text, **_):
+        if isinstance(text, str):
+            return {"input_ids": self._ids(text)}
+        return {"input_ids": [self._ids(t) for t in text]}
+
+    def batch_decode(self, ids, skip_special_tokens: bool = True, clean_up_tokenization_spaces: bool = True):
+        keep = (lambda t: t > 2) if skip_special_tokens else (lambda t: True)
+        return [" ".join(f"w{int(t)}" for t in row if keep(int(t))) for row in ids]
+
+
+def synth_question_rows(n: int, seed: int = 0):
+    """n rows in the RLAIF-V layout the rollout stage reads ('question', 'chosen', 'image' = {'bytes', 'path'}) with flat-colour PNGs."""
+    import io
+    from PIL import Image
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for i in range(n):
+        col = tuple(int(c) for c in torch.randint(0, 256, (3,), generator=g))
+        buf = io.BytesIO()
+        Image.new("RGB", (int(torch.randint(8, 40, (1,), generator=g)), int(torch.randint(8, 40, (1,), generator=g))), col).save(buf, format="PNG")
+        nq = int(torch.randint(3, 9, (1,), generator=g))
+        rows.append({"question": " ".join(f"q{i}w{j}" for j in range(nq)) + " ?", "chosen": " ".join(f"a{i}w{j}" for j in range(4)),
+                     "image": {"bytes": buf.getvalue(), "path": f"synthetic_{i}.png"}})
+    return rows

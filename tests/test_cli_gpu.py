@@ -61,3 +61,55 @@ def test_sft_entry_point(tmp_path):
     assert set(ck3) == set(sd) and sum(float((ck3[k].float() - sd[k].float()).abs().sum()) for k in sd) > 0
     with pytest.raises(SystemExit):
         cli_sft.main(argv + ["--full_tune", "True"])
+
+
+def test_rollout_entry_point_writes_step_files(tmp_path, monkeypatch):
+    """opadpo/online_generation_custom.py surface on a synthetic tiny model: rows -> left-padded queries -> sampled responses ->
+    step{N}_rank{R}.json, readable by the dataset builder (all records dropped by its first filter: no feedback model here)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd import cli_generate as cg
+    from opadpo_amd.dataset_build import build_rows, load_rollout_records
+    out = str(tmp_path / "gen")
+    ns, _ = cg.rollout_parser().parse_known_args(
+        ["--synthetic", "tiny", "--synthetic_rows", "7", "--output_dir", out, "--rollout_batch_size", "4", "--rollout_per_device_batch_size", "2",
+         "--query_len", "64", "--response_len", "6", "--top_k", "10", "--base_model", "ignored", "--phase", "0", "--local-rank", "0"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    files = cg.run_rollout(ns, log=lambda *_: None)
+    assert [os.path.basename(f) for f in files] == ["step0_rank0.json", "step1_rank0.json"]
+    recs = load_rollout_records([os.path.join(out, "rollouts")], log=lambda *_: None)
+    assert len(recs) == 7 and set(recs[0]) == {"query", "image_id", "standard_response", "original_generate_response", "AI_generate_response",
+                                               "AI_pseudo_response", "AI_json_report", "image_bytes"}
+    assert [r["image_id"] for r in recs] == [f"synthetic_{i}.png" for i in range(7)]
+    assert all(r["query"].startswith("<image>\n") for r in recs)
+    assert build_rows([os.path.join(out, "rollouts")], log=lambda *_: None) == []
+    # a feedback callable fills the report fields
+    fb = lambda urls, q, rsp, std: {"Pseudo_response": [s + " fixed" for s in std], "Generated_response": list(rsp),
+                                    "report_json": [{"Sentence 1": {"score": 4}}] * len(rsp)}
+    ns.output_dir = str(tmp_path / "gen_fb")
+    ns.max_step = 1
+    files = cg.run_rollout(ns, feedback=fb, log=lambda *_: None)
+    assert len(files) == 1
+    rows = build_rows([os.path.join(ns.output_dir, "rollouts")], log=lambda *_: None)
+    assert 0 < len(rows) <= 4 and rows[0]["AI_pseudo_response"].endswith(" fixed")
+
+
+def test_eval_entry_point(tmp_path):
+    """eval_llava_rlhf_coco/model_vqa.py surface: question file -> answers file; an existing answers file is refused."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from PIL import Image
+    from opadpo_amd import cli_generate as cg
+    Image.new("RGB", (12, 7), (10, 120, 200)).save(tmp_path / "x.png")
+    qf = tmp_path / "q.jsonl"
+    qf.write_text("".join(json.dumps({"question_id": i, "image": "x.png", "text": f"what is item {i} ?"}) + "\n" for i in range(5)))
+    ans = tmp_path / "out" / "a.jsonl"
+    argv = ["--synthetic", "tiny", "--model-path", "tiny-model", "--use-qlora", "True", "--qlora-path", "synthetic", "--question-file", str(qf),
+            "--image-folder", str(tmp_path), "--answers-file", str(ans), "--short_eval", "True", "--batch-size", "2", "--num-chunks", "2",
+            "--chunk-idx", "0", "--test-prompt", ""]
+    cg.main_eval(argv)
+    lines = [json.loads(x) for x in open(ans)]
+    assert [x["question_id"] for x in lines] == [0, 1, 2] and lines[0]["model_id"] == "tiny-model" and lines[0]["prompt"] == "what is item 0 ?"
+    with pytest.raises(SystemExit):
+        cg.main_eval(argv)
