@@ -144,7 +144,10 @@ def run_rollout(args, feedback: Optional[Callable] = None, log=print) -> List[st
 
 
 def main_rollout(argv: Optional[List[str]] = None) -> None:
-    ns, _ignored = rollout_parser().parse_known_args(sys.argv[1:] if argv is None else argv)
+    argv = sys.argv[1:] if argv is None else argv
+    ns, _ignored = rollout_parser().parse_known_args(argv)
+    from .cli import load_yaml_defaults
+    load_yaml_defaults(ns, argv)          # --cfg fills what the command line left unset
     run_rollout(ns)
 
 
