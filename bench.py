@@ -22,6 +22,8 @@ for p in (REPO, os.path.join(REPO, "opa-dpo_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
