@@ -119,9 +119,10 @@ class QueryResponseDataset(torch.utils.data.Dataset):
         self.queries = torch.stack([_pad(queries[i], query_len, tokenizer.pad_token_id, left=True) for i in keep])
         self.query_attn_masks = self.queries.ne(tokenizer.pad_token_id).long()
         self.standard_responses = torch.stack([_pad(r, width, tokenizer.pad_token_id, left=False) for r in responses])
-        # Quirk kept: the auxiliary records are NOT filtered (data_utils_online_gpt4v.py:127), so after a dropped row the image
-        # at index i belongs to the i-th ORIGINAL row.
-        self.rows = rows
+        # Deliberate fix: the reference keeps the UNFILTERED records next to the filtered tensors (data_utils_online_gpt4v.py:127),
+        # so after a dropped row item i pairs query i with the image of original row i - a different sample.  Here the records
+        # are filtered with the tensors.  Identical whenever no prompt exceeds query_len (the shipped data: questions << 128 tokens).
+        self.rows = [rows[i] for i in keep]
         self.image_size, self.pad_to_square = image_size, pad_to_square
 
     def __len__(self) -> int:

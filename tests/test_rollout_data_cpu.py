@@ -90,8 +90,8 @@ def test_items_and_collation():
     assert batch["queries"].shape == (2, 48) and batch["images"].shape == (2, 3, 8, 8)
     assert batch["images_path"] == ["a.png", "b.png"] and batch["images_bytes"][0] == _rows()[0]["image"]["bytes"]
     assert batch["images_url"][1].startswith("data:image/jpeg;base64,")
-    # quirk kept (data_utils_online_gpt4v.py:127): records are not filtered, index 2 still points at the dropped row's image
-    assert ds[2]["images_path"] == "c.png"
+    # deliberate fix of data_utils_online_gpt4v.py:127 (records kept unfiltered there): item 2 is original row 3, image included
+    assert ds[2]["images_path"] == "d.png" and ds[2]["images_bytes"] == _rows()[3]["image"]["bytes"]
     with pytest.raises(ValueError):
         bad = _rows(); bad[0]["image"]["bytes"] = b"not an image"
         rd.QueryResponseDataset(bad, tok, query_len=48, image_size=8, log=lambda *_: None)[0]
@@ -126,7 +126,7 @@ def test_rollout_step_columns_and_dataset_round_trip(tmp_path):
                          "AI_pseudo_response", "AI_json_report", "image_bytes"]
     assert all(len(v) == 3 for v in out.values())
     assert out["original_generate_response"] == canned and out["standard_response"][0] == "a cat sits there"
-    assert out["image_id"] == ["a.png", "b.png", "c.png"] and all(q.startswith("<image>\n") for q in out["query"])
+    assert out["image_id"] == ["a.png", "b.png", "d.png"] and all(q.startswith("<image>\n") for q in out["query"])
     path = write_rollout_json(str(tmp_path), 0, out, rank=0)
     rows = build_rows([os.path.dirname(path)], log=lambda *_: None)
     assert len(rows) == 3 and rows[1]["AI_pseudo_response"] == "two dogs run . (fixed)"
