@@ -113,6 +113,36 @@ def test_gemm_nt_skinny(L, M, tr, N, K1, K2, groups):
     assert torch.equal(o5, o32)
 
 
+@pytest.mark.parametrize("M", [2, 8, 13, 24, 31, 50])
+def test_gemm_nt_decode_strided_operands(L, M):
+    """Decode-schedule kernels with every operand a column slice of a wider buffer (lda / ldb / ldc / ldr != logical width),
+    LoRA tail included: the streaming kernels address rows through the leading dimensions only."""
+    L.set_flags(10, True)
+    N, K1, K2 = 640, 320, 64
+    A = rnd(M, K1 + 96, scale=0.5, seed=1); W = rnd(N, K1 + 32, scale=0.2, seed=2)
+    A2 = rnd(M, K2 + 64, scale=0.5, seed=3); W2 = rnd(N, K2 + 128, scale=0.2, seed=4)
+    a1, b1, a2, b2 = A[:, 32:32 + K1], W[:, 8:8 + K1], A2[:, 64:], W2[:, 64:64 + K2]
+    Rf = torch.randn(M, N + 16, device=dev()); res = Rf[:, 8:8 + N]
+    O = torch.full((M + 1, N + 24), 5.0, device=dev()); out = O[:M, 16:16 + N]
+    want = a1.float() @ b1.float().t() + a2.float() @ b2.float().t() + res
+    with L.decode_schedule():
+        L.gemm_nt(a1, b1, out, a2=a2, b2=b2, residual=res)
+    torch.cuda.synchronize()
+    assert relerr(out, want) < 2e-5
+    O2 = O.clone(); O2[:M, 16:16 + N] = 5.0
+    assert float((O2 - 5.0).abs().max()) == 0.0          # nothing outside the [M, N] window written
+    F = 256
+    Wg = rnd(2 * F, K1 + 64, scale=0.2, seed=7); wsw = Wg[:, 16:16 + K1]
+    Ob = torch.full((M + 1, F + 8), 3.0, dtype=BF, device=dev()); ob = Ob[:M, 8:]
+    with L.decode_schedule():
+        L.gemm_nt(a1, wsw, ob, act=L.ACT_SWIGLU_PAIR)
+    torch.cuda.synchronize()
+    z = a1.float() @ wsw.float().t()
+    z = z.view(M, F // 64, 2, 64)
+    assert relerr(ob, (torch.nn.functional.silu(z[:, :, 0]) * z[:, :, 1]).reshape(M, F)) < 2e-2
+    assert float((Ob[M].float() - 3.0).abs().max()) == 0.0 and float((Ob[:M, :8].float() - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant", [10, 23, 17])
 def test_gemm_nt_epilogue_large(L, variant):
     """Epilogues at a size the auto dispatch sends to the 256x256 kernels (>= 320 blocks, ragged M edge): the 4-wave kernel's
