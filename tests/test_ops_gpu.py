@@ -785,6 +785,34 @@ def test_attn_decode_fused(L, B, nh, hd, pos, max_ctx):
         assert relerr(o2, o1.float()) < 4e-3
 
 
+def test_attn_decode_fused_last_slot_and_wide_rows(L):
+    """Fused decode attention at the LAST cache slot (pos = max_ctx - 1) with the q|k|v rows embedded in a wider buffer (ld > 3H)."""
+    B, nh, hd, max_ctx = 3, 4, 128, 40
+    pos, H = max_ctx - 1, nh * hd
+    wide = rnd(B, 3 * H + 64, seed=1)
+    qkv = wide[:, 32:32 + 3 * H]
+    half = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, device=dev()).float() / half))
+    ang = torch.arange(max_ctx, device=dev()).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    posd = torch.tensor([pos], dtype=torch.int32, device=dev())
+    kc, vc = rnd(B, nh, max_ctx, hd, seed=2), rnd(B, nh, max_ctx, hd, seed=3)
+    km = torch.ones(B, max_ctx, dtype=torch.uint8, device=dev())
+    km[1, 5:9] = 0
+    kc1, vc1, q1 = kc.clone(), vc.clone(), qkv.clone().contiguous()
+    o1 = torch.empty(B, H, dtype=BF, device=dev())
+    L.call("opadpo_rope_kv_append", q1.data_ptr(), 3 * H, cos.data_ptr(), sin.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), B, nh, hd, posd.data_ptr(), max_ctx, L.stream())
+    L.call("opadpo_attn_decode", q1.data_ptr(), 3 * H, kc1.data_ptr(), vc1.data_ptr(), o1.data_ptr(), km.data_ptr(), B, nh, hd, 0, posd.data_ptr(), max_ctx,
+           hd ** -0.5, None, 0, L.stream())
+    o2 = torch.empty(B, H, dtype=BF, device=dev())
+    before = wide.clone()
+    L.call("opadpo_attn_decode_fused", qkv.data_ptr(), wide.stride(0), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr(), o2.data_ptr(), km.data_ptr(),
+           B, nh, hd, posd.data_ptr(), max_ctx, hd ** -0.5, None, 0, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wide, before) and torch.equal(kc, kc1) and torch.equal(vc, vc1)
+    assert relerr(o2, o1.float()) < 4e-3
+
+
 def test_sampler_distribution(L):
     V, rows = 512, 4000
     torch.manual_seed(3)
