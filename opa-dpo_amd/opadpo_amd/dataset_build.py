@@ -171,3 +171,33 @@ def main(argv=None) -> None:
 
 if __name__ == "__main__":
     main()
+
+
+# ---- rollout-stage input: four stratified subsets of the RLAIF-V pool (base_operations/make_online_generation_dataset.py:10-47) ----
+def stratified_subsets(df, per_subset: int = 2500, key: str = "origin_dataset", seed: int = 42):
+    """Four disjoint subsets of `per_subset` rows each, stratified by `key`: 4 * per_subset rows are drawn from the pool, halved,
+    and each half halved again - the reference's chain of sklearn `train_test_split(stratify=..., random_state=42)` calls, so the
+    same pool gives the same rows in the same order.  Returns [subset1, subset2, subset3, subset4] (pandas DataFrames)."""
+    from sklearn.model_selection import train_test_split
+    n = 4 * per_subset
+    _, pool = train_test_split(df, test_size=n, stratify=df[key], random_state=seed)
+    first, second = train_test_split(pool, test_size=n // 2, stratify=pool[key], random_state=seed)
+    s1, s2 = train_test_split(first, test_size=n // 4, stratify=first[key], random_state=seed)
+    s3, s4 = train_test_split(second, test_size=n // 4, stratify=second[key], random_state=seed)
+    return [s1, s2, s3, s4]
+
+
+def make_online_generation_subsets(data_files: Sequence[str], out_root: str = "./base_datasets/LLaVA-RLAIF-SubData", per_subset: int = 2500,
+                                   log=print) -> List[str]:
+    """Parquet shards of the RLAIF-V dataset -> `<out_root>/subset{1..4}` HF datasets (the `--data_path` of run/online_generate.sh)."""
+    import pandas as pd
+    from datasets import Dataset, load_dataset
+    train = load_dataset("parquet", data_files=list(data_files))["train"]
+    df = pd.DataFrame(train)
+    log(f"pool: {len(df)} rows, origins: {dict(df['origin_dataset'].value_counts())}")
+    paths = []
+    for i, sub in enumerate(stratified_subsets(df, per_subset), 1):
+        path = os.path.join(out_root, f"subset{i}")
+        Dataset.from_pandas(sub).save_to_disk(path)
+        paths.append(path)
+    return paths

@@ -75,3 +75,33 @@ def test_rollout_json_writer(tmp_path):
     with pytest.raises(ValueError):
         DB.write_rollout_json(str(tmp_path), 8, {"query": ["a"], "image_id": []}, rank=0)
     assert DB.write_rollout_json(None, 1, cols) is None
+
+
+def test_stratified_subsets_match_the_reference_script(tmp_path):
+    """dataset_build.stratified_subsets / make_online_generation_subsets on the synthetic pool of tests/golden/make_subsets_golden.py:
+    the same four 2500-row subsets, in the same order, as the reference's base_operations/make_online_generation_dataset.py."""
+    import importlib.util
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_online_subsets.json")))
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(__file__), "golden", "make_subsets_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    assert (mk.N_ROWS, mk.N_SHARDS, mk.SEED) == (gold["n_rows"], gold["n_shards"], gold["seed"])
+    df = mk.pool()
+    from opadpo_amd.dataset_build import make_online_generation_subsets, stratified_subsets
+    subs = stratified_subsets(df)
+    assert [list(s["idx"]) for s in subs] == gold["subsets"]
+    ids = [set(s["idx"]) for s in subs]
+    assert all(len(i) == 2500 for i in ids) and len(set().union(*ids)) == 10000           # disjoint
+    share = [float((s["origin_dataset"] == "VQAv2").mean()) for s in subs]
+    assert max(share) - min(share) < 0.01                                                  # stratified
+    # through parquet shards and HF datasets on disk (smaller subsets: same chain of splits)
+    d = tmp_path / "pool"
+    d.mkdir()
+    per = (len(df) + 3) // 4
+    files = []
+    for i in range(4):
+        files.append(str(d / f"RLAIF-V-Dataset_{i:03d}.parquet"))
+        df.iloc[i * per:(i + 1) * per].to_parquet(files[-1], index=False)
+    paths = make_online_generation_subsets(files, str(tmp_path / "sub"), per_subset=2500, log=lambda *_: None)
+    from datasets import load_from_disk
+    assert [list(load_from_disk(p)["idx"]) for p in paths] == gold["subsets"]
