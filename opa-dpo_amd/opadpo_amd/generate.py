@@ -102,7 +102,7 @@ class Generator:
         last = (torch.arange(B, device=dev, dtype=torch.int32) * Lp + (Lp - 1)).contiguous()
         # ---- decode: ONE step captured in a HIP graph and replayed per token -----------------------------------
         # Everything that changes from step to step lives in device memory (position / step counter,
-        # current tokens, finished flags), so the ~10 launches x n_layers of a step are recorded once and
+        # current tokens, finished flags), so the 7-12 launches x n_layers of a step (7: adapter-free or merged adapter with the fused SwiGLU projection) are recorded once and
         # replayed with a single hipGraphLaunch (the eager loop was host-launch-bound: ~480 Python->C calls per token).
         key_mask[:, Lp:] = 1                       # future slots: valid as soon as ctx (device counter) reaches them
         x = e((B, H), torch.float32)
