@@ -488,10 +488,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
+  const int width = p.group_m * tiles_n;
   const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int first_m = group_id * p.group_m;
+  const int gsz = min(tiles_m - first_m, p.group_m);
   const int tm = first_m + (swz % width) % gsz;
   const int tn = (swz % width) / gsz;
   const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
@@ -1092,10 +1092,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4m_kernel(GemmNTArgs p) {
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
+  const int width = p.group_m * tiles_n;
   const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int first_m = group_id * p.group_m;
+  const int gsz = min(tiles_m - first_m, p.group_m);
   const int tm = first_m + (swz % width) % gsz;
   const int tn = (swz % width) / gsz;
   const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
@@ -2230,6 +2230,11 @@ bool opadpo_flag_tr() { return g_use_tr; }
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
   GemmNTArgs a = a_in;
+  // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
+  // (N <= 4096: o / down and three of the four dgrads) - measured at M = 32362: down 1.363 -> 1.397 PF/s, o 1.394 -> 1.401,
+  // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).
+  static const int env_gm = getenv("OPADPO_W4_GM") ? atoi(getenv("OPADPO_W4_GM")) : 0;
+  a.group_m = env_gm > 0 ? env_gm : (a.N / P_BN <= 16 ? 4 : 8);
   const bool stream_hint = (a.act & OPADPO_GEMM_STREAM) != 0;
   a.act &= 0xff;
   if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;

@@ -25,6 +25,7 @@ struct GemmNTArgs {
   const float* rope_cos = nullptr;
   const float* rope_sin = nullptr;
   int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
+  int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
 };
 
 struct GemmTNArgs {
