@@ -31,12 +31,17 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH
 
 
 def _pmc_traffic():
-    """Average HBM bytes per gemm_nt launch from the committed PMC passes of this same workload (rocprofv3 cannot run
-    inside the timed process): profiles/r01_pmc_traffic.json, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE."""
-    try:
-        return json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["gemm_nt_avg_hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM-side bytes per gemm_nt launch (launch-weighted mean over the gemm_nt kernels of one optimizer step) from the committed
+    rocprofv3 --pmc passes of THIS workload and THIS round's kernels (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate
+    passes, FETCH_SIZE x2 = the gfx950 correction; rocprofv3 cannot run inside the timed process).  Newest profiles/r*_pmc_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            return json.load(open(f))["gemm_nt_avg_hbm_bytes_per_launch"], os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(dims_kw, q_len, t_len):
@@ -73,9 +78,86 @@ def cpu_baseline(dims_kw, q_len, t_len):
         return time.time() - t0
     dt = min(one_pair(), one_pair())                                                   # ~10 s of CPU work in total
     pair_s = dt * d.n_layers
-    return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": min(os.cpu_count(), 64), "kind": "port",
-            "sample": f"1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), L={L}, "
+    return {"value": 1.0 / pair_s, "unit": "pairs/s", "cores": min(os.cpu_count(), 64), "kind": "port", "extrapolated": True,
+            "sample": f"EXTRAPOLATED from 1 of {d.n_layers} decoder layers at 7B width (fp32 torch CPU oracle), L={L}, "
                       f"both sequences of a pair: reference forward + policy forward + LoRA backward = {dt:.1f} s per layer-pair (best of 2), scaled x{d.n_layers}"}
+
+
+def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
+    """BASELINE.json configs[4] (on-policy rollout, opadpo/generator_models/online_generator.py:292-309) in the driver's line:
+    LLaVA-1.5-7B KV-cache sampling decode (top-k 30 / top-p 0.95, no LoRA = the shipped rollout config), prefill L = 703, `steps`
+    graph-replayed decode steps per batch size.  HBM-bound: bytes per step = bf16 weights of every linear + lm_head (read once per
+    step) + the KV cache read of every sequence at the mean context of the timed steps; frac = bytes / time / 8 TB/s."""
+    from opadpo_amd.generate import Generator
+    from opadpo_amd.synth import synth_pairs
+    out = {}
+    gen = Generator(eng, None, use_graph=True, fuse_swiglu=True)
+    wbytes = 2 * (d.n_layers * (4 * d.hidden ** 2 + 3 * d.hidden * d.ffn) + d.vocab * d.hidden)
+    for B in batches:
+        p = synth_pairs(d, B, 128, 8, seed=77, device=dev)
+        feats = eng.encode_images(p["images"])
+        t = {}
+        for n in (2, steps + 2):
+            kw = dict(image_feats=feats, max_new_tokens=n, top_k=30, top_p=0.95, suppress_eos=True)
+            gen.generate(p["queries"], p["queries_attn_masks"], seed=1, **kw)            # warm (kernels, graph capture path)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gen.generate(p["queries"], p["queries_attn_masks"], seed=2, **kw)
+            torch.cuda.synchronize()
+            t[n] = time.perf_counter() - t0
+        per_step = (t[steps + 2] - t[2]) / steps
+        ctx = 128 + d.n_patches - 1 + 2 + steps / 2
+        kv = 2 * 2 * d.n_layers * d.hidden * ctx * B
+        out[f"b{B}"] = {"batch": B, "decode_ms_per_step": per_step * 1e3, "tokens_per_s": B / per_step, "prefill_plus_2_steps_ms": t[2] * 1e3,
+                        "bytes_per_step_GB": (wbytes + kv) / 1e9, "weight_GB": wbytes / 1e9, "kv_GB": kv / 1e9,
+                        "hbm_frac": (wbytes + kv) / per_step / 8e12, "steps_timed": steps}
+        del feats, p
+        torch.cuda.empty_cache()
+    return {"workload": "LLaVA-1.5-7B rollout decode, query 128 -> prefill L=703, top-k 30 / top-p 0.95, no LoRA (shipped rollout config), "
+                        "one HIP-graph replay per token", "bound": "hbm", "peak_GBps": 8000.0, **out}
+
+
+def exchange_probe(numel, dev, layer_numel, n_layers):
+    """1-rank timing of the data-parallel exchange path of one optimizer step on THIS GPU (no multi-GPU node is
+    visible to this run): the fp32 -> bf16 staging casts, the per-bucket reduce-scatter and the per-bucket all-gather of FlatAdamW
+    over a 1-rank RCCL group (device-local copies at world 1 - the floor of the exchange, not an xGMI number)."""
+    from opadpo_amd.optim import FlatAdamW, layer_buckets
+    made = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        made = True
+    prev = os.environ.get("OPADPO_FORCE_COLLECTIVES")
+    os.environ["OPADPO_FORCE_COLLECTIVES"] = "1"
+    try:
+        master = torch.zeros(numel, dtype=torch.float32, device=dev)
+        grad = torch.randn(numel, dtype=torch.float32, device=dev) * 1e-3
+        work = torch.zeros(numel, dtype=torch.bfloat16, device=dev)
+        opt = FlatAdamW(master, grad, work, lr=1e-6, max_grad_norm=1.0, mode="zero1", bucket_bounds=layer_buckets(layer_numel, n_layers, 4))
+        res = {}
+        for it in range(3):
+            torch.cuda.synchronize()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            for bi in range(len(opt.buckets) - 1, -1, -1):
+                opt.launch_bucket(bi)
+            opt.prepare()
+            e[1].record()
+            opt.apply()
+            e[2].record()
+            torch.cuda.synchronize()
+            res = {"reduce_scatter_and_norm_ms": e[0].elapsed_time(e[1]), "adamw_and_all_gather_ms": e[1].elapsed_time(e[2])}
+        res.update({"world": 1, "buckets": len(opt.buckets), "wire_dtype": "bf16", "wire_bytes_per_rank_GB": 2 * numel / 1e9,
+                    "note": "1-rank RCCL group on one MI355X (OPADPO_FORCE_COLLECTIVES=1): device-local floor of the exchange path, launched per bucket"})
+        return res
+    finally:
+        if prev is None:
+            os.environ.pop("OPADPO_FORCE_COLLECTIVES", None)
+        else:
+            os.environ["OPADPO_FORCE_COLLECTIVES"] = prev
+        if made:
+            dist.destroy_process_group()
 
 
 def main():
@@ -93,6 +175,8 @@ def main():
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
     args = ap.parse_args()
     pack = not args.no_pack
@@ -116,7 +200,7 @@ def main():
     from opadpo_amd.dims import LlavaDims, lora_param_count, pair_flops, pair_flops_packed
     from opadpo_amd.losses import DPOArgs, pair_loss
     from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
-    from opadpo_amd.optim import FlatAdamW
+    from opadpo_amd.optim import FlatAdamW, layer_buckets
     from opadpo_amd.policy import AutoregressivePolicy
     from opadpo_amd.synth import init_lora, init_weights, synth_pairs
     L.load()
@@ -134,12 +218,19 @@ def main():
     torch.cuda.empty_cache()
     policy = AutoregressivePolicy(eng, pol_ad, t_len, pack_responses=pack)
     ref_policy = AutoregressivePolicy(eng, ref_ad, t_len, pack_responses=pack)
-    opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode)
+    opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode,
+                    bucket_bounds=layer_buckets(pol_ad.layer_numel, d.n_layers, 4))
+
+    def bucket_hook(layer):          # the exchange of a bucket of layers starts when the backward has left its lowest layer
+        pos = layer * pol_ad.layer_numel
+        for bi, b in enumerate(opt.buckets):
+            if b.lo == pos:
+                opt.launch_bucket(bi)
     largs = DPOArgs()
     batches = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(args.accum)]
 
     def step():
-        for b in batches:
+        for mi, b in enumerate(batches):
             feats = eng.encode_images(b["images"])
             kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
                       chosen_response=b["chosen"], rejected_response=b["rejected"])
@@ -148,7 +239,9 @@ def main():
             o = policy(**kw)
             loss, _, _ = pair_loss(largs, o["chosen_response_logprobs"], o["rejected_response_logprobs"],
                                    r["chosen_response_logprobs"], r["rejected_response_logprobs"])
+            policy.layer_done_hook = bucket_hook if mi == len(batches) - 1 else None
             loss.backward()
+            policy.layer_done_hook = None
         opt.step(grad_accum_div=args.accum)
         opt.zero_grad()
         pol_ad.refresh_transposed()
@@ -184,9 +277,10 @@ def main():
             tot_f = sum(p[0] for p in prof)
             tot_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
             ach = tot_f / (tot_ms * 1e-3) / 1e12
+            traffic, traffic_src = _pmc_traffic()
             roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, long-lead LDS-DMA ring / 128x128 for skinny N; LoRA tail fused by K-concatenation)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                    "traffic": _pmc_traffic(), "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
         out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": value, "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -203,10 +297,9 @@ def main():
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
                           "loss": float(loss)},
                "executed_flops_per_pair_TF": fl / 1e12, "reference_layout_flops_per_pair_TF": fl_ref / 1e12,
-               # hardware utilisation: FLOPs this run executes; algorithmic: SURVEY.md §8(d) F_pair (4 full sequence forwards + dgrad +
-               # wgrad per pair — the shared prefix counted once per response like the reference computes it)
+               # hardware utilisation = FLOPs this run EXECUTES per second / peak.  The packed layout executes 0.66x the FLOPs of the
+               # reference's stacked layout per pair (reference_layout_flops_per_pair_TF); that saving is credited in pairs/s only.
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
-               "mfma_roofline_frac_algorithmic": value / world * fl_ref / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
                "roofline": roof}
         if args.model == "7b" and world == 1 and not args.no_cpu_baseline:
@@ -215,6 +308,23 @@ def main():
                                                         ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
+        if args.model == "7b" and world == 1 and not (args.no_rollout and args.no_exchange_probe):
+            # side records, measured AFTER the timed region on the same GPU; the training state is released first
+            numel, layer_numel = pol_ad.numel, pol_ad.layer_numel
+            del opt, policy, ref_policy, pol_ad, ref_ad, batches, loss
+            eng.release()
+            torch.cuda.empty_cache()
+            if not args.no_exchange_probe:
+                try:
+                    out["exchange_probe"] = exchange_probe(numel, dev, layer_numel, d.n_layers)
+                except Exception as e:
+                    out["exchange_probe"] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            if not args.no_rollout:
+                try:
+                    out["rollout"] = rollout_leg(eng, d, dev)
+                except Exception as e:
+                    out["rollout"] = {"error": repr(e)}
     else:
         out = None
     if dist.is_initialized():

@@ -139,6 +139,8 @@ int opadpo_transpose(const uint16_t* in, uint16_t* out, int R, int C, void* stre
  * max over jobs of ceil(rows/64)*ceil(cols/64).  Used for the K-major copies of all LoRA blocks after an optimizer step. */
 int opadpo_transpose_batched(const uint16_t* src, uint16_t* dst, const int64_t* jobs, int n_jobs, int max_tiles, void* stream);
 int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream);
+/* bf16 -> fp32 widening copy (exact); 16-byte aligned buffers.  Gradient slices received in bf16 from the ZeRO-1 reduce-scatter. */
+int opadpo_bf16_to_f32(const uint16_t* in, float* out, size_t n, void* stream);
 int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream);
 
 /* ---- head: compute_logprobs (utils/common_utils.py:112-118) + entropy (rl_models.py:128,132) -------

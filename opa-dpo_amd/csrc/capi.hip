@@ -179,6 +179,10 @@ int opadpo_transpose_batched(const uint16_t* src, uint16_t* dst, const int64_t* 
 int opadpo_f32_to_bf16(const float* in, uint16_t* out, size_t n, void* stream) {
   return done(launch_f32_to_bf16(in, out, n, S(stream)), "opadpo_f32_to_bf16");
 }
+int opadpo_bf16_to_f32(const uint16_t* in, float* out, size_t n, void* stream) {
+  if (n && ((uintptr_t)in % 16 || (uintptr_t)out % 16)) return bad("opadpo_bf16_to_f32", "buffers must be 16-byte aligned");
+  return done(launch_bf16_to_f32(in, out, n, S(stream)), "opadpo_bf16_to_f32");
+}
 int opadpo_f32_to_bf16_strided(const float* in, uint16_t* out, size_t rows, int C, int ld, void* stream) {
   if (ld % 4) return bad("opadpo_f32_to_bf16_strided", "misaligned leading dimension");
   return done(launch_f32_to_bf16_strided(in, out, rows, C, ld, S(stream)), "opadpo_f32_to_bf16_strided");

@@ -459,6 +459,23 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* in, bf16_
   }
 }
 
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* in, float* out, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * 256 * 8) {
+    if (i + 7 < n) {
+      const uint4 v = *(const uint4*)(in + i);
+      float4 a, b;
+      a.x = __uint_as_float(v.x << 16); a.y = __uint_as_float(v.x & 0xffff0000u);
+      a.z = __uint_as_float(v.y << 16); a.w = __uint_as_float(v.y & 0xffff0000u);
+      b.x = __uint_as_float(v.z << 16); b.y = __uint_as_float(v.z & 0xffff0000u);
+      b.z = __uint_as_float(v.w << 16); b.w = __uint_as_float(v.w & 0xffff0000u);
+      *(float4*)(out + i) = a;
+      *(float4*)(out + i + 4) = b;
+    } else {
+      for (size_t j = i; j < n; ++j) out[j] = __uint_as_float((uint32_t)in[j] << 16);
+    }
+  }
+}
+
 // fp32 [rows, C] contiguous -> bf16 columns [0, C) of a wider buffer with leading dimension ld
 __global__ __launch_bounds__(256) void f32_to_bf16_strided_kernel(const float* in, bf16_t* out, size_t rows, int C, int ld) {
   const int per_row = C / 4;
@@ -599,6 +616,11 @@ hipError_t launch_transpose_batched(const bf16_t* src, bf16_t* dst, const long l
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+hipError_t launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_grid((n + 7) / 8)), dim3(256), 0, st, in, out, n);
   return hipGetLastError();
 }
 hipError_t launch_f32_to_bf16_strided(const float* in, bf16_t* out, size_t rows, int C, int ld, hipStream_t st) {

@@ -88,6 +88,7 @@ hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_
 hipError_t launch_transpose(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t st);
 hipError_t launch_transpose_batched(const bf16_t* src, bf16_t* dst, const long long* jobs, int n_jobs, int max_tiles, hipStream_t st);
 hipError_t launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st);
+hipError_t launch_bf16_to_f32(const bf16_t* in, float* out, size_t n, hipStream_t st);
 hipError_t launch_f32_to_bf16_strided(const float* in, bf16_t* out, size_t rows, int C, int ld, hipStream_t st);
 
 hipError_t launch_head_fwd(const float* logits, int ldl, const int32_t* labels, float inv_temp, float* logp, float* ent,

@@ -115,6 +115,9 @@ def main(argv: Optional[List[str]] = None) -> None:
     if args.world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    # CoPO image masks draw from the global CPU generator (losses.mask_single_image: torch.randperm); the reference seeds every
+    # library from the configured seed before building anything (opadpo_train.py:564 set_reproducibility(seed))
+    torch.manual_seed(args.seed)
     from . import checkpoint_io as CK
     from .data import DataCollatorForCausalLM, DPODataset
     from .dims import LlavaDims
@@ -125,8 +128,10 @@ def main(argv: Optional[List[str]] = None) -> None:
     if args.synthetic:      # no network in the build environment: random-init model + synthetic rollouts
         from .synth import init_lora, init_weights
         d = {"tiny": LlavaDims.tiny, "7b": LlavaDims.llava15_7b, "13b": LlavaDims.llava15_13b}[args.synthetic]()
-        state, adapter_sd = init_weights(d, seed=args.seed, device=dev), init_lora(d, seed=args.seed + 1, device=dev)
-        ref_sd, vision_lora = adapter_sd, None
+        # the OPA-stage adapter carries CLIP-tower + projector LoRA too (frozen here, merged into the vision weights at load)
+        state, adapter_sd = init_weights(d, seed=args.seed, device=dev), init_lora(d, seed=args.seed + 1, device=dev, with_vision=True)
+        ref_sd, src_cfg = adapter_sd, None
+        vision_lora = {k: v for k, v in ref_sd.items() if "vision_tower" in k or "mm_projector" in k}
         last, done = get_last_checkpoint(args.output_dir) if args.resume_from_training else (None, False)
         if done:
             print("training already completed")
@@ -146,6 +151,9 @@ def main(argv: Optional[List[str]] = None) -> None:
         adapter_sd = CK.load_adapter(os.path.join(last, "adapter_model", "lora_policy") if last else ckpt)
         ref_sd = CK.load_adapter(ckpt)
         vision_lora = {k: v for k, v in ref_sd.items() if "vision_tower" in k or "mm_projector" in k}
+        import json
+        cfg_path = os.path.join(ckpt, "adapter_config.json")
+        src_cfg = json.load(open(cfg_path)) if os.path.exists(cfg_path) else None
     base = BaseWeights(d, state, dev, need_backward=True, vision_lora=vision_lora)
     engine = LlavaEngine(base)
     policy = AutoregressivePolicy(engine, LoraAdapter(d, adapter_sd, dev, True), args.response_len, args.temperature, "lora_policy")
@@ -153,7 +161,8 @@ def main(argv: Optional[List[str]] = None) -> None:
     if args.merge_ref_adapter:      # frozen reference adapter folded into its own bf16 weight copy (model.LoraAdapter.merge_into_base)
         ref_adapter.merge_into_base(base)
     ref_policy = AutoregressivePolicy(engine, ref_adapter, args.response_len, args.temperature, "lora_ref_policy")
-    trainer = DPOTrainer(args, policy, ref_policy, optimizer_mode=args.optimizer_mode)
+    trainer = DPOTrainer(args, policy, ref_policy, optimizer_mode=args.optimizer_mode, frozen_adapter_state=vision_lora,
+                         source_adapter_config=src_cfg)
     if args.synthetic:
         from .synth import synth_rollout_batches
         n = args.rollout_batch_size * 2

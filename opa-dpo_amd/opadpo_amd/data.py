@@ -120,9 +120,12 @@ class DataCollatorForCausalLM:
         if not self.detailed_report:
             plain_pair(False)
         else:
+            # the reports are parsed BEFORE the try (data_utils_dpo.py:116): a malformed AI_json_report raises instead of silently
+            # zero-weighting the whole batch; only failures of the alignment logic fall back (data_utils_dpo.py:259-278)
+            reports = [json.loads(r) for r in get("AI_json_report")]
             try:
-                batch.update(self._from_reports([json.loads(r) for r in get("AI_json_report")], originals))
-            except Exception as e:   # the reference prints and falls back (data_utils_dpo.py:259-278)
+                batch.update(self._from_reports(reports, originals))
+            except Exception as e:
                 print(e)
                 plain_pair(True)
         images = get("images")
@@ -215,7 +218,10 @@ def preprocess_image(pil_img, size: int = 336, pad_to_square: bool = True) -> to
         img = bg
     w, h = img.size
     scale = size / min(w, h)
-    img = img.resize((max(size, round(w * scale)), max(size, round(h * scale))), Image.BICUBIC)
+    # CLIPImageProcessor.get_resize_output_image_size: short edge = size, long edge = int(size * long / short) (truncation)
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_long = int(size * long_ / short)
+    img = img.resize((size, new_long) if w <= h else (new_long, size), Image.BICUBIC)
     w, h = img.size
     left, top = (w - size) // 2, (h - size) // 2
     img = img.crop((left, top, left + size, top + size))

@@ -47,6 +47,7 @@ SIGNATURES = {
     "opadpo_transpose": [_p, _p, _i, _i, _p],
     "opadpo_transpose_batched": [_p, _p, _p, _i, _i, _p],
     "opadpo_f32_to_bf16": [_p, _p, _sz, _p],
+    "opadpo_bf16_to_f32": [_p, _p, _sz, _p],
     "opadpo_f32_to_bf16_strided": [_p, _p, _sz, _i, _i, _p],
     "opadpo_head_fwd": [_p, _i, _p, _f, _p, _p, _p, _i, _i, _p],
     "opadpo_head_bwd": [_p, _i, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _p],

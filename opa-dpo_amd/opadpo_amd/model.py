@@ -513,9 +513,10 @@ class LlavaEngine:
         return logp.view(K * S, T), ent.view(K * S, T), sv
 
     def seq_logprobs_bwd(self, adapter: LoraAdapter, sv: Saved, dlogp: torch.Tensor, d_feats: Optional[torch.Tensor] = None,
-                         d_ent: Optional[torch.Tensor] = None) -> None:
+                         d_ent: Optional[torch.Tensor] = None, layer_done=None) -> None:
         """Accumulate d(loss)/d(LoRA A,B) into adapter.grad given dlogp [S,T] fp32.  d_feats (optional, fp32 [n_images, P, H],
-        accumulated): gradient w.r.t. the projected image features — only the OPA LoRA-SFT stage needs it (trainable vision /
+        accumulated; layer_done(i): called once layer i's LoRA gradients are queued - the data-parallel exchange of a finished
+        bucket of layers starts there): gradient w.r.t. the projected image features — only the OPA LoRA-SFT stage needs it (trainable vision /
         projector LoRA, vision_train.py); the DPO stage stops at the frozen layer-0 input.  d_ent (optional, [S,T]): gradient
         w.r.t. the per-token entropies (SFT entropy regulariser)."""
         assert sv.train and adapter.trainable and self.base.need_backward
@@ -594,6 +595,8 @@ class LlavaEngine:
                 L.gemm_nt(dqkv, w["wqkv_t"], d_n, a2=dt_3r, b2=adapter.wt(i, "a_qkv"))
                 L.call("opadpo_rmsnorm_bwd", L.ptr(d_n), L.ptr(sv.x[i]), 1, L.ptr(w["ln1"]), L.ptr(sv.rstd1[i]), L.ptr(d_h), 1,
                        L.ptr(dX), L.ptr(dXb), M, H, st)
+            if layer_done is not None:           # every wgrad of layer i is queued: its slice of the flat gradient is final
+                layer_done(i)
         if d_feats is not None:
             # splice backward: rows [img_pos, img_pos + P) of every sequence hold its image's features (dims.IMAGE_TOKEN_INDEX
             # sits at img_pos of the text ids); sequences sharing an image (stacked layout) accumulate.  Index plumbing in torch.

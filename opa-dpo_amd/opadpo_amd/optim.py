@@ -1,21 +1,35 @@
 """Clip + AdamW over the flat LoRA buffer, data-parallel gradient exchange, cosine schedule.
 
 Replaces accelerate.clip_grad_norm_ + bitsandbytes paged AdamW + DDP of the reference
-(opadpo/dpo_models/rl_trainer.py:164-175, utils/trainer_utils.py:9-49).  The reference never
+(opadpo/dpo_models/rl_trainer.py:155-175, utils/trainer_utils.py:9-49).  The reference never
 syncs gradients (every backward runs under no_sync — SURVEY.md Quirk Q1); this build does what
-north_star mandates: ONE collective exchange of the flat LoRA gradient per optimizer step.
+north_star mandates: ONE exchange of the flat LoRA gradient per optimizer step, in BUCKETS of
+whole decoder layers that are launched while the backward of the earlier layers is still running
+(DDP's bucketed overlap, dpo_trainer.py:1036 / opadpo_train.py:604-609, re-done for a flat
+layer-major buffer: backward walks the layers last -> first, so the buckets become final in
+reverse order).
 
-Two exchange modes (both over RCCL on GPUs, gloo in CPU tests):
-  * "allreduce": all-reduce(SUM) of the flat fp32 gradient, every rank updates everything;
-  * "zero1"    : reduce-scatter -> each rank clips + AdamW-updates its 1/N shard (fp32 master, m, v
-                 live only for that shard) -> all-gather of the bf16 working copy.
-The per-shard update function is injected so that the partitioning / collective logic is testable
+Two exchange modes (RCCL on GPUs, gloo in the CPU tests):
+  * "allreduce": per-bucket all-reduce(SUM) of the fp32 gradient in place, every rank updates everything;
+  * "zero1"    : per-bucket reduce-scatter (bf16 on the wire by default: 2 B per LoRA gradient element, what
+                 a bf16 DDP model exchanges; `exchange_dtype=torch.float32` keeps fp32) -> each rank clips +
+                 AdamW-updates its 1/N slice of EVERY bucket (fp32 master, m, v live only for those slices)
+                 -> per-bucket all-gather of the bf16 working copy, straight into the adapter's buffer.
+Collectives are issued with async_op=True: the backend's communication stream picks up where the
+compute stream stands at the call and runs next to the remaining backward; `prepare()` waits for them.
+
+Checkpoints are world-size independent: `state_dict()` assembles the FULL fp32 master / m / v on
+every rank (rank 0 writes them), `load_state_dict()` slices this rank's share of whatever layout the
+current world size gives (dpo_trainer.py:885-896, 1098-1137 save and reload the whole optimizer).
+
+The per-shard update functions are injected so that the partitioning / collective logic is testable
 on CPU (tests/test_dist_cpu.py) while the product passes the HIP kernels.
 """
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -48,58 +62,164 @@ def hip_adamw(p, g, m, v, p_bf16, *, lr, beta1, beta2, eps, weight_decay, step, 
            weight_decay, step, L.ptr(sumsq), max_norm if max_norm is not None else 0.0, grad_div, L.stream())
 
 
+def hip_cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """fp32 -> bf16 / bf16 -> fp32 copy of a flat range through the C ABI (device tensors)."""
+    from . import lib as L
+    if src.dtype == torch.float32 and dst.dtype == torch.bfloat16:
+        L.call("opadpo_f32_to_bf16", L.ptr(src), L.ptr(dst), src.numel(), L.stream())
+    elif src.dtype == torch.bfloat16 and dst.dtype == torch.float32:
+        L.call("opadpo_bf16_to_f32", L.ptr(src), L.ptr(dst), src.numel(), L.stream())
+    else:
+        raise TypeError((src.dtype, dst.dtype))
+
+
+def torch_cast(src: torch.Tensor, dst: torch.Tensor) -> None:
+    dst.copy_(src)
+
+
+class _Bucket:
+    __slots__ = ("lo", "hi", "per", "s_off", "s_len", "handle", "stage", "direct_gather")
+
+    def __init__(self, lo: int, hi: int, world: int, rank: int, s_off: int, align: int):
+        self.lo, self.hi = lo, hi
+        n = hi - lo
+        self.per = (n + world * align - 1) // (world * align) * align if world > 1 else n      # slice length of every rank
+        r_lo = min(n, rank * self.per)
+        self.s_len = min(n, r_lo + self.per) - r_lo                                            # this rank's real elements
+        self.s_off = s_off                                                                     # offset inside the shard state
+        self.handle = None
+        self.stage = None
+        self.direct_gather = world > 1 and self.per * world == n                              # all-gather straight into `work`
+
+
 class FlatAdamW:
     """AdamW(beta=(0.9,0.999), eps=1e-8, wd=0) + global-norm clip on flat fp32 master / grad buffers."""
 
     def __init__(self, master: torch.Tensor, grad: torch.Tensor, work_bf16: torch.Tensor, *, lr: float,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, max_grad_norm: Optional[float] = 1.0,
-                 mode: str = "allreduce", group=None, sumsq_fn: Callable = hip_sumsq, adamw_fn: Callable = hip_adamw):
+                 mode: str = "allreduce", group=None, sumsq_fn: Callable = hip_sumsq, adamw_fn: Callable = hip_adamw,
+                 cast_fn: Callable = hip_cast, bucket_bounds: Optional[Sequence[int]] = None,
+                 exchange_dtype: Optional[torch.dtype] = None, align: int = 256):
+        """bucket_bounds: ascending cut points [0, ..., numel] of the flat buffer (whole decoder layers, see
+        `layer_buckets`); None = one bucket.  exchange_dtype: dtype on the wire of the zero1 reduce-scatter (default bf16)."""
         assert mode in ("allreduce", "zero1")
         self.master, self.grad, self.work = master, grad, work_bf16
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.mode = mode
         self.group = group
-        self.sumsq_fn, self.adamw_fn = sumsq_fn, adamw_fn
+        self.sumsq_fn, self.adamw_fn, self.cast_fn = sumsq_fn, adamw_fn, cast_fn
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        # OPADPO_FORCE_COLLECTIVES=1 (diagnostics): run the exchange code path even in a 1-rank group
+        # OPADPO_FORCE_COLLECTIVES=1 (diagnostics / 1-GPU timing of the exchange): run the collective code path in a 1-rank group
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
-                                                and __import__("os").environ.get("OPADPO_FORCE_COLLECTIVES") == "1")
+                                                and os.environ.get("OPADPO_FORCE_COLLECTIVES") == "1")
         n = master.numel()
-        if mode == "zero1" and self._collective:
-            self.lo, self.hi, self.per = shard_bounds(n, self.world, self.rank)
-        else:
-            self.lo, self.hi, self.per = 0, n, n
-        sh = self.hi - self.lo
-        self.m = torch.zeros(sh, dtype=torch.float32, device=master.device)
-        self.v = torch.zeros(sh, dtype=torch.float32, device=master.device)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=master.device)
+        self.numel = n
+        self.sharded = mode == "zero1" and self._collective
+        self.exchange_dtype = exchange_dtype or (torch.bfloat16 if self.sharded else torch.float32)
+        bounds = list(bucket_bounds) if bucket_bounds is not None else [0, n]
+        assert bounds[0] == 0 and bounds[-1] == n and all(a < b for a, b in zip(bounds, bounds[1:])), bounds
+        if not self._collective:
+            bounds = [0, n]
+        self.buckets: List[_Bucket] = []
+        off = 0
+        for lo, hi in zip(bounds, bounds[1:]):
+            b = _Bucket(lo, hi, self.world if self.sharded else 1, self.rank if self.sharded else 0, off, align)
+            off += b.s_len
+            self.buckets.append(b)
+        sh = off if self.sharded else n
+        self.shard_numel = sh
+        dev = master.device
+        self.m = torch.zeros(sh, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(sh, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
-        self.last_grad_norm = None     # lazily materialised POST-clip norm (Quirk Q15)
-        if mode == "zero1" and self._collective:
-            pad_n = self.per * self.world
-            self._gpad = torch.zeros(pad_n, dtype=torch.float32, device=master.device)
-            self._gshard = torch.zeros(self.per, dtype=torch.float32, device=master.device)
-            self._wpad = torch.zeros(pad_n, dtype=work_bf16.dtype, device=master.device)
+        self.exchange_ms = None           # filled by bench.py (OPADPO_FORCE_COLLECTIVES) from events around prepare()
+        if self.sharded:
+            # ZeRO-1: the fp32 master exists only for this rank's slices (the adapter's full-size `master` buffer is released by the
+            # caller via `release_full_master()`); gradient slices arrive in `exchange_dtype`
+            self.p_shard = torch.empty(sh, dtype=torch.float32, device=dev)
+            self.g_shard = torch.zeros(sh, dtype=self.exchange_dtype, device=dev)
+            self.g_shard32 = self.g_shard if self.exchange_dtype == torch.float32 else torch.zeros(sh, dtype=torch.float32, device=dev)
+            self.w_shard = torch.empty(sh, dtype=work_bf16.dtype, device=dev)
+            for b in self.buckets:
+                r_lo = b.lo + min(b.hi - b.lo, self.rank * b.per)
+                self.p_shard[b.s_off:b.s_off + b.s_len].copy_(master[r_lo:r_lo + b.s_len])
+                b.stage = torch.zeros(b.per * self.world, dtype=self.exchange_dtype, device=dev)
+        self._launched = [False] * len(self.buckets)
+        # legacy attribute names (single-bucket view of this rank's share)
+        self.lo = self.buckets[0].lo + (min(self.buckets[0].hi, self.rank * self.buckets[0].per) if self.sharded else 0)
+        self.hi = self.lo + (self.buckets[0].s_len if self.sharded else n)
+        self.per = self.buckets[0].per
+
+    # ---- layout helpers -----------------------------------------------------------------------------
+    def shard_ranges(self) -> List[Tuple[int, int, int]]:
+        """[(flat_lo, flat_hi, shard_offset)] of the elements this rank updates."""
+        if not self.sharded:
+            return [(0, self.numel, 0)]
+        out = []
+        for b in self.buckets:
+            r_lo = b.lo + min(b.hi - b.lo, self.rank * b.per)
+            out.append((r_lo, r_lo + b.s_len, b.s_off))
+        return out
+
+    def bucket_of_layer(self, layer_numel: int, layer: int) -> int:
+        """Index of the bucket holding decoder layer `layer` of a layer-major flat buffer."""
+        pos = layer * layer_numel
+        for i, b in enumerate(self.buckets):
+            if b.lo <= pos < b.hi:
+                return i
+        raise IndexError(layer)
 
     # ---- gradient exchange --------------------------------------------------------------------------
-    def _exchange(self) -> torch.Tensor:
-        """Returns the (summed over ranks) gradient slice this rank updates."""
+    def launch_bucket(self, i: int) -> None:
+        """Start the exchange of bucket i (its gradient is final on this rank).  Asynchronous: returns at once; the
+        collective runs on the backend's stream behind everything already queued on the current stream."""
+        if not self._collective or self._launched[i]:
+            return
+        b = self.buckets[i]
+        self._launched[i] = True
+        g = self.grad[b.lo:b.hi]
+        if self.mode == "allreduce":
+            b.handle = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        n = b.hi - b.lo
+        self.cast_fn(g, b.stage[:n]) if self.exchange_dtype != torch.float32 else b.stage[:n].copy_(g)
+        out = self.g_shard[b.s_off:b.s_off + b.per] if b.s_len == b.per else None
+        if dist.get_backend(self.group) == "gloo":      # gloo has no reduce_scatter (CPU tests): all-reduce the staging buffer
+            b.handle = dist.all_reduce(b.stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            if out is None:                              # last rank's slice is shorter than `per`: receive into scratch
+                out = torch.empty(b.per, dtype=self.exchange_dtype, device=self.grad.device)
+                b.handle = (dist.reduce_scatter_tensor(out, b.stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), out)
+            else:
+                b.handle = dist.reduce_scatter_tensor(out, b.stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _finish_exchange(self) -> torch.Tensor:
+        """Launch what was not launched during backward, wait for everything; returns the summed gradient this rank updates."""
         if not self._collective:
             return self.grad
-        if self.mode == "allreduce":
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+        for i in range(len(self.buckets) - 1, -1, -1):
+            self.launch_bucket(i)
+        gloo = dist.get_backend(self.group) == "gloo"
+        for b in self.buckets:
+            h = b.handle
+            b.handle = None
+            if isinstance(h, tuple):
+                h[0].wait()
+                self.g_shard[b.s_off:b.s_off + b.s_len].copy_(h[1][:b.s_len])
+            elif h is not None:
+                h.wait()
+            if self.sharded and gloo:
+                r0 = self.rank * b.per
+                self.g_shard[b.s_off:b.s_off + b.s_len].copy_(b.stage[r0:r0 + b.s_len])
+        self._launched = [False] * len(self.buckets)
+        if not self.sharded:
             return self.grad
-        n = self.grad.numel()
-        self._gpad[:n].copy_(self.grad)
-        backend = dist.get_backend(self.group)
-        if backend == "gloo":   # gloo has no reduce_scatter: all-reduce then slice (CPU tests only)
-            dist.all_reduce(self._gpad, op=dist.ReduceOp.SUM, group=self.group)
-            self._gshard.copy_(self._gpad[self.rank * self.per:(self.rank + 1) * self.per])
-        else:
-            dist.reduce_scatter_tensor(self._gshard, self._gpad, op=dist.ReduceOp.SUM, group=self.group)
-        return self._gshard[: self.hi - self.lo]
+        if self.g_shard32 is not self.g_shard:
+            self.cast_fn(self.g_shard, self.g_shard32)
+        return self.g_shard32
 
     def step(self, grad_accum_div: float = 1.0) -> None:
         """One optimizer step.  Effective gradient = sum over ranks / (world * grad_accum_div)."""
@@ -107,16 +227,16 @@ class FlatAdamW:
         self.apply()
 
     def prepare(self, grad_accum_div: float = 1.0) -> None:
-        """Phase 1: gradient exchange + sum of squares of the (summed) gradient.  Several FlatAdamW instances that must be
-        clipped by ONE global norm (SFT stage: LLM LoRA + vision LoRA buffers) call prepare() on each, add their `sumsq`
+        """Phase 1: finish the gradient exchange + sum of squares of the (summed) gradient.  Several FlatAdamW instances that
+        must be clipped by ONE global norm (SFT stage: LLM LoRA + vision LoRA buffers) call prepare() on each, add their `sumsq`
         tensors, write the total back into each (`share_sumsq`) and then call apply()."""
         self.step_count += 1
-        self._g = self._exchange()
+        self._g = self._finish_exchange()
         self._grad_div = 1.0 / (self.world * grad_accum_div)
         self.sumsq.zero_()
         if self.max_grad_norm is not None:
             self.sumsq_fn(self._g, self.sumsq)
-            if self._collective and self.mode == "zero1":
+            if self.sharded:
                 dist.all_reduce(self.sumsq, op=dist.ReduceOp.SUM, group=self.group)
 
     @staticmethod
@@ -126,25 +246,34 @@ class FlatAdamW:
             o.sumsq.copy_(total)
 
     def apply(self) -> None:
-        """Phase 2: clip by the norm in `sumsq`, AdamW on this rank's slice, (ZeRO-1) all-gather of the working copy."""
-        g, grad_div = self._g, self._grad_div
-        p = self.master[self.lo:self.hi]
-        wk = self.work[self.lo:self.hi]
-        self.adamw_fn(p, g, self.m, self.v, wk, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                      weight_decay=self.wd, step=self.step_count,
-                      sumsq=self.sumsq if self.max_grad_norm is not None else None,
-                      max_norm=self.max_grad_norm, grad_div=grad_div)
-        if self._collective and self.mode == "zero1":
-            n = self.work.numel()
-            self._wpad[self.lo:self.hi].copy_(wk)
-            shard = self._wpad[self.rank * self.per:(self.rank + 1) * self.per]
-            if dist.get_backend(self.group) == "gloo":
-                parts = [torch.empty_like(shard) for _ in range(self.world)]
-                dist.all_gather(parts, shard.clone(), group=self.group)
-                self._wpad.copy_(torch.cat(parts))
+        """Phase 2: clip by the norm in `sumsq`, AdamW on this rank's slices, (ZeRO-1) all-gather of the working copy."""
+        kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.step_count,
+                  sumsq=self.sumsq if self.max_grad_norm is not None else None, max_norm=self.max_grad_norm, grad_div=self._grad_div)
+        if not self.sharded:
+            self.adamw_fn(self.master, self._g, self.m, self.v, self.work, **kw)
+            return
+        self.adamw_fn(self.p_shard, self._g, self.m, self.v, self.w_shard, **kw)
+        gloo = dist.get_backend(self.group) == "gloo"
+        handles = []
+        for b in self.buckets:
+            n = b.hi - b.lo
+            mine = self.w_shard[b.s_off:b.s_off + b.s_len]
+            if b.s_len < b.per:                                   # padded slice of the last rank
+                pad = torch.zeros(b.per, dtype=mine.dtype, device=mine.device)
+                pad[:b.s_len].copy_(mine)
+                mine = pad
+            if gloo:
+                parts = [torch.empty(b.per, dtype=mine.dtype) for _ in range(self.world)]
+                dist.all_gather(parts, mine.contiguous(), group=self.group)
+                self.work[b.lo:b.hi].copy_(torch.cat(parts)[:n])
+            elif b.direct_gather:
+                handles.append(dist.all_gather_into_tensor(self.work[b.lo:b.hi], mine, group=self.group, async_op=True))
             else:
-                dist.all_gather_into_tensor(self._wpad, shard.clone(), group=self.group)
-            self.work.copy_(self._wpad[:n])
+                out = torch.empty(b.per * self.world, dtype=mine.dtype, device=mine.device)
+                dist.all_gather_into_tensor(out, mine, group=self.group)
+                self.work[b.lo:b.hi].copy_(out[:n])
+        for h in handles:
+            h.wait()
 
     def zero_grad(self) -> None:
         self.grad.zero_()
@@ -156,11 +285,48 @@ class FlatAdamW:
         norm = math.sqrt(float(self.sumsq.item())) * self._grad_div
         return norm * min(1.0, self.max_grad_norm / (norm + 1e-6))
 
-    def state_dict(self):
-        return {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.step_count, "lo": self.lo, "hi": self.hi}
+    # ---- checkpoint state (world-size independent) ---------------------------------------------------
+    def _full(self, shard: torch.Tensor) -> torch.Tensor:
+        """Assemble the full flat fp32 tensor from every rank's slices (collective; every rank returns the full copy)."""
+        if not self.sharded:
+            return shard.detach().clone()
+        full = torch.zeros(self.numel, dtype=torch.float32, device=shard.device)
+        for lo, hi, off in self.shard_ranges():
+            full[lo:hi].copy_(shard[off:off + hi - lo])
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)          # slices are disjoint: the sum is the concatenation
+        return full
 
-    def load_state_dict(self, sd):
-        assert sd["lo"] == self.lo and sd["hi"] == self.hi, "optimizer shard layout changed (world size differs)"
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+    def state_dict(self):
+        """COLLECTIVE under zero1 (call on every rank): full m, v and fp32 master, independent of the sharding."""
+        p = self._full(self.p_shard) if self.sharded else self.master
+        return {"m": self._full(self.m).cpu(), "v": self._full(self.v).cpu(), "master": p.detach().cpu().clone(),
+                "step": self.step_count, "numel": self.numel, "format": 2}
+
+    def load_state_dict(self, sd) -> None:
+        """Takes the full tensors of `state_dict()` and keeps this rank's share of the CURRENT layout (the world size may have
+        changed since the save).  Restores the fp32 master too (a resume does not restart from bf16-rounded weights)."""
+        if sd.get("format") != 2:
+            raise ValueError("optimizer.pt was written by an older build (rank-0 shard only); it cannot be resumed - delete it to "
+                             "restart the optimizer state from the adapter weights")
+        assert int(sd["numel"]) == self.numel, "optimizer state belongs to a different adapter size"
         self.step_count = int(sd["step"])
+        dev = self.m.device
+        if not self.sharded:
+            self.m.copy_(sd["m"].to(dev))
+            self.v.copy_(sd["v"].to(dev))
+            self.master.copy_(sd["master"].to(dev))
+            self.work.copy_(self.master.to(self.work.dtype))
+            return
+        for lo, hi, off in self.shard_ranges():
+            self.m[off:off + hi - lo].copy_(sd["m"][lo:hi].to(dev))
+            self.v[off:off + hi - lo].copy_(sd["v"][lo:hi].to(dev))
+            self.p_shard[off:off + hi - lo].copy_(sd["master"][lo:hi].to(dev))
+        self.work.copy_(sd["master"].to(dev).to(self.work.dtype))
+
+
+def layer_buckets(layer_numel: int, n_layers: int, layers_per_bucket: int = 4) -> List[int]:
+    """Cut points of a layer-major flat LoRA buffer into buckets of whole decoder layers (7B, r = 256: 4 layers = 80 M
+    elements = 160 MB of bf16 on the wire - large enough for the per-link-bound xGMI ring, small enough that the exchange of
+    the first bucket starts after an eighth of the backward)."""
+    cuts = list(range(0, n_layers, max(1, layers_per_bucket))) + [n_layers]
+    return [c * layer_numel for c in cuts]

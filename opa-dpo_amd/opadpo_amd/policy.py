@@ -31,12 +31,18 @@ class _SeqLogprobs(torch.autograd.Function):
     def forward(ctx, anchor, policy, batch, feats, temperature):
         logp, ent, saved = policy.engine.seq_logprobs_fwd(policy.adapter, batch, feats, temperature, train=True)
         ctx.policy, ctx.saved = policy, saved
+        policy._pending_bwd += 1
         ctx.mark_non_differentiable(ent)
         return logp, ent
 
     @staticmethod
     def backward(ctx, dlogp, _dent):
-        ctx.policy.engine.seq_logprobs_bwd(ctx.policy.adapter, ctx.saved, dlogp)
+        pol = ctx.policy
+        pol._pending_bwd -= 1
+        # the per-layer "gradient is final" hook only fires in the LAST pending backward pass of the micro-batch (CoPO runs two
+        # policy forwards, clean + masked image: a layer's gradient is complete after both passes have left it)
+        hook = pol.layer_done_hook if pol._pending_bwd == 0 else None
+        pol.engine.seq_logprobs_bwd(pol.adapter, ctx.saved, dlogp, layer_done=hook)
         ctx.saved = None
         return None, None, None, None, None
 
@@ -57,6 +63,8 @@ class AutoregressivePolicy(torch.nn.Module):
         self.temperature = temperature
         # autograd anchor: a leaf that requires grad so that the HIP forward gets a grad_fn
         self._anchor = torch.zeros(1, device=engine.dev, requires_grad=True) if adapter.trainable else None
+        self._pending_bwd = 0             # training forwards whose backward has not run yet
+        self.layer_done_hook = None       # callable(layer) set by the trainer on the gradient-sync micro-batch (optim.launch_bucket)
 
     def build_batch(self, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
         dev = self.engine.dev

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from .dims import PAD_ID
 from .losses import DPOArgs, mask_percentage_per_row, mask_single_image, policy_loss
-from .optim import FlatAdamW, cosine_lr
+from .optim import FlatAdamW, cosine_lr, layer_buckets
 from .policy import AutoregressivePolicy, response_keys
 
 ADAPTER_MODEL_DIR = "adapter_model"
@@ -51,13 +51,32 @@ def get_last_checkpoint(checkpoint_dir: str):
     return None, False
 
 
-def save_adapter(adapter, directory: str, dims, base_model_name_or_path: str = "") -> None:
-    """PEFT-0.5 layout (dpo_trainer.py:1047-1095): adapter_model.bin (torch pickle, keys without
-    the adapter name) + adapter_config.json with inference_mode forced True."""
+def save_adapter(adapter, directory: str, dims, base_model_name_or_path: str = "", extra_state: Optional[Dict[str, torch.Tensor]] = None,
+                 source_config: Optional[dict] = None) -> None:
+    """PEFT-0.5 layout (dpo_trainer.py:1047-1095): adapter_model.bin (torch pickle, keys without the adapter name) +
+    adapter_config.json with inference_mode forced True.
+
+    `extra_state`: the FROZEN tensors of the same PEFT adapter that this stage does not train - the CLIP-tower and mm_projector
+    LoRA of the OPA-stage adapter the policy starts from (qlora_model.py:133-143 attaches LoRA to them too;
+    dpo_trainer.py:1022-1030 freezes them).  The reference's `get_peft_model_state_dict(model, adapter_name='lora_policy')` keeps
+    them in every checkpoint, so evaluation / PEFT loading of checkpoint-N sees the vision LoRA the model was trained with; they
+    are written back unchanged.  `source_config`: adapter_config.json of that source adapter (its target_modules are kept)."""
     os.makedirs(directory, exist_ok=True)
-    torch.save(adapter.to_peft_state(), os.path.join(directory, WEIGHTS_NAME))
+    sd = adapter.to_peft_state()
+    for k, v in (extra_state or {}).items():
+        if k not in sd:
+            sd[k] = v.detach().to(torch.bfloat16).cpu().clone()
+    torch.save(sd, os.path.join(directory, WEIGHTS_NAME))
+    targets = list(LLM_TARGET_MODULES)
+    if source_config and source_config.get("target_modules"):
+        targets = list(source_config["target_modules"])
+    elif extra_state:
+        for k in extra_state:                     # derive the module names from the kept keys (e.g. out_proj, fc1, fc2, "0", "2")
+            mod = k.split(".lora_")[0].rsplit(".", 1)[-1]
+            if mod not in targets:
+                targets.append(mod)
     cfg = {"peft_type": "LORA", "task_type": "CAUSAL_LM", "r": dims.lora_r, "lora_alpha": dims.lora_alpha,
-           "lora_dropout": 0.0, "bias": "none", "target_modules": LLM_TARGET_MODULES,
+           "lora_dropout": 0.0, "bias": "none", "target_modules": targets,
            "base_model_name_or_path": base_model_name_or_path, "inference_mode": True, "fan_in_fan_out": False,
            "init_lora_weights": True, "modules_to_save": None, "layers_to_transform": None,
            "layers_pattern": None, "revision": None}
@@ -67,22 +86,29 @@ def save_adapter(adapter, directory: str, dims, base_model_name_or_path: str = "
 
 class DPOTrainer:
     def __init__(self, args, policy: AutoregressivePolicy, ref_policy: AutoregressivePolicy,
-                 train_dataset=None, data_collator: Optional[Callable] = None, *, optimizer_mode: str = "allreduce"):
+                 train_dataset=None, data_collator: Optional[Callable] = None, *, optimizer_mode: str = "allreduce",
+                 frozen_adapter_state: Optional[Dict[str, torch.Tensor]] = None, source_adapter_config: Optional[dict] = None,
+                 layers_per_bucket: int = 4, exchange_dtype: Optional[torch.dtype] = None, optimizer_kwargs: Optional[dict] = None):
         """`args` carries the reference's TrainingArguments fields that are used on this path:
         DPOArgs fields + rollout_accumulation_steps, gradient_accumulation_steps, step_per_device_batch_size,
         rollout_per_device_batch_size, rollout_batch_size, noptepochs, max_grad_norm, learning_rate, warmup_steps,
-        total_epochs, max_step, save_steps, save_steps_extra_list, output_dir, seed, weight_decay."""
+        total_epochs, max_step, save_steps, save_steps_extra_list, output_dir, seed, weight_decay.
+        frozen_adapter_state / source_adapter_config: vision-tower + projector LoRA tensors and adapter_config.json of the adapter
+        the policy starts from; written unchanged into every checkpoint (save_adapter)."""
         self.args = args
         self.policy, self.ref_policy = policy, ref_policy
         self.engine = policy.engine
         self.train_dataset, self.data_collator = train_dataset, data_collator
+        self.frozen_adapter_state, self.source_adapter_config = frozen_adapter_state, source_adapter_config
         self.loss_args = DPOArgs(**{k: getattr(args, k) for k in DPOArgs.__dataclass_fields__ if hasattr(args, k)})
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         ad = policy.adapter
         self.optimizer = FlatAdamW(ad.master, ad.grad, ad.work, lr=getattr(args, "learning_rate", 1e-6),
                                    weight_decay=getattr(args, "weight_decay", 0.0),
-                                   max_grad_norm=getattr(args, "max_grad_norm", 1.0), mode=optimizer_mode)
+                                   max_grad_norm=getattr(args, "max_grad_norm", 1.0), mode=optimizer_mode,
+                                   bucket_bounds=layer_buckets(ad.layer_numel, self.engine.d.n_layers, layers_per_bucket),
+                                   exchange_dtype=exchange_dtype, **(optimizer_kwargs or {}))
         self.sched_step = 0
         self.total_sched_steps = 1
         self.log_history: List[dict] = []
@@ -184,7 +210,12 @@ class DPOTrainer:
             for bi, idx in enumerate(micro, 1):
                 mb = {k: v[idx] for k, v in rollouts.items()}
                 loss, st = self.compute_policy_loss(mb)
+                # last micro-batch of the accumulation window: the gradient of a bucket of layers is final as soon as the LAST
+                # backward pass of this micro-batch has left its lowest layer -> its exchange starts there, next to the backward
+                # of the earlier layers (the reference's DDP buckets, rl_trainer.py:155-175)
+                self.policy.layer_done_hook = self._bucket_hook if bi % accum == 0 else None
                 loss.backward()
+                self.policy.layer_done_hook = None
                 if bi % accum == 0:
                     self.optimizer.step(grad_accum_div=accum)
                     st["loss/grad_norm"] = torch.tensor(self.optimizer.grad_norm_post_clip())
@@ -192,6 +223,13 @@ class DPOTrainer:
                     self.policy.adapter.refresh_transposed()
                     stats_list.append({k: v.detach().float().cpu() for k, v in st.items()})
         return {k: torch.stack([s[k] for s in stats_list]) for k in stats_list[0]} if stats_list else {}
+
+    def _bucket_hook(self, layer: int) -> None:
+        ad, opt = self.policy.adapter, self.optimizer
+        pos = layer * ad.layer_numel
+        for bi, b in enumerate(opt.buckets):
+            if b.lo == pos:                       # `layer` is the lowest layer of bucket bi: every layer above it is done too
+                opt.launch_bucket(bi)
 
     def step(self, train_iter, step_idx: int) -> dict:
         batches = [next(train_iter) for _ in range(self.args.rollout_accumulation_steps)]
@@ -243,12 +281,14 @@ class DPOTrainer:
 
     # ---- checkpoints (dpo_trainer.py:837-931) ----------------------------------------------------------------
     def save_model(self, output_dir: str) -> None:
+        """dpo_trainer.py:837-931: adapter (PEFT layout) + full optimizer state + scheduler.  Under ZeRO-1 the optimizer state is
+        assembled from every rank's slices (collective: ALL ranks call this), so optimizer.pt is independent of the world size."""
+        opt_sd = self.optimizer.state_dict()
         if self.is_main:
             os.makedirs(output_dir, exist_ok=True)
             save_adapter(self.policy.adapter, os.path.join(output_dir, ADAPTER_MODEL_DIR, "lora_policy"), self.engine.d,
-                         getattr(self.args, "base_model_name", ""))
-            torch.save({"optimizer": self.optimizer.state_dict(), "sched_step": self.sched_step},
-                       os.path.join(output_dir, OPTIMIZER_NAME))
+                         getattr(self.args, "base_model_name", ""), self.frozen_adapter_state, self.source_adapter_config)
+            torch.save({"optimizer": opt_sd, "sched_step": self.sched_step}, os.path.join(output_dir, OPTIMIZER_NAME))
             torch.save({"last_epoch": self.sched_step, "total": self.total_sched_steps},
                        os.path.join(output_dir, SCHEDULER_NAME))
             parent = os.path.dirname(output_dir.rstrip("/"))
@@ -260,11 +300,15 @@ class DPOTrainer:
             dist.barrier()
 
     def resume_training(self, checkpoint_dir: str) -> int:
+        """dpo_trainer.py:1098-1137: optimizer (m, v, step AND the fp32 master weights - a resume continues the trajectory instead
+        of restarting from bf16-rounded weights), scheduler position; every rank keeps its share of the current ZeRO-1 layout."""
         opt = os.path.join(checkpoint_dir, OPTIMIZER_NAME)
         if os.path.exists(opt):
             sd = torch.load(opt, map_location="cpu")
             self.optimizer.load_state_dict(sd["optimizer"])
             self.sched_step = int(sd["sched_step"])
             self._set_lr()
+            if self.policy.adapter.trainable:
+                self.policy.adapter.refresh_transposed()
         m = re.search(r"checkpoint-(\d+)", os.path.basename(checkpoint_dir.rstrip("/")))
         return int(m.group(1)) if m else 0

@@ -1,0 +1,245 @@
+"""GPU parity of the configuration bench.py actually times, against the CPU oracle (oracle/llava_ref.py):
+
+  * the frozen reference adapter MERGED into its own bf16 weight copy with the SwiGLU-pair epilogue
+    (LoraAdapter.merge_into_base / lib.ACT_SWIGLU_PAIR), the trainable policy adapter K-concatenated;
+  * problem sizes at which the default dispatch takes the large-shape kernels of the benchmark
+    (gemm_nt_w4_kernel<12>, gemm_tn_w4_kernel, the 128-row attention kernels): LLaVA-1.5-7B WIDTH
+    (H 4096, FFN 11008, V 32000, r 256), 4 decoder layers, 6 pairs x (query 128 + 2 x response 384), packed
+    rows = 5 466 -> 22 row tiles x 16..86 column tiles >= 320 blocks for every base projection;
+  * LLaVA-1.5-13B width (H 5120, 40 heads, FFN 13824), 2 layers, same shape rule;
+  * the on-policy rollout at batch 64 and 7B width (prefill L = 703, context up to ~750).
+
+Tolerance (BASELINE.md §4 / north_star): per-token log-probs within 1e-3 RELATIVE.  Asserted on the mean and on
+the 99th percentile against the oracle run with bf16 rounding at the HBM write points of the HIP pipeline
+(``emulate_bf16=True``: same arithmetic, same rounding points, different accumulation order); the maximum and the
+drift against the pure-fp32 oracle are reported (gpurun_out/parity_bench_config.json) and bounded more loosely -
+two bf16 pipelines that round at different points cannot agree to 1e-3 with an fp32 run of a 4-layer model.
+
+Reference call sites: opadpo/dpo_models/rl_models.py:114-132, utils/common_utils.py:112-118.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+REPORT = {}
+
+
+def _dump():
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_bench_config.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+def _inputs(d, B, Q, T, seed):
+    """Left-padded queries with one image token, two ragged right-padded responses (EOS then pad)."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g).to(BF).float()
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    for b in range(B):
+        n_pad = int(torch.randint(0, Q // 2, (1,), generator=g)) if b else 0
+        queries[b, :n_pad] = 0
+        qmask[b, :n_pad] = False
+        queries[b, int(torch.randint(n_pad, Q, (1,), generator=g))] = -200
+    resp = {}
+    for k in ("chosen_response", "rejected_response"):
+        ids = torch.randint(3, d.vocab, (B, T), generator=g)
+        for b in range(B):
+            ln = int(torch.randint(T // 6, T, (1,), generator=g))
+            if b == 1 and k == "chosen_response":
+                continue                       # one response without any padding
+            ids[b, ln] = 2
+            ids[b, ln + 1:] = 0
+        resp[k] = ids
+    return images, queries, qmask, resp
+
+
+def _relstats(got, want, valid):
+    r = ((got - want).abs()[valid] / want.abs()[valid].clamp_min(1e-3)).double()
+    return float(r.mean()), float(torch.quantile(r, 0.99)), float(r.max())
+
+
+def _grad_blocks(d, adapter, ol):
+    from opadpo_amd.model import _peft_map, lora_blocks
+    pm = _peft_map(d)
+    out = {}
+    for i in range(d.n_layers):
+        for name, rows, cols in lora_blocks(d):
+            got = adapter.g(i, name).cpu()
+            ref = torch.zeros(rows, cols)
+            for mod, ab, r0, nr in pm[name]:
+                ref[r0:r0 + nr] = ol[f"base_model.model.model.layers.{i}.{mod}.{ab}.weight"].grad
+            assert bool(torch.isfinite(got).all())
+            out[f"L{i}_{name}"] = float((got - ref).norm() / (ref.norm() + 1e-12))
+    return out
+
+
+def _model(kw, n_seed_w=0, std=0.02):
+    from opadpo_amd import lib
+    from opadpo_amd.dims import LlavaDims
+    from opadpo_amd.model import BaseWeights, LlavaEngine
+    from oracle import llava_ref as LR
+    lib.load()
+    d, od = LlavaDims(**kw), LR.LlavaDims(**kw)
+    W = {k: v.to(BF).float() for k, v in LR.init_weights(od, seed=n_seed_w, std=std).items()}
+    dev = torch.device("cuda:0")
+    eng = LlavaEngine(BaseWeights(d, W, dev, need_backward=True))
+    return d, od, W, eng, dev, LR
+
+
+def _check_config(tag, kw, B, Q, T, *, check_grads=True):
+    """Merged reference pass + trainable policy pass + LoRA gradients of one model geometry against the oracle."""
+    from opadpo_amd import lib
+    from opadpo_amd.model import LoraAdapter
+    from opadpo_amd.policy import AutoregressivePolicy
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    d, od, W, eng, dev, LR = _model(kw)
+    lora_pol = {k: v.to(BF).float() for k, v in LR.init_lora(od, seed=1, b_std=0.01, with_vision=False).items()}
+    lora_ref = {k: v.to(BF).float() for k, v in LR.init_lora(od, seed=2, b_std=0.01, with_vision=False).items()}
+    images, queries, qmask, resp = _inputs(d, B, Q, T, seed=11)
+    # the dispatch the benchmark takes: default flags, packed rows; every base projection must reach the 256x256 4-wave kernel
+    M = B * (Q + d.n_patches - 1 + 2 * T)
+    assert ((M + 255) // 256) * (d.hidden // 256) >= 320, "too few row tiles: the 256x256 kernel would not be dispatched"
+    lib.set_flags(True, True)
+    ref_ad = LoraAdapter(d, lora_ref, dev, trainable=False)
+    ref_ad.merge_into_base(eng.base)
+    assert ref_ad.merged is not None and "wgu_sw" in ref_ad.merged[0], "bench.py's reference pass uses the SwiGLU-pair epilogue"
+    pol_ad = LoraAdapter(d, lora_pol, dev, trainable=True)
+    kwargs = dict(images=images.to(dev), queries=queries, queries_attn_masks=qmask, **resp)
+    with torch.no_grad():
+        r_out = AutoregressivePolicy(eng, ref_ad, T, pack_responses=True)(**kwargs)
+    g = torch.Generator().manual_seed(3)
+    wts = {k: torch.randn(B, T, generator=g) for k in resp}
+    p_out = AutoregressivePolicy(eng, pol_ad, T, pack_responses=True)(**kwargs)
+    loss = sum((p_out[k + "_logprobs"] * wts[k].to(dev)).sum() for k in resp)
+    loss.backward()
+    torch.cuda.synchronize()
+    # ---- oracle -----------------------------------------------------------------------------------------------------
+    with torch.no_grad():
+        Wm, rest = LR.merge_llm_lora(W, lora_ref, od, emulate_bf16=True)
+        ref_emu_merged = LR.policy_forward(images, queries, qmask, resp, Wm, rest, od, 1.0, emulate_bf16=True)
+        ref_emu = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0, emulate_bf16=True)
+        ref_f32 = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0)
+        pol_emu = LR.policy_forward(images, queries, qmask, resp, W, lora_pol, od, 1.0, emulate_bf16=True)
+    ol = {k: v.clone().requires_grad_(True) for k, v in lora_pol.items()}
+    pol_f32 = LR.policy_forward(images, queries, qmask, resp, W, ol, od, 1.0)
+    if check_grads:
+        oloss = sum((pol_f32[k + "_logprobs"] * wts[k]).sum() for k in resp)
+        oloss.backward()
+    worst = {}
+    for k in resp:
+        valid = resp[k] != 0
+        for name, got_d, want_d in (("ref_merged_vs_emu_merged", r_out, ref_emu_merged), ("ref_merged_vs_emu_unmerged", r_out, ref_emu),
+                                    ("ref_merged_vs_fp32", r_out, ref_f32), ("policy_vs_emu", p_out, pol_emu), ("policy_vs_fp32", p_out, pol_f32)):
+            got, want = got_d[k + "_logprobs"].detach().cpu(), want_d[k + "_logprobs"].detach()
+            assert bool((got[~valid] == 0).all()) and bool((want[~valid] == 0).all())        # mask placement is exact (Quirk Q4)
+            mean, p99, mx = _relstats(got, want, valid)
+            REPORT[f"{tag}_{name}_{k}"] = {"mean": mean, "p99": p99, "max": mx}
+            w = worst.setdefault(name, [0.0, 0.0, 0.0])
+            worst[name] = [max(w[0], mean), max(w[1], p99), max(w[2], mx)]
+        ent = r_out[k + "_entropies"].cpu()
+        REPORT[f"{tag}_ref_entropy_maxabs_{k}"] = float((ent - ref_f32[k + "_entropies"]).abs().max())
+        assert float((ent - ref_f32[k + "_entropies"]).abs().max()) < 5e-2
+    REPORT[f"{tag}_worst"] = worst
+    if check_grads:
+        blocks = _grad_blocks(d, pol_ad, ol)
+        REPORT[f"{tag}_grad_blocks"] = blocks
+        REPORT[f"{tag}_loss_rel"] = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    _dump()
+    print(f"[{tag}] rows={M}", json.dumps(worst))
+    # north_star's tolerance on the benchmarked configuration: 1e-3 relative, mean AND 99th percentile, against the oracle that
+    # rounds where the HIP pipeline rounds (merged weights rounded once for the reference pass)
+    for name in ("ref_merged_vs_emu_merged", "policy_vs_emu"):
+        mean, p99, mx = worst[name]
+        assert mean < 1e-3 and p99 < 1e-3, f"{tag} {name}: mean {mean:.2e} p99 {p99:.2e} max {mx:.2e} (limit 1e-3)"
+        assert mx < 5e-3, f"{tag} {name}: max {mx:.2e}"
+    # reported drift: merged-vs-unmerged rounding of the reference adapter, and bf16 pipeline vs fp32 arithmetic
+    assert worst["ref_merged_vs_emu_unmerged"][0] < 1.5e-3, worst
+    assert worst["ref_merged_vs_fp32"][0] < 2.5e-3 and worst["policy_vs_fp32"][0] < 2.5e-3, worst
+    if check_grads:
+        bad = {k: round(v, 4) for k, v in blocks.items() if not v < 3e-2}
+        assert not bad, f"{tag}: LoRA gradient blocks beyond 3e-2 relative Frobenius error: {bad}"
+        assert REPORT[f"{tag}_loss_rel"] < 2e-3
+    eng.release()
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_bench_config_parity_7b_width_4_layers():
+    kw = dict(hidden=4096, n_layers=4, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
+              v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
+    _check_config("7b_w4", kw, B=6, Q=128, T=384)
+
+
+def test_bench_config_parity_13b_width_2_layers():
+    """configs[3] of BASELINE.json: LLaVA-1.5-13B dims (H 5120, 40 heads of 128, FFN 13824) - N = 5120 / 15360 / 27648 column
+    counts, K = 13824, the shapes no 7B test reaches."""
+    from opadpo_amd.dims import LlavaDims
+    full = LlavaDims.llava15_13b()
+    kw = dict(hidden=full.hidden, n_layers=2, n_heads=full.n_heads, head_dim=full.head_dim, ffn=full.ffn, vocab=full.vocab,
+              v_hidden=128, v_layers=2, v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
+    _check_config("13b_w2", kw, B=5, Q=128, T=384)
+
+
+def test_rollout_batch64_7b_width():
+    """configs[4] of BASELINE.json: KV-cache decode at batch 64, 7B width (2 layers), prefill L = 128 + 576 - 1 = 703, context
+    up to 751: (a) graph-replayed == eager decode token for token (sampled, top-k 30 / top-p 0.95, seeded), deterministic;
+    (b) greedy decode of the whole batch checked against the oracle re-running the full model on sampled rows
+    (online_generator.py:292-309)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd.generate import Generator
+    kw = dict(hidden=4096, n_layers=2, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
+              v_heads=2, v_ffn=256, image_size=336, patch=14, lora_r=256, lora_alpha=512.0)
+    d, od, W, eng, dev, LR = _model(kw, std=0.03)
+    B, Q, N = 64, 128, 48
+    assert d.n_patches == 576
+    g = torch.Generator().manual_seed(8)
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g).to(BF).float()
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    for b in range(B):
+        n_pad = int(torch.randint(0, Q // 2, (1,), generator=g)) if b % 3 else 0
+        queries[b, :n_pad] = 0
+        qmask[b, :n_pad] = False
+        queries[b, int(torch.randint(n_pad, Q, (1,), generator=g))] = -200
+    feats = eng.encode_images(images.to(dev))
+    outs = []
+    for use_graph in (True, False, True):
+        gen = Generator(eng, None, use_graph=use_graph, fuse_swiglu=True)
+        outs.append(gen.generate(queries, qmask, image_feats=feats, max_new_tokens=N, temperature=1.0, top_k=30, top_p=0.95, seed=4,
+                                 suppress_eos=True))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "graph replay != eager decode at batch 64"
+    assert outs[0].shape == (B, N) and int((outs[0] >= 3).sum()) == outs[0].numel()
+    # greedy, against the oracle on 3 rows x the first 6 steps (every oracle step re-runs the full 703+ position model)
+    n_chk = 6
+    greedy = Generator(eng, None, use_graph=True).generate(queries, qmask, image_feats=feats, max_new_tokens=N, top_k=1, top_p=1.0,
+                                                           seed=1, suppress_eos=True).cpu()
+    rows = [0, 31, 63]
+    ofe = LR.image_features(images[rows], W, None, od)
+    assert float((feats[rows].float().cpu() - ofe).norm() / ofe.norm()) < 3e-2
+    ids, mask = queries[rows].clone(), qmask[rows].clone()
+    close = 0
+    for step in range(n_chk):
+        logits = LR.llava_logits(ids, mask, None, W, None, od, feats=ofe)[:, -1]
+        logits[:, 2] = float("-inf")
+        top2 = logits.topk(2, dim=-1)
+        for j, b in enumerate(rows):
+            tok = int(greedy[b, step])
+            if tok != int(top2.indices[j, 0]):
+                gap = float(top2.values[j, 0] - top2.values[j, 1])
+                assert tok == int(top2.indices[j, 1]) and gap < 3e-2, (step, b, tok, top2.indices[j].tolist(), gap)
+                close += 1
+        nxt = greedy[rows, step]
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        mask = torch.cat([mask, torch.ones(len(rows), 1, dtype=torch.bool)], 1)
+    REPORT["rollout_b64_checked"] = {"rows": rows, "steps": n_chk, "near_ties_resolved_to_second": close, "ctx_max": Q + d.n_patches - 1 + N}
+    _dump()
+    eng.release()

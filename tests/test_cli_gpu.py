@@ -28,15 +28,41 @@ def test_train_entry_point_checkpoints_and_resume(tmp_path):
     assert cfg["r"] == 128 and cfg["inference_mode"] is True
     sd2 = torch.load(os.path.join(ck2, "adapter_model.bin"))
     sdf = torch.load(os.path.join(fin, "adapter_model.bin"))
-    assert set(sd2) == set(sdf) and len(sd2) == 2 * 7 * 2          # layers x linears x (A,B)
-    moved = sum(float((sdf[k].float() - sd2[k].float()).abs().sum()) for k in sd2)
+    # every checkpoint carries the LLM LoRA (layers x linears x (A,B)) AND the frozen CLIP-tower / projector LoRA of the adapter the
+    # policy started from, like get_peft_model_state_dict(adapter_name='lora_policy') (dpo_trainer.py:1047-1095)
+    llm = [k for k in sd2 if "vision_tower" not in k and "mm_projector" not in k]
+    vis = [k for k in sd2 if "vision_tower" in k]
+    assert set(sd2) == set(sdf) and len(llm) == 2 * 7 * 2 and len(vis) == 3 * 6 * 2 and sum("mm_projector" in k for k in sd2) == 4
+    assert {"fc1", "fc2", "out_proj", "q_proj", "down_proj"} <= set(cfg["target_modules"])
+    assert all(torch.equal(sd2[k], sdf[k]) for k in sd2 if k not in llm), "frozen vision / projector LoRA must be written back unchanged"
+    moved = sum(float((sdf[k].float() - sd2[k].float()).abs().sum()) for k in llm)
     assert moved > 0, "training after checkpoint-2 did not change the adapter"
     assert get_last_checkpoint(out) == (None, True)                 # 'completed' marker -> nothing to resume
     os.remove(os.path.join(out, "completed"))
     path, done = get_last_checkpoint(out)
     assert path.endswith("checkpoint-2") and not done
+    opt2 = torch.load(os.path.join(out, "checkpoint-2", "optimizer.pt"))["optimizer"]
+    assert opt2["format"] == 2 and opt2["master"].dtype == torch.float32 and opt2["master"].numel() == opt2["m"].numel() > 0
     cli.main(argv)                                                    # resumes from checkpoint-2
     assert os.path.exists(os.path.join(out, "completed"))
+    # resume continues the trajectory: fp32 master + Adam moments + step restored.  Deterministic variant (no CoPO image masks,
+    # which draw from the global RNG), lr large enough that an un-restored optimizer would show: resumed == uninterrupted.
+    out2 = str(tmp_path / "run2")
+    argv2 = [a for a in argv]
+    argv2[argv2.index("--output_dir") + 1] = out2
+    argv2[argv2.index("--learning_rate") + 1] = "1e-2"
+    argv2 += ["--CoPO", "False"]
+    cli.main(argv2)
+    fin2 = os.path.join(out2, "checkpoint-final", "adapter_model", "lora_policy", "adapter_model.bin")
+    sda = torch.load(fin2)
+    start = torch.load(os.path.join(out2, "checkpoint-2", "adapter_model", "lora_policy", "adapter_model.bin"))
+    os.remove(os.path.join(out2, "completed"))
+    os.remove(fin2)
+    cli.main(argv2)
+    sdb = torch.load(fin2)
+    worst = max(float((sda[k].float() - sdb[k].float()).abs().max()) for k in llm)
+    step = max(float((sda[k].float() - start[k].float()).abs().max()) for k in llm)
+    assert step > 5e-3 and worst < 1e-3, f"resumed run differs from the uninterrupted one by {worst} (last step moved {step})"
 
 
 def test_sft_entry_point(tmp_path):

@@ -41,7 +41,10 @@ def setup():
     eng = LlavaEngine(base)
     pol = LoraAdapter(d, lora_pol, dev, trainable=True)
     ref = LoraAdapter(d, lora_ref, dev, trainable=False)
-    yield dict(d=d, od=od, W=W, lora_pol=lora_pol, lora_ref=lora_ref, eng=eng, pol=pol, ref=ref, dev=dev, LR=LR)
+    ref_merged = LoraAdapter(d, lora_ref, dev, trainable=False)      # what bench.py runs: frozen adapter folded into its own bf16 copy,
+    ref_merged.merge_into_base(base)                                  # SwiGLU applied in the gate|up projection's epilogue
+    assert "wgu_sw" in ref_merged.merged[0]
+    yield dict(d=d, od=od, W=W, lora_pol=lora_pol, lora_ref=lora_ref, eng=eng, pol=pol, ref=ref, ref_merged=ref_merged, dev=dev, LR=LR)
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.json"), "w") as f:
@@ -95,17 +98,27 @@ def _policy(s, adapter, T, pack=True):
 PACK = pytest.mark.parametrize("pack", [True, False])
 
 
+MERGED = pytest.mark.parametrize("merged", [False, True])
+
+
+@MERGED
 @PACK
-def test_logprobs_forward(setup, pack):
+def test_logprobs_forward(setup, pack, merged):
+    """merged=True: the reference pass of bench.py / the trainer default (LoraAdapter.merge_into_base + SwiGLU-pair epilogue)
+    against the same oracle numbers; its bf16-emulating oracle rounds the merged weights once, like the HIP pipeline."""
     s = setup
     LR = s["LR"]
     B, Q, T = 2, 12, 9
     images, queries, qmask, resp = make_inputs(s["d"], B, Q, T)
-    pol = _policy(s, s["ref"], T, pack)
+    pol = _policy(s, s["ref_merged"] if merged else s["ref"], T, pack)
     out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, temperature=0.9, **resp)
     torch.cuda.synchronize()
     want32 = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_ref"], s["od"], 0.9, emulate_bf16=False)
-    want16 = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_ref"], s["od"], 0.9, emulate_bf16=True)
+    if merged:
+        Wm, rest = LR.merge_llm_lora(s["W"], s["lora_ref"], s["od"], emulate_bf16=True)
+        want16 = LR.policy_forward(images, queries, qmask, resp, Wm, rest, s["od"], 0.9, emulate_bf16=True)
+    else:
+        want16 = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_ref"], s["od"], 0.9, emulate_bf16=True)
     worst16 = worst32 = 0.0
     for k in resp:
         got = out[k + "_logprobs"].cpu()
@@ -119,8 +132,8 @@ def test_logprobs_forward(setup, pack):
                 worst16 = max(worst16, float(r.mean()))
             else:
                 worst32 = max(worst32, float(r.mean()))
-            REPORT[f"logp_{k}_maxrel_vs_{tag}{'_packed' if pack else ''}"] = float(r.max())
-            REPORT[f"logp_{k}_meanrel_vs_{tag}{'_packed' if pack else ''}"] = float(r.mean())
+            REPORT[f"logp_{k}_maxrel_vs_{tag}{'_packed' if pack else ''}{'_merged' if merged else ''}"] = float(r.max())
+            REPORT[f"logp_{k}_meanrel_vs_{tag}{'_packed' if pack else ''}{'_merged' if merged else ''}"] = float(r.mean())
         ge = out[k + "_entropies"].cpu()
         REPORT[f"ent_{k}_maxabs_vs_32"] = float((ge - want32[k + "_entropies"]).abs().max())
         assert float((ge - want32[k + "_entropies"]).abs().max()) < 5e-2
@@ -167,9 +180,11 @@ def test_lora_backward(setup, pack):
     s["pol"].grad.zero_()
 
 
+@MERGED
 @PACK
-def test_trainer_step_against_oracle(setup, pack):
-    """rollout -> compute_policy_loss (CoPO + AncPO + scores) -> backward -> clip -> AdamW, vs the oracle."""
+def test_trainer_step_against_oracle(setup, pack, merged):
+    """rollout -> compute_policy_loss (CoPO + AncPO + scores) -> backward -> clip -> AdamW, vs the oracle.
+    merged=True: the rollout's reference pass runs on the merged adapter copy (the CLI / bench default)."""
     s = setup
     LR = s["LR"]
     from types import SimpleNamespace
@@ -189,7 +204,7 @@ def test_trainer_step_against_oracle(setup, pack):
                            learning_rate=1e-3, warmup_steps=0, total_epochs=1, max_step=100, save_steps=1000,
                            output_dir="/tmp/none", seed=0, weight_decay=0.0, CoPO=True, AncPO=True, temperature=1.0)
     master0 = s["pol"].master.clone()
-    tr = DPOTrainer(args, _policy(s, s["pol"], T, pack), _policy(s, s["ref"], T, pack))
+    tr = DPOTrainer(args, _policy(s, s["pol"], T, pack), _policy(s, s["ref_merged"] if merged else s["ref"], T, pack))
     tr.total_sched_steps = 10
     tr.optimizer.lr = 1e-3
     torch.manual_seed(77)                      # CoPO mask positions come from the global CPU RNG
@@ -246,7 +261,27 @@ def test_trainer_step_against_oracle(setup, pack):
     cos = float((upd_got * upd_want).sum() / (upd_got.norm() * upd_want.norm()))
     REPORT["update_cosine"] = cos
     REPORT["grad_norm_post_clip"] = tr.optimizer.grad_norm_post_clip()
-    assert cos > 0.9, cos    # first Adam step is sign-like: near-zero gradient entries may flip
+    # element-wise AdamW check.  The first Adam step is -lr * g / (|g| + eps): sign-like, so entries whose gradient is below the
+    # bf16 noise of the backward may legitimately flip; every entry ABOVE that noise floor must match the oracle's update
+    # (a sign error or a dropped scale in any block fails here, which a cosine over the whole buffer would not show).
+    g_hip = s["pol"].grad.cpu()
+    g_rel = float((g_hip - flat_g).norm() / flat_g.norm())
+    REPORT["trainer_grad_rel_frobenius"] = g_rel
+    assert g_rel < 3e-2, g_rel
+    noise = float((g_hip - flat_g).abs().max())
+    sig = flat_g.abs() > 4.0 * noise
+    REPORT["adamw_elementwise_checked_fraction"] = float(sig.float().mean())
+    assert float(sig.float().mean()) > 0.05, "noise floor too high: the element-wise check would cover too little"
+    assert bool((torch.sign(upd_got[sig]) == torch.sign(upd_want[sig])).all()), "AdamW update sign differs above the noise floor"
+    err = (upd_got[sig] - upd_want[sig]).abs().max()
+    REPORT["adamw_elementwise_max_err_over_lr"] = float(err) / 1e-3
+    assert float(err) < 2e-2 * 1e-3, f"AdamW update differs element-wise by {float(err):.3e} (lr 1e-3)"
+    for i in range(s["d"].n_layers):        # and per fused block (a block-level sign / scale error shows as cos << 1)
+        for name, rows, cols in lora_blocks(s["d"]):
+            off = s["pol"].offsets[i][name][0]
+            a, b = upd_got[off:off + rows * cols], upd_want[off:off + rows * cols]
+            bc = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            assert bc > 0.8, (i, name, bc)
     assert abs(tr.optimizer.grad_norm_post_clip() - min(1.0, float(flat_g.norm()))) < 5e-2
     # leave the shared fixture as it was (the optimizer moved the policy adapter)
     s["pol"].master.copy_(master0)
