@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
@@ -199,6 +200,7 @@ def main():
     from opadpo_amd import lib as L
     from opadpo_amd.dims import LlavaDims, lora_param_count, pair_flops, pair_flops_packed
     from opadpo_amd.losses import DPOArgs, pair_loss
+    from opadpo_amd.ctx import CtxEngine
     from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
     from opadpo_amd.optim import FlatAdamW, layer_buckets
     from opadpo_amd.policy import AutoregressivePolicy
@@ -210,7 +212,7 @@ def main():
     W = init_weights(d, seed=0, device=dev)
     base = BaseWeights(d, W, dev, need_backward=True)
     del W
-    eng = LlavaEngine(base)
+    eng = LlavaEngine(base) if args.op_level else CtxEngine(base)      # default: ONE C call per pass (opadpo_seq_logprobs_fwd / _bwd)
     pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
     if not args.no_merge_ref:      # frozen adapter: s*B@A folded once into a second bf16 copy of the projections (PEFT-style merge)
@@ -255,13 +257,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    L.PROFILE = [] if rank == 0 else None
+    L.PROFILE = [] if rank == 0 else None               # vision / adapter-refresh GEMMs launched from Python (op-level wrapper)
+    if rank == 0 and hasattr(eng, "profile"):
+        eng.profile(True)                               # the LLM passes: launched inside opadpo_seq_logprobs_fwd / _bwd
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
     prof, L.PROFILE = L.PROFILE, None
+    ctx_prof = None
+    if rank == 0 and hasattr(eng, "profile"):
+        ctx_prof = eng.profile_read()
+        eng.profile(False)
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -273,14 +281,17 @@ def main():
         merged = not args.no_merge_ref
         fl = pair_flops_packed(d, q_len, t_len, 2, ref_merged=merged) if pack else fl_ref - (2 * 2 * lora_param_count(d) * (q_len + t_len + d.n_patches - 1) if merged else 0)     # what this run executes
         roof = None
-        if prof:
-            tot_f = sum(p[0] for p in prof)
-            tot_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        if prof or ctx_prof:
+            tot_f = sum(p[0] for p in prof or [])
+            tot_ms = sum(p[1].elapsed_time(p[2]) for p in prof or [])
+            n_launch = len(prof or [])
+            if ctx_prof:
+                tot_f, tot_ms, n_launch = tot_f + ctx_prof[0], tot_ms + ctx_prof[1], n_launch + ctx_prof[2]
             ach = tot_f / (tot_ms * 1e-3) / 1e12
             traffic, traffic_src = _pmc_traffic()
             roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, long-lead LDS-DMA ring / 128x128 for skinny N; LoRA tail fused by K-concatenation)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src, "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": tot_ms / n_launch,
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
         out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": value, "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

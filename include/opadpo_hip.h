@@ -190,6 +190,119 @@ int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperatu
                   uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
                   int32_t* out, int32_t* history, void* stream);
 
+/* =====================================================================================================================
+ * Context API: the SEQUENCE-LEVEL entry points.
+ *
+ * The reference's seam is one Python call per pass - `self.base_model(**inputs)` (opadpo/dpo_models/rl_models.py:114-120), its
+ * backward `accelerator.backward(loss)` (rl_trainer.py:162) and `policy.generate(...)` (rl_models.py:166-183,
+ * opadpo/generator_models/online_generator.py:292-309).  An `opadpo_ctx` puts the whole schedule of such a pass below the C ABI:
+ *   - one context per process / GPU (one process per GPU, run/train_opa_dpo.sh:96-99); not re-entrant per context;
+ *   - weights, adapters, token ids, masks and outputs are BORROWED raw device pointers (the caller keeps them alive);
+ *   - the workspace, the saved activations of a training forward and the KV cache of a rollout are OWNED by the context
+ *     (hipMalloc by default, or the caller's stream-ordered allocator - opadpo_ctx_set_allocator - so that a torch host keeps ONE
+ *     memory pool); opadpo_ctx_destroy frees everything;
+ *   - every call takes the caller's hipStream_t and is asynchronous on it (opadpo_decode_begin synchronises twice for two tiny
+ *     host->device counters); int return code, 0 = ok, text through opadpo_ctx_last_error(ctx); never aborts, never a CPU path;
+ *   - kernel-variant switches are per context (opadpo_ctx_set_flags), not process-global.
+ * ===================================================================================================================== */
+#define OPADPO_MAX_ADAPTERS 8
+#define OPADPO_IMAGE_TOKEN (-200) /* utils/constants.py:28 IMAGE_TOKEN_INDEX */
+
+typedef struct opadpo_ctx opadpo_ctx;
+typedef struct opadpo_saved opadpo_saved; /* activations of one training forward, owned by the context */
+
+typedef struct opadpo_dims {
+  int hidden, n_layers, n_heads, head_dim, ffn, vocab; /* Llama-2 decoder (7B: 4096, 32, 32, 128, 11008, 32000) */
+  float rms_eps, rope_theta;
+  int v_hidden, v_used_layers, v_heads, v_ffn, image_size, patch; /* CLIP-ViT-L/14-336: 1024, 23 (hidden_states[-2]), 16, 4096, 336, 14 */
+  float v_eps;
+  int lora_r; /* 256 in the OPA-DPO recipe */
+  float lora_alpha;
+} opadpo_dims;
+
+/* One decoder layer, bf16, row-major [out, in]: q|k|v and gate|up fused along the output dimension.  *_t = K-major transposed
+ * copies ([in, out]) used by the dgrad GEMMs (NULL for inference-only contexts). */
+typedef struct opadpo_layer_weights {
+  const uint16_t *wqkv, *wo, *wgu, *wd, *ln1, *ln2;
+  const uint16_t *wqkv_t, *wo_t, *wgu_t, *wd_t;
+} opadpo_layer_weights;
+
+typedef struct opadpo_vision_layer_weights {
+  const uint16_t *ln1_w, *ln1_b, *ln2_w, *ln2_b, *wqkv, *bqkv, *wo, *bo, *fc1, *b1, *fc2, *b2;
+} opadpo_vision_layer_weights;
+
+typedef struct opadpo_vision_weights {
+  const uint16_t *patch_w;              /* [v_hidden, ceil64(3*patch*patch)] zero-padded conv weight */
+  const uint16_t *cls, *pos, *pre_ln_w, *pre_ln_b;
+  const uint16_t *proj0, *proj0_b, *proj2, *proj2_b; /* mm_projector mlp2x_gelu */
+} opadpo_vision_weights;
+
+/* stream-ordered allocator hooks: alloc(bytes, stream, user) -> device pointer (NULL on failure); free(ptr, user) */
+typedef void* (*opadpo_alloc_fn)(size_t bytes, void* stream, void* user);
+typedef void (*opadpo_free_fn)(void* ptr, void* user);
+
+int opadpo_ctx_create(const opadpo_dims* dims, int device, opadpo_ctx** out);
+void opadpo_ctx_destroy(opadpo_ctx* ctx);
+const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
+int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
+/* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default */
+int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
+/* return cached arenas and the workspace to the allocator */
+int opadpo_ctx_trim(opadpo_ctx* ctx);
+size_t opadpo_ctx_bytes_peak(const opadpo_ctx* ctx);
+/* live measurement of the dominant kernel: while enabled every gemm_nt launch of the context is bracketed by HIP events on the launch
+ * stream; _read waits for them and returns (and clears) the sum of algorithmic FLOPs 2*M*N*(K1+K2), the sum of launch durations in ms
+ * and the launch count */
+int opadpo_ctx_profile(opadpo_ctx* ctx, int enable);
+int opadpo_ctx_profile_read(opadpo_ctx* ctx, double* flops, double* ms, int64_t* launches);
+
+/* make_models (dpo_trainer.py:958-1038): ONE frozen base shared by every adapter */
+int opadpo_ctx_set_llm_weights(opadpo_ctx* ctx, const uint16_t* embed, const uint16_t* final_norm, const uint16_t* lm_head,
+                               const uint16_t* lm_head_t, const opadpo_layer_weights* layers, int n_layers);
+int opadpo_ctx_set_vision_weights(opadpo_ctx* ctx, const opadpo_vision_weights* w, const opadpo_vision_layer_weights* layers, int n_layers);
+/* optional: rotary tables [n_pos][head_dim/2] fp32 from the host (default: the context computes HF Llama's own) */
+int opadpo_ctx_set_rope_tables(opadpo_ctx* ctx, const float* cos_tab, const float* sin_tab, int n_pos);
+/* set_adapter (rl_models.py:84-85): adapter `id` = flat bf16 LoRA buffer (layer-major; per layer a_qkv [3r,H] | b_qkv [3H,r] | a_o |
+ * b_o | a_gu [2r,H] | b_gu [2F,r] | a_d [r,F] | b_d [H,r]); work_t = its K-major copy, grad = flat fp32 gradient (both NULL for a
+ * frozen adapter); work = NULL selects the bare base model */
+int opadpo_ctx_set_adapter(opadpo_ctx* ctx, int id, const uint16_t* work, const uint16_t* work_t, float* grad);
+/* a FROZEN adapter folded into its own copy of the projections (PEFT merge); swiglu_pair: wgu rows per 128 = [64 gate | 64 up] */
+int opadpo_ctx_set_merged_adapter(opadpo_ctx* ctx, int id, const opadpo_layer_weights* merged, int n_layers, int swiglu_pair);
+
+/* get_vision_tower() + mm_projector: pixels [B,3,S,S] bf16 -> feats [B, 576, hidden] bf16 */
+int opadpo_vision_encode(opadpo_ctx* ctx, const uint16_t* pixels, int B, uint16_t* feats, void* stream);
+
+/* base_model(**inputs) + logits[:, -T-1:-1] / temperature + compute_logprobs + entropy (rl_models.py:114-132), for S rows
+ * [query | response_0 | .. | response_{K-1}] of n_txt ids each (one OPADPO_IMAGE_TOKEN per row; K > 1: the responses share one pass
+ * over the image + query prefix).  feat_row[s] = which image's features row s uses; image_mask [S,576] (nullable) = CoPO
+ * 'attention' key mask.  logp / ent: [K*S*T] fp32 in the reference's stacking order [k][s][t].  train = 1 keeps the activations
+ * (handle in *saved); train = 0 releases them (*saved = NULL). */
+int opadpo_seq_logprobs_fwd(opadpo_ctx* ctx, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const int32_t* feat_row,
+                            const uint8_t* image_mask, const uint16_t* feats, int S, int n_txt, int T, int K, float temperature, int train,
+                            float* logp, float* ent, opadpo_saved** saved, void* stream);
+/* accelerator.backward(loss): accumulates d loss / d LoRA into the adapter's flat fp32 grad buffer for decoder layers
+ * layer_hi .. layer_lo (top-down).  The first call of a backward starts at n_layers - 1 (it runs the head backward from dlogp
+ * [K*S*T] and the optional entropy gradient dent); later calls continue below - a data-parallel host launches the exchange of a
+ * finished bucket of layers between two calls.  d_feats (nullable, fp32 [n_images,576,hidden], accumulated): gradient w.r.t.
+ * the image features (OPA LoRA-SFT stage), written when layer_lo == 0. */
+int opadpo_seq_logprobs_bwd(opadpo_ctx* ctx, opadpo_saved* saved, const float* dlogp, const float* dent, float* d_feats, int layer_hi,
+                            int layer_lo, void* stream);
+int opadpo_saved_release(opadpo_ctx* ctx, opadpo_saved* saved);
+
+/* policy.generate(do_sample=True, ...) (online_generator.py:292-309): prefill of B left-padded queries [B,Q] + token 0; the KV
+ * cache ([n_layers, B, heads, Q+575+max_new_tokens, head_dim] x2) lives in the context.  history [max_new_tokens, B] int32
+ * (caller-owned) receives the tokens; finished rows emit pad_id.  suppress_eos: benchmarks (never sample EOS). */
+int opadpo_decode_begin(opadpo_ctx* ctx, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const uint16_t* feats, int B, int Q,
+                        int max_new_tokens, float temperature, int top_k, float top_p, uint64_t seed, int eos_id, int pad_id, int suppress_eos,
+                        int32_t* history, void* stream);
+/* one more token for every row: all launches of a step, asynchronous */
+int opadpo_decode_step(opadpo_ctx* ctx, void* stream);
+/* n_steps more tokens; use_graph: one step is captured into a hipGraph once and replayed per token */
+int opadpo_decode_run(opadpo_ctx* ctx, int n_steps, int use_graph, void* stream);
+/* synchronous: *all_finished = every row has emitted EOS */
+int opadpo_decode_all_finished(opadpo_ctx* ctx, int* all_finished, void* stream);
+int opadpo_decode_end(opadpo_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

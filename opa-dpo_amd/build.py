@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libopadpo_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "head_optim.hip", "decode.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "head_optim.hip", "decode.hip", "capi.hip", "ctx.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 

@@ -672,7 +672,7 @@ hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
-  const bool tr = opadpo_flag_tr();
+  const bool tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : opadpo_flag_tr();
   const bool dma = g_attn_dma && (double)a.L * a.ld * 2 < 2.0e9;     // per-sequence extent must fit the 32-bit descriptor
   static bool attr_set = false;
   if (!attr_set) {
@@ -697,7 +697,7 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   const int total = a.S * a.L * a.nh;
   const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
-  const bool tr = opadpo_flag_tr();
+  const bool tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : opadpo_flag_tr();
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80);

@@ -91,7 +91,7 @@ int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.key_mask = key_mask;
   a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
   if (seg_len < 0 || seg_prefix < 0 || (seg_len > 0 && !causal)) return bad("opadpo_attn_fwd", "packed responses need causal attention and seg_prefix, seg_len >= 0");
-  a.seg_prefix = seg_prefix; a.seg_len = seg_len;
+  a.seg_prefix = seg_prefix; a.seg_len = seg_len; a.use_tr = -1;
   return done(launch_attn_fwd(a, S(stream)), "opadpo_attn_fwd");
 }
 
@@ -108,7 +108,7 @@ int opadpo_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
   a.q = q; a.k = k; a.v = v; a.o = (uint16_t*)o; a.lse = (float*)lse; a.key_mask = key_mask;
   a.S = S_; a.L = L; a.nh = nh; a.hd = hd; a.ld = ld; a.ldo = ldo; a.causal = causal; a.scale = scale;
   a.dout = dout; a.dq_acc = dq_f32; a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta;
-  a.seg_prefix = seg_prefix; a.seg_len = seg_len;
+  a.seg_prefix = seg_prefix; a.seg_len = seg_len; a.use_tr = -1;
   return done(launch_attn_bwd(a, S(stream)), "opadpo_attn_bwd");
 }
 

@@ -2237,6 +2237,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   a.group_m = env_gm > 0 ? env_gm : (a.N / P_BN <= 16 ? 4 : 8);
   const bool stream_hint = (a.act & OPADPO_GEMM_STREAM) != 0;
   a.act &= 0xff;
+  const int g_gemm_variant = a.variant >= 0 ? a.variant : ::g_gemm_variant;      // per-call override (opadpo_ctx_set_flags)
   if (a.N % BN || a.K1 % BK || a.K2 % BK || a.K1 + a.K2 <= 0) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
@@ -2410,6 +2411,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (a.N1 % 128 || a.N2 % 128) return hipErrorInvalidValue;
+  const bool g_use_tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : ::g_use_tr;       // per-call override (opadpo_ctx_set_flags)
   // wide tiles: span 256 of the SMALL dimension so that the big operand is read once (twice / three times for 2r / 3r)
   const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
   int bn1 = 128, bn2 = 128;

@@ -26,6 +26,7 @@ struct GemmNTArgs {
   const float* rope_sin = nullptr;
   int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
   int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
+  int variant = -1;                     // kernel-variant override of this call (opadpo_ctx_set_flags); -1 = process default (opadpo_set_flags)
 };
 
 struct GemmTNArgs {
@@ -36,6 +37,7 @@ struct GemmTNArgs {
   int q_group_n1, q_group_stride;       // Q column offset = (n1_0 / q_group_n1) * q_group_stride
   float alpha;
   int splits;                           // <=0: auto
+  int use_tr = -1;                      // per-call override of the transposed-LDS-read switch; -1 = process default
 };
 
 struct AttnArgs {
@@ -53,6 +55,7 @@ struct AttnArgs {
   float* dq_acc;                                        // optional fp32 copy of dQ [S*L, nh*hd] (nullable)
   bf16_t* dq; bf16_t* dk; bf16_t* dv;                   // ld addressing (same as q / k / v)
   float* delta;                                         // [S, nh, L] scratch
+  int use_tr;                                           // per-call override of the transposed-LDS-read switch; < 0 = process default
 };
 
 void opadpo_set_flags_impl(int use_glds, int use_tr);

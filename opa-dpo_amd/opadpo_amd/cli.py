@@ -121,7 +121,8 @@ def main(argv: Optional[List[str]] = None) -> None:
     from . import checkpoint_io as CK
     from .data import DataCollatorForCausalLM, DPODataset
     from .dims import LlavaDims
-    from .model import BaseWeights, LlavaEngine, LoraAdapter
+    from .ctx import CtxEngine
+    from .model import BaseWeights, LoraAdapter
     from .policy import AutoregressivePolicy
     from .trainer import DPOTrainer, get_last_checkpoint
 
@@ -155,7 +156,7 @@ def main(argv: Optional[List[str]] = None) -> None:
         cfg_path = os.path.join(ckpt, "adapter_config.json")
         src_cfg = json.load(open(cfg_path)) if os.path.exists(cfg_path) else None
     base = BaseWeights(d, state, dev, need_backward=True, vision_lora=vision_lora)
-    engine = LlavaEngine(base)
+    engine = CtxEngine(base)          # sequence-level C entry points (opadpo_ctx): layer loop, workspace, activations below the ABI
     policy = AutoregressivePolicy(engine, LoraAdapter(d, adapter_sd, dev, True), args.response_len, args.temperature, "lora_policy")
     ref_adapter = LoraAdapter(d, ref_sd, dev, False)
     if args.merge_ref_adapter:      # frozen reference adapter folded into its own bf16 weight copy (model.LoraAdapter.merge_into_base)

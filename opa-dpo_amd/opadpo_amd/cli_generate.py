@@ -79,7 +79,8 @@ def _engine(base_dir: str, synthetic: Optional[str], adapter_dir: Optional[str],
     import torch
     from . import checkpoint_io as CK
     from .dims import LlavaDims
-    from .model import BaseWeights, LlavaEngine, LoraAdapter
+    from .ctx import CtxEngine
+    from .model import BaseWeights, LoraAdapter
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
     if synthetic:
@@ -101,7 +102,7 @@ def _engine(base_dir: str, synthetic: Optional[str], adapter_dir: Optional[str],
         if tok.pad_token_id is None:
             tok.pad_token = tok.unk_token
     vision = {k: v for k, v in (adapter_sd or {}).items() if "vision_tower" in k or "mm_projector" in k} or None
-    engine = LlavaEngine(BaseWeights(d, state, dev, need_backward=False, vision_lora=vision))
+    engine = CtxEngine(BaseWeights(d, state, dev, need_backward=False, vision_lora=vision))
     adapter = LoraAdapter(d, adapter_sd, dev, trainable=False) if adapter_sd else None
     return engine, adapter, tok
 

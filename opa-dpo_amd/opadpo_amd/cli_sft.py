@@ -66,7 +66,8 @@ def main(argv: Optional[List[str]] = None) -> None:
         dist.init_process_group("nccl", device_id=dev)
     from . import checkpoint_io as CK
     from .dims import LlavaDims
-    from .model import BaseWeights, LlavaEngine, LoraAdapter
+    from .ctx import CtxEngine
+    from .model import BaseWeights, LoraAdapter
     from .optim import cosine_lr
     from .sft import SFTTrainer, sft_batches_from_dpo_batch
     from .vision_train import VisionLoraAdapter
@@ -107,7 +108,7 @@ def main(argv: Optional[List[str]] = None) -> None:
                 for sb in sft_batches_from_dpo_batch(coll([dataset[j] for j in perm[i:i + B]])):
                     yield sb
         steps_per_epoch = max(1, (2 * (len(dataset) // world) // B) // ns.gradient_accumulation_steps)
-    engine = LlavaEngine(BaseWeights(d, state, dev, need_backward=True))
+    engine = CtxEngine(BaseWeights(d, state, dev, need_backward=True))
     del state
     tr = SFTTrainer(engine, LoraAdapter(d, lora, dev, trainable=True), VisionLoraAdapter(d, lora, dev), response_len=t_len,
                     lr=ns.learning_rate, max_grad_norm=ns.max_grad_norm, weight_decay=ns.weight_decay, optimizer_mode=ns.optimizer_mode,

@@ -63,6 +63,13 @@ class Generator:
         """-> responses [B, max_new_tokens] int64 (pad after a row finished)."""
         eng, d, b = self.engine, self.engine.d, self.engine.base
         dev = eng.dev
+        if hasattr(eng, "ctx"):      # CtxEngine: prefill, KV cache, the per-token hipGraph and the sampler loop live below the C ABI
+            if image_feats is None:
+                image_feats = eng.encode_images(images)
+            return eng.generate(self.adapter, queries, query_attn_masks, image_feats, max_new_tokens=max_new_tokens, temperature=temperature,
+                                top_k=top_k, top_p=top_p, seed=seed, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                suppress_eos=suppress_eos, use_graph=self.use_graph)
+        # op-level sequencing of the same kernels (LlavaEngine): kept as the cross-check of the context path (tests/test_ctx_gpu.py)
         st = L.stream()
         B, Q = queries.shape
         P, H, F, r, nh, hd, V = d.n_patches, d.hidden, d.ffn, d.lora_r, d.n_heads, d.head_dim, d.vocab

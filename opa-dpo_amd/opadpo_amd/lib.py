@@ -58,7 +58,31 @@ SIGNATURES = {
     "opadpo_attn_decode_fused": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _f, _p, _sz, _p],
     "opadpo_sample": [_p, _i, _i, _i, _f, _i, _f, _u64, _u64, _p, _p, _i, _i, _p, _p, _p],
 }
-OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes"]
+# context API (include/opadpo_hip.h, "Context API"): sequence-level entry points on an opaque opadpo_ctx*
+SIGNATURES.update({
+    "opadpo_ctx_create": [_p, _i, _p],
+    "opadpo_ctx_set_allocator": [_p, _p, _p, _p],
+    "opadpo_ctx_set_flags": [_p, _i, _i],
+    "opadpo_ctx_trim": [_p],
+    "opadpo_ctx_profile": [_p, _i],
+    "opadpo_ctx_profile_read": [_p, _p, _p, _p],
+    "opadpo_ctx_set_llm_weights": [_p, _p, _p, _p, _p, _p, _i],
+    "opadpo_ctx_set_vision_weights": [_p, _p, _p, _i],
+    "opadpo_ctx_set_rope_tables": [_p, _p, _p, _i],
+    "opadpo_ctx_set_adapter": [_p, _i, _p, _p, _p],
+    "opadpo_ctx_set_merged_adapter": [_p, _i, _p, _i, _i],
+    "opadpo_vision_encode": [_p, _p, _i, _p, _p],
+    "opadpo_seq_logprobs_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p],
+    "opadpo_seq_logprobs_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "opadpo_saved_release": [_p, _p],
+    "opadpo_decode_begin": [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _f, _u64, _i, _i, _i, _p, _p],
+    "opadpo_decode_step": [_p, _p],
+    "opadpo_decode_run": [_p, _i, _i, _p],
+    "opadpo_decode_all_finished": [_p, _p, _p],
+    "opadpo_decode_end": [_p],
+})
+OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes",
+                 "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_ctx_bytes_peak"]
 
 _lib: Optional[C.CDLL] = None
 
@@ -86,6 +110,12 @@ def load() -> C.CDLL:
     lib.opadpo_set_flags.restype = None
     lib.opadpo_attn_decode_workspace_bytes.argtypes = [_i, _i, _i, _i]
     lib.opadpo_attn_decode_workspace_bytes.restype = _sz
+    lib.opadpo_ctx_destroy.argtypes = [_p]
+    lib.opadpo_ctx_destroy.restype = None
+    lib.opadpo_ctx_last_error.argtypes = [_p]
+    lib.opadpo_ctx_last_error.restype = C.c_char_p
+    lib.opadpo_ctx_bytes_peak.argtypes = [_p]
+    lib.opadpo_ctx_bytes_peak.restype = _sz
     if lib.opadpo_abi_version() != 1:
         raise OpadpoError("ABI version mismatch")
     _lib = lib

@@ -23,7 +23,7 @@ def parse_header():
         if args and args != "void":
             for a in args.split(","):
                 a = a.strip()
-                if "*" in a:
+                if "*" in a or a.split()[0].endswith("_fn"):       # pointers, and the typedef'd allocator function pointers
                     types.append(ctypes.c_void_p)
                 else:
                     types.append(CTYPE[a.replace("const ", "").split()[0]])
@@ -44,7 +44,10 @@ def test_header_declares_the_path():
     protos = parse_header()
     assert len(protos) >= 33
     for need in ("opadpo_gemm_nt", "opadpo_gemm_tn", "opadpo_attn_fwd", "opadpo_attn_bwd", "opadpo_head_fwd",
-                 "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_rope_kv_append", "opadpo_embed_splice"):
+                 "opadpo_head_bwd", "opadpo_adamw", "opadpo_sample", "opadpo_attn_decode", "opadpo_rope_kv_append", "opadpo_embed_splice",
+                 # sequence-level context API
+                 "opadpo_ctx_create", "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_vision_encode", "opadpo_seq_logprobs_fwd",
+                 "opadpo_seq_logprobs_bwd", "opadpo_decode_begin", "opadpo_decode_step", "opadpo_decode_run"):
         assert need in protos
 
 
@@ -78,3 +81,25 @@ def test_host_side_validation_needs_no_gpu(built_lib):
     fn.restype = ctypes.c_int
     rc = fn(None, 64, None, 64, 64, None, 0, None, 0, 0, 0, 0, 0, 0, None, 100, 0, None, 0, 0, None, 10, 100, 1.0, 0, None)
     assert rc != 0 and b"multiple of 128" in lib.opadpo_last_error()
+
+
+def test_context_lifecycle_and_errors_need_no_gpu(built_lib):
+    """opadpo_ctx: creation validates the geometry, entry points fail with a message (never abort) before any launch."""
+    from opadpo_amd import lib as L
+    from opadpo_amd.ctx import Dims
+    lib = L.load()
+    good = Dims(256, 2, 2, 128, 384, 512, 1e-5, 10000.0, 128, 2, 2, 256, 56, 14, 1e-5, 128, 256.0)
+    h = ctypes.c_void_p()
+    assert lib.opadpo_ctx_create(ctypes.byref(good), 0, ctypes.byref(h)) == 0 and h.value
+    assert lib.opadpo_ctx_set_flags(h, 4, 1) == 0
+    # forward before the weights were handed over: refused with text
+    rc = lib.opadpo_seq_logprobs_fwd(h, 0, None, None, None, None, None, 1, 8, 2, 1, 1.0, 0, None, None, None, None)
+    assert rc != 0 and b"weights not set" in lib.opadpo_ctx_last_error(h)
+    assert lib.opadpo_ctx_set_adapter(h, 99, None, None, None) != 0 and b"out of range" in lib.opadpo_ctx_last_error(h)
+    assert lib.opadpo_decode_step(h, None) != 0 and b"no active rollout" in lib.opadpo_ctx_last_error(h)
+    assert lib.opadpo_saved_release(h, ctypes.c_void_p(1234)) != 0
+    assert lib.opadpo_ctx_bytes_peak(h) == 0
+    lib.opadpo_ctx_destroy(h)
+    bad = Dims(250, 2, 2, 128, 384, 512, 1e-5, 10000.0, 128, 2, 2, 256, 56, 14, 1e-5, 128, 256.0)     # hidden != heads * head_dim
+    h2 = ctypes.c_void_p()
+    assert lib.opadpo_ctx_create(ctypes.byref(bad), 0, ctypes.byref(h2)) != 0 and not h2.value

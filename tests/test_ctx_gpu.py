@@ -1,0 +1,178 @@
+"""GPU: the sequence-level C entry points (opadpo_ctx, csrc/ctx.hip; include/opadpo_hip.h "Context API") against the
+op-level sequencing of the same kernels (model.LlavaEngine / generate.Generator's Python loop): the context moves the layer loop,
+the workspace, the saved activations and the KV cache below the C ABI and must not change a single bit of the log-probs
+(same launches, same order); LoRA gradients agree to fp32 accumulation order (the wgrad kernels add with atomics)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd import lib
+    from opadpo_amd.ctx import CtxEngine
+    from opadpo_amd.dims import LlavaDims
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
+    from opadpo_amd.synth import init_lora, init_weights, synth_pairs
+    lib.load()
+    dev = torch.device("cuda:0")
+    d = LlavaDims.tiny()
+    base = BaseWeights(d, init_weights(d, seed=0, std=0.05, device=dev), dev, need_backward=True)
+    op, cx = LlavaEngine(base), CtxEngine(base)
+    sd_pol, sd_ref = init_lora(d, seed=1, b_std=0.03, device=dev), init_lora(d, seed=2, b_std=0.03, device=dev)
+    ads = dict(pol=LoraAdapter(d, sd_pol, dev, True), ref=LoraAdapter(d, sd_ref, dev, False), merged=LoraAdapter(d, sd_ref, dev, False))
+    ads["merged"].merge_into_base(base)
+    p = synth_pairs(d, 3, 16, 24, seed=5, device=dev)
+    yield dict(d=d, dev=dev, base=base, op=op, cx=cx, ads=ads, p=p)
+    cx.close()
+
+
+def _policy(eng, ad, T, pack):
+    from opadpo_amd.policy import AutoregressivePolicy
+    return AutoregressivePolicy(eng, ad, T, pack_responses=pack)
+
+
+def _kw(p, eng):
+    return dict(images=p["images"], queries=p["queries"], queries_attn_masks=p["queries_attn_masks"], chosen_response=p["chosen"],
+                rejected_response=p["rejected"])
+
+
+def test_vision_encode_is_bit_identical(env):
+    a, b = env["op"].encode_images(env["p"]["images"]), env["cx"].encode_images(env["p"]["images"])
+    torch.cuda.synchronize()
+    assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("pack", [True, False])
+@pytest.mark.parametrize("which", ["ref", "merged", "none", "pol"])
+def test_forward_is_bit_identical(env, which, pack):
+    ad = env["ads"].get(which)
+    outs = []
+    for eng in (env["op"], env["cx"]):
+        with torch.no_grad():
+            outs.append(_policy(eng, ad, 24, pack)(**_kw(env["p"], eng), temperature=0.8))
+    torch.cuda.synchronize()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{which} pack={pack}: {k} differs, max {float((outs[0][k] - outs[1][k]).abs().max())}"
+    lp = outs[1]["chosen_response_logprobs"]
+    assert bool((lp[env["p"]["chosen"] == 0] == 0).all()) and float(lp.min()) < 0
+
+
+@pytest.mark.parametrize("pack", [True, False])
+def test_training_forward_backward_matches_op_level(env, pack):
+    ad, p = env["ads"]["pol"], env["p"]
+    g = torch.Generator().manual_seed(3)
+    w = {k: torch.randn(3, 24, generator=g).to(env["dev"]) for k in ("chosen_response", "rejected_response")}
+    res = []
+    for eng, hook in ((env["op"], None), (env["cx"], None), (env["cx"], "ranged")):
+        ad.grad.zero_()
+        pol = _policy(eng, ad, 24, pack)
+        seen = []
+        pol.layer_done_hook = (lambda i: seen.append(i)) if hook else None
+        out = pol(**_kw(p, eng))
+        loss = sum((out[k + "_logprobs"] * w[k]).sum() for k in w)
+        loss.backward()
+        torch.cuda.synchronize()
+        if hook:
+            assert seen == list(range(env["d"].n_layers - 1, -1, -1)), "layer-done hook must fire top-down, once per layer"
+        res.append((out["chosen_response_logprobs"].detach().clone(), ad.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][0], res[2][0])
+    for j in (1, 2):
+        rel = float((res[j][1] - res[0][1]).norm() / res[0][1].norm())
+        assert rel < 1e-5, f"context backward (variant {j}) differs from the op-level backward: rel {rel}"
+    assert float(res[0][1].abs().max()) > 0
+    ad.grad.zero_()
+
+
+def test_two_pending_forwards_like_copo(env):
+    """Two training forwards alive at once (clean + masked image), backward of both: activations of each are separate handles."""
+    ad, p, cx = env["ads"]["pol"], env["p"], env["cx"]
+    ad.grad.zero_()
+    pol = _policy(cx, ad, 24, True)
+    o1 = pol(**_kw(p, cx))
+    p2 = dict(p, images=(p["images"].float() * 0.5).to(BF))
+    o2 = pol(**_kw(p2, cx))
+    (o1["chosen_response_logprobs"].sum() + o2["rejected_response_logprobs"].sum()).backward()
+    torch.cuda.synchronize()
+    g_both = ad.grad.clone()
+    ad.grad.zero_()
+    pol(**_kw(p, cx))["chosen_response_logprobs"].sum().backward()
+    pol(**_kw(p2, cx))["rejected_response_logprobs"].sum().backward()
+    torch.cuda.synchronize()
+    assert float((g_both - ad.grad).norm() / ad.grad.norm()) < 1e-5
+    ad.grad.zero_()
+
+
+def test_default_allocator_and_per_context_flags(env):
+    """hipMalloc-backed context (no torch allocator hooks) and a context forced onto the 128x128 GEMM: same numbers as the default one
+    (the 256x256 and 128x128 kernels accumulate in a different order -> close, not equal); flags of one context do not leak."""
+    from opadpo_amd.ctx import CtxEngine
+    ad, p = env["ads"]["ref"], env["p"]
+    with torch.no_grad():
+        want = _policy(env["cx"], ad, 24, True)(**_kw(p, env["cx"]))
+        plain = CtxEngine(env["base"], torch_allocator=False)
+        got = _policy(plain, ad, 24, True)(**_kw(p, plain))
+        small = CtxEngine(env["base"])
+        small.set_flags(gemm_variant=4)
+        got4 = _policy(small, ad, 24, True)(**_kw(p, small))
+        again = _policy(env["cx"], ad, 24, True)(**_kw(p, env["cx"]))
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(want[k], got[k]) and torch.equal(want[k], again[k])
+        assert float((want[k] - got4[k]).abs().max()) < 5e-2
+    plain.close()
+    small.close()
+
+
+@pytest.mark.parametrize("mode", ["none", "ref", "merged", "fused"])
+def test_generation_matches_op_level_loop(env, mode):
+    from opadpo_amd.generate import Generator
+    p, d = env["p"], env["d"]
+    ad = {"none": None, "ref": env["ads"]["ref"], "merged": env["ads"]["merged"], "fused": None}[mode]
+    feats = env["op"].encode_images(p["images"])
+    for kw in (dict(top_k=1, top_p=1.0, seed=1), dict(temperature=0.8, top_k=20, top_p=0.9, seed=5), dict(top_k=30, top_p=0.95, seed=2, suppress_eos=True)):
+        outs = []
+        for eng, graph in ((env["op"], True), (env["cx"], True), (env["cx"], False)):
+            gen = Generator(eng, ad, use_graph=graph, fuse_swiglu=mode == "fused")
+            outs.append(gen.generate(p["queries"], p["queries_attn_masks"], image_feats=feats, max_new_tokens=40, **kw))
+        torch.cuda.synchronize()
+        assert outs[1].shape == (3, 40) and outs[1].dtype == torch.int64
+        assert torch.equal(outs[0], outs[1]), f"{mode} {kw}: context rollout differs from the op-level loop"
+        assert torch.equal(outs[1], outs[2]), f"{mode} {kw}: graph replay differs from eager steps"
+        for row in outs[1].tolist():                     # pad after the first EOS
+            if 2 in row:
+                assert all(t == 0 for t in row[row.index(2) + 1:])
+
+
+def test_wide_7b_forward_is_bit_identical():
+    """LLaVA-1.5-7B width, 2 layers, enough rows for the 256x256 kernels: context path == op-level path, bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from opadpo_amd.ctx import CtxEngine
+    from opadpo_amd.dims import LlavaDims
+    from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
+    from opadpo_amd.synth import init_lora, init_weights, synth_pairs
+    dev = torch.device("cuda:0")
+    d = LlavaDims(hidden=4096, n_layers=2, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2, v_heads=2, v_ffn=256,
+                  image_size=56, patch=14)
+    base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
+    op, cx = LlavaEngine(base), CtxEngine(base)
+    ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, True)
+    p = synth_pairs(d, 6, 128, 384, seed=7, device=dev)
+    g = torch.Generator().manual_seed(1)
+    w = {k: torch.randn(6, 384, generator=g).to(dev) for k in ("chosen_response", "rejected_response")}
+    res = []
+    for eng in (op, cx):
+        ad.grad.zero_()
+        out = _policy(eng, ad, 384, True)(**_kw(p, eng))
+        sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+        torch.cuda.synchronize()
+        res.append((out["chosen_response_logprobs"].detach().clone(), out["rejected_response_entropies"].clone(), ad.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[0][2] - res[1][2]).norm() / res[0][2].norm()) < 1e-5
+    cx.close()
+    op.release()
