@@ -16,6 +16,7 @@ tests/test_ctx_gpu.py checks that both give bit-identical log-probs.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -118,8 +119,7 @@ class CtxEngine(LlavaEngine):
         self._vl, self._vw = vl, vw
         self._call("opadpo_ctx_set_vision_weights", C.byref(vw), vl, d.v_used_layers)
         self._rope_len = 0
-        self._adapters: Dict[int, tuple] = {}        # id(adapter object) -> (slot, adapter, signature, keep-alive)
-        self._next_slot = 1                          # slot 0 = bare base model
+        self._adapters: Dict[int, tuple] = {}        # id(adapter object) -> (slot 1..7, weakref, signature, keep-alive); slot 0 = bare base
         self._call("opadpo_ctx_set_adapter", 0, None, None, None)
 
     # ---- plumbing -------------------------------------------------------------------------------------------------------
@@ -176,13 +176,21 @@ class CtxEngine(LlavaEngine):
         else:
             sig = ("lora", adapter.work.data_ptr(), _ptr(adapter.work_t), _ptr(adapter.grad))
         ent = self._adapters.get(id(adapter))
+        if ent is not None and ent[1]() is not adapter:       # the id was recycled by a new object
+            ent = None
         if ent is not None and ent[2] == sig:
             return ent[0]
-        slot = ent[0] if ent is not None else self._next_slot
         if ent is None:
-            if slot >= 8:
-                raise L.OpadpoError("more than 7 adapters registered with one context")
-            self._next_slot += 1
+            dead = [k for k, e in self._adapters.items() if e[1]() is None]      # slots of adapters that no longer exist are reused
+            free = sorted(self._adapters.pop(k)[0] for k in dead)
+            used = {e[0] for e in self._adapters.values()}
+            cand = [s_ for s_ in range(1, 8) if s_ not in used]
+            if not cand:
+                raise L.OpadpoError("more than 7 live adapters registered with one context")
+            slot = cand[0]
+            del free
+        else:
+            slot = ent[0]
         keep = None
         if merged is not None:
             arr = (LayerWeights * self.d.n_layers)()
@@ -197,7 +205,7 @@ class CtxEngine(LlavaEngine):
             keep = (arr, merged)
         else:
             self._call("opadpo_ctx_set_adapter", slot, _ptr(adapter.work), _ptr(adapter.work_t), _ptr(adapter.grad))
-        self._adapters[id(adapter)] = (slot, adapter, sig, keep)
+        self._adapters[id(adapter)] = (slot, weakref.ref(adapter), sig, keep)
         return slot
 
     # ---- the three passes -----------------------------------------------------------------------------------------------

@@ -13,9 +13,10 @@ Tolerance (BASELINE.md §4 / north_star): per-token log-probs within 1e-3 RELATI
 
   * two bf16 pipelines cannot agree to 1e-3 on a deep random-init model even when they round at the same points: a last-bit
     difference in an fp32 accumulation flips bf16 rounding decisions, and every flip (a 2^-8 relative step) is amplified by the
-    following layers.  The oracle shows it on itself: `oracle.llava_ref.REORDER_K` evaluates the SAME bf16-emulating oracle with
-    every contraction summed in reverse order - its two realisations differ by about as much as the HIP path differs from either
-    (while the two fp32 evaluations agree to 1e-7).  That distance is the NOISE FLOOR of this oracle for any bf16 implementation,
+    following layers.  The oracle shows it on itself: `oracle.llava_ref.REORDER_K` / `P_ROUNDING` evaluate the SAME bf16-emulating
+    oracle with every contraction summed in reverse order and the attention probabilities rounded after instead of before their
+    normalisation (both implementation-defined in any flash-attention bf16 pipeline) - its two realisations differ by about as
+    much as the HIP path differs from either (while the two fp32 evaluations agree to 1e-7).  That distance is the NOISE FLOOR of this oracle for any bf16 implementation,
     the reference's own CUDA run included.
   * so: (1) at ONE decoder layer of full 7B width - every benchmarked kernel runs at its benchmark shape, nothing amplifies the
     noise yet - the mean relative error is asserted below 1e-3 with margin against the bf16-emulating oracle (`emulate_bf16=True`:
@@ -103,12 +104,14 @@ def _model(kw, n_seed_w=0, std=0.02):
 
 
 def _floor(LR, fn):
-    """Second realisation of the bf16-emulating oracle: same function, every contraction summed in reverse order."""
-    LR.REORDER_K = True
+    """Second realisation of the bf16-emulating oracle: same function, the two implementation-defined choices of a bf16 pipeline taken
+    the other way - every contraction summed in reverse order, attention probabilities rounded after instead of before the
+    normalisation."""
+    LR.REORDER_K, LR.P_ROUNDING = True, "softmax"
     try:
         return fn()
     finally:
-        LR.REORDER_K = False
+        LR.REORDER_K, LR.P_ROUNDING = False, "flash"
 
 
 def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):

@@ -48,7 +48,7 @@ def test_vision_encode_is_bit_identical(env):
 
 
 @pytest.mark.parametrize("pack", [True, False])
-@pytest.mark.parametrize("which", ["ref", "merged", "none", "pol"])
+@pytest.mark.parametrize("which", ["ref", "merged", "pol"])
 def test_forward_is_bit_identical(env, which, pack):
     ad = env["ads"].get(which)
     outs = []
