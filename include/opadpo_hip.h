@@ -36,11 +36,11 @@ extern "C" {
 
 int opadpo_abi_version(void);
 const char* opadpo_last_error(void);
-/* kernel-variant switches (diagnostics): use_glds = gemm_nt variant (10 = auto (default), 4 = 128x128 kernel, 8 / 17 = 8-wave
- * 256x256 kernels, 16 / 23 / 24 / 28 / 29 / 31 = 4-wave 256x256 family, 27 / 30 = stamped diagnostics); use_tr bit 0 =
- * ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 = attention forward through a direct-to-LDS
- * double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks per CU), bit 2 = wide gemm_tn tiles,
- * bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
+/* process-default kernel-variant switches of the op-level entry points (a context carries its own: opadpo_ctx_set_flags):
+ * use_glds = gemm_nt variant (10 = auto (default), 4 = 128x128 kernel, 17 = 8-wave 256x256 kernel, 31 = 4-wave 256x256 kernel forced,
+ * 15 = M <= 64 weight-streaming kernel); use_tr bit 0 = ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 =
+ * attention forward through a direct-to-LDS double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks
+ * per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
  * M <= 16 (default there: the whole-cache-line 8-row form). */
 void opadpo_set_flags(int use_glds, int use_tr);
 

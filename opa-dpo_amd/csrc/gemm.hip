@@ -233,212 +233,6 @@ constexpr int P_BM = 256, P_BN = 256, P_BK = 64;
 constexpr int P_TILE = P_BM * P_BK * 2;          // 32 KiB per operand tile
 constexpr int P_STAGE = 2 * P_TILE;              // A + B
 
-template <bool MF32, bool PRIO = true, bool ISSUE_FIRST = true, int GM = GROUP_M>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNTArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GM * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * GM;
-  const int gsz = min(tiles_m - first_m, GM);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
-  const int m0 = tm * P_BM, n0 = tn * P_BN;
-
-  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
-  const bf16_t* a2 = p.A2;
-  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
-  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
-  const int srow = lane >> 3, spos = lane & 7;
-
-  // one 1-KiB LDS-DMA piece (8 rows x 128 B) of K-tile t: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave.
-  // buffer_load ... lds through wave-uniform buffer descriptors: per issue ONE 32-bit VALU op (row * ld + swizzled
-  // chunk) — the tile / piece / K offsets ride in the scalar soffset; rows >= M fall outside the A descriptor's range
-  // (hardware range check, no clamp needed: those rows are never stored).
-  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.B1, 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? a2 : p.A1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc((void*)(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
-  const unsigned lrow = (unsigned)(wave * 32 + srow);                    // row of piece 0 inside the 256-row tile
-  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16),    // swizzled 16-B chunk, even / odd pieces
-                           (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
-  const unsigned m_last = (unsigned)(p.M - 1);
-  auto issue_piece = [&](int t, int q) {
-    const bool second = t >= nt1;
-    const int k0 = (second ? (t - nt1) : t) * P_BK;
-    char* base = smem + (t & 1) * P_STAGE;
-    const int pi = q & 3;
-    const int piece = wave * 4 + pi;
-    if (q < 4) {
-      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
-      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
-      const unsigned voff = row * ld2 + csw[pi & 1];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff, k0 * 2, 0, 0);
-    } else {
-      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-      const unsigned voff = lrow * ld2 + csw[pi & 1];
-      const unsigned soff = ((unsigned)n0 + pi * 8u) * ld2 + k0 * 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff, soff, 0, 0);
-    }
-  };
-  auto issue = [&](int t) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) issue_piece(t, q);
-  };
-
-  // 16x16x32 path: acc16[8][4] (f32x4), fragments af[2][8], bfr[2][4] of K=32 each;
-  // 32x32x16 path: acc32[4][2] (f32x16), fragments af[4][4], bfr[4][2] of K=16 each.  Same register budget.
-  f32x4_t acc16[MF32 ? 1 : 8][MF32 ? 1 : 4];
-  f32x16_t acc32[MF32 ? 4 : 1][MF32 ? 2 : 1];
-  bf16x8_t af[MF32 ? 4 : 2][MF32 ? 4 : 8], bfr[MF32 ? 4 : 2][MF32 ? 2 : 4];
-  if constexpr (MF32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc32[i][j][q] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  const int frow = MF32 ? (lane & 31) : (lane & 15), fchk = MF32 ? (lane >> 5) : (lane >> 4);
-
-  auto load_frags = [&](int t) {
-    const char* As = smem + (t & 1) * P_STAGE;
-    const char* Bs = As + P_TILE;
-    if constexpr (MF32) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int c = kk * 2 + fchk;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int row = wc * 64 + j * 32 + frow;
-          bfr[kk][j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wr * 128 + i * 32 + frow;
-          af[kk][i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int c = kk * 4 + fchk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wc * 64 + j * 16 + frow;
-          bfr[kk][j] = *(const bf16x8_t*)(Bs + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int row = wr * 128 + i * 16 + frow;
-          af[kk][i] = *(const bf16x8_t*)(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-      }
-    }
-  };
-  // 64 (32) MFMAs in 8 groups; when t_issue >= 0 one LDS-DMA piece of K-tile t_issue is issued after each group so
-  // that the (expensive) global_load_lds issue slots overlap with MFMAs already in the matrix pipe.
-  auto mfma_all = [&](int t_issue) {
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8) {
-      if constexpr (MF32) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int idx = g8 * 4 + e, kk = idx >> 3, i = (idx & 7) >> 1, j = idx & 1;
-          acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[kk][j], af[kk][i], acc32[i][j], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int idx = g8 * 8 + e, kk = idx >> 5, i = (idx & 31) >> 2, j = idx & 3;
-          acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc16[i][j], 0, 0, 0);
-        }
-      }
-      if (t_issue >= 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        issue_piece(t_issue, g8);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-  };
-#define PP_BARRIER()                               \
-  do {                                             \
-    __builtin_amdgcn_sched_barrier(0);             \
-    __builtin_amdgcn_s_barrier();                  \
-    __builtin_amdgcn_sched_barrier(0);             \
-  } while (0)
-
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PP_BARRIER();
-
-  if (wr == 0) {
-    for (int t = 0; t < nt; ++t) {
-      if constexpr (ISSUE_FIRST) { if (t + 1 < nt) issue(t + 1); }
-      load_frags(t);
-      if constexpr (!ISSUE_FIRST) { if (t + 1 < nt) issue(t + 1); }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PP_BARRIER();
-      mfma_all(-1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
-    }
-    PP_BARRIER();
-  } else {
-    if (nt > 1) issue(1);
-    PP_BARRIER();
-    for (int t = 0; t < nt; ++t) {
-      load_frags(t);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      PP_BARRIER();
-      mfma_all(t + 2 < nt ? t + 2 : -1);
-      PP_BARRIER();
-    }
-  }
-#undef PP_BARRIER
-  if constexpr (MF32) {
-    // D[i' = n][j' = m]: lane holds m = .. + (lane&31); n = .. + 8*q + 4*(lane>>5) + (reg&3)
-    epi_dispatch(p, [&](auto MD_) {
-      constexpr int md = decltype(MD_)::value;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 128 + i * 32 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            epilogue4<md>(p, m, n0 + wc * 64 + j * 32 + q * 8 + fchk * 4, acc32[i][j][q * 4 + 0], acc32[i][j][q * 4 + 1],
-                      acc32[i][j][q * 4 + 2], acc32[i][j][q * 4 + 3]);
-      }
-    });
-  } else {
-    epi_dispatch(p, [&](auto MD_) {
-      constexpr int md = decltype(MD_)::value;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          epilogue4<md>(p, m, n0 + wc * 64 + j * 16 + fchk * 4, acc16[i][j][0], acc16[i][j][1], acc16[i][j][2], acc16[i][j][3]);
-      }
-    });
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // gemm_nt "w4" kernel: 256x256 tile, BK = 64, FOUR waves (2x2), each owning a 128x128 block of C in 64 accumulator
 // fragments (256 accumulator registers -> one wave per SIMD, 512-register budget), two 64-KiB LDS stages filled by
@@ -1071,265 +865,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// gemm_nt "w4m" kernel: the w4 geometry and long-lead schedule with v_mfma_f32_32x32x16_bf16 (32 cycles in the matrix pipe
-// instead of 16).  One wave per SIMD issues in order, so an instruction between two MFMAs is free only if it issues within
-// the running MFMA's shadow; measured (tools/micro/mfma_dma.hip): an LDS-DMA instruction costs the 16-cycle MFMA stream ~35
-// cycles, the 32-cycle stream ~19; ds_read_b128 ~1, buffer_load into VGPRs ~3.  Same operand bytes, LDS reads (32 ds_read_b128
-// per tile), accumulator registers (16 x f32x16) and DMA pieces as w4; 64 MFMAs per K-tile:
-//   fragment sets: set s = k-steps 2s, 2s+1 (16 k each): r = 0..15 -> (ks_l = r >> 3; r & 7 < 4: B block, else A block)
-//   P1: 20 MFMAs(set 0) | 16 reads set1(t)                      | lgkmcnt(0), barrier -> the stage of tile t is dead
-//   P2/P3: 30 MFMAs | 13 DMA pieces of tile t+2 (one per 2 MFMAs) | vmcnt(13), barrier -> tile t+1 has landed
-//   P4: 14 MFMAs | 16 reads set0(t+1), 3 DMA pieces
-// Accumulator layout (operands swapped, D[n][m]): lane holds C row (lane & 31) of a 32-row block and, per 32-column block,
-// 4 groups q of 4 consecutive columns q*8 + (lane >> 5)*4.
-// ------------------------------------------------------------------------------------------
-template <bool PROF>
-__global__ __launch_bounds__(256) void gemm_nt_w4m_kernel(GemmNTArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = p.group_m * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * p.group_m;
-  const int gsz = min(tiles_m - first_m, p.group_m);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
-  const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
-
-  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
-  const bf16_t* a2 = p.A2;
-  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
-  const bf16_t* a1 = p.A1;
-  if (p.a1_group_n > 0) a1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
-  const int srow = lane >> 3, spos = lane & 7;
-  auto uni = [](const void* q) -> void* {      // resource bases stated wave-uniform (see gemm_nt_w4_kernel)
-    const unsigned long long v = (unsigned long long)q;
-    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-  };
-  const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(uni(a1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? a2 : a1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
-  const unsigned lrow = (unsigned)(wave * 64 + srow);
-  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
-  const unsigned m_last = (unsigned)(p.M - 1);
-  auto issue_piece = [&](int t, int q) {      // q = 0..7: A pieces (8 rows x 128 B) wave*8 + q, q = 8..15: B pieces
-    const bool second = t >= nt1;
-    const int k0 = (second ? (t - nt1) : t) * P_BK;
-    char* base = smem + (t & 1) * P_STAGE;
-    const int pi = q & 7;
-    const int piece = wave * 8 + pi;
-    if (q < 8) {
-      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
-      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, row * ld2 + csw[pi & 1], k0 * 2, 0, 0);
-    } else {
-      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)n0 + pi * 8u) * ld2 + k0 * 2));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, lrow * ld2 + csw[pi & 1], soff, 0, 0);
-    }
-  };
-
-  f32x16_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  bf16x8_t fa[2][8], fb[2][8];                         // [set][ks_l * 4 + block]
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int fsw = (frow >> 1) & 7;
-  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + frow) * 128;
-  auto read_frag = [&](int t, int s, int r) {
-    const char* st = smem + (t & 1) * P_STAGE;
-    const int ksl = r >> 3, b = r & 3;
-    const int cb = ((((s * 2 + ksl) * 2) + fhalf) ^ fsw) << 4;
-    if ((r & 7) < 4) fb[s][ksl * 4 + b] = *(const bf16x8_t*)(st + offB + b * 4096 + cb);
-    else fa[s][ksl * 4 + b] = *(const bf16x8_t*)(st + offA + b * 4096 + cb);
-  };
-#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // MFMAs idx0..idx0+n-1 of a set (idx = ks_l*16 + i*4 + j), accumulators tied in place
-  auto mfma_run = [&](int s, int idx0, int n) {
-#pragma unroll
-    for (int e = 0; e < n; ++e) {
-      const int idx = idx0 + e, ksl = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[s][ksl * 4 + j]), "v"(fa[s][ksl * 4 + i]));
-    }
-  };
-  unsigned long long prof_w1 = 0, prof_w2 = 0, prof_p1 = 0, prof_p23 = 0, prof_p4 = 0, prof_tb = 0;
-  auto tile_body = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
-    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    unsigned long long ts = 0;
-    if constexpr (PROF) { ts = __builtin_readcyclecounter(); W4_PIN(); }
-    // ---- P1: one read of set 1 per MFMA, 4 MFMAs of slack
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      mfma_run(0, g, 1);
-      W4_PIN();
-      read_frag(t, 1, g);
-      W4_PIN();
-    }
-    mfma_run(0, 16, 4);
-    W4_PIN();
-    if constexpr (has_next2) {
-      unsigned long long ta = 0;
-      if constexpr (PROF) { ta = __builtin_readcyclecounter(); W4_PIN(); prof_p1 += ta - ts; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
-      W4_PIN();
-      if constexpr (PROF) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
-    }
-    // ---- P2/P3: MFMAs 20..49, one DMA piece of tile t+2 per 2 MFMAs (13 pieces)
-#pragma unroll
-    for (int m = 0; m < 30; ++m) {
-      const int gi = 20 + m;
-      mfma_run(gi >> 5, gi & 31, 1);
-      if ((m + 1) % 2 == 0 && (m + 1) / 2 <= 13) {
-        W4_PIN();
-        if constexpr (has_next2) issue_piece(t + 2, (m + 1) / 2 - 1);
-        W4_PIN();
-      }
-    }
-    W4_PIN();
-    if constexpr (has_next) {
-      unsigned long long tc = 0;
-      if constexpr (PROF) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) prof_p23 += tc - prof_tb; }
-      if constexpr (has_next2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
-      if constexpr (PROF) { W4_PIN(); prof_tb = __builtin_readcyclecounter(); prof_w2 += prof_tb - tc; }
-    }
-    W4_PIN();
-    // ---- P4: MFMAs 50..63 (set 1, idx 18..31), the 16 reads of set 0 of tile t+1, the last 3 pieces
-#pragma unroll
-    for (int g = 0; g < 14; ++g) {
-      mfma_run(1, 18 + g, 1);
-      W4_PIN();
-      if constexpr (has_next) {
-        read_frag(t + 1, 0, g);
-        if (g < 2) { W4_PIN(); read_frag(t + 1, 0, 14 + g); }
-      }
-      if constexpr (has_next2) { if (g == 4 || g == 8 || g == 12) { W4_PIN(); issue_piece(t + 2, 13 + (g - 4) / 4); } }
-      W4_PIN();
-    }
-    if constexpr (PROF && has_next) { prof_p4 += __builtin_readcyclecounter() - prof_tb; W4_PIN(); }
-  };
-  using T_ = std::true_type; using F_ = std::false_type;
-
-#pragma unroll
-  for (int q = 0; q < 16; ++q) issue_piece(0, q);
-  if (nt > 1) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) issue_piece(1, q);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  W4_PIN();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
-  W4_PIN();
-  {
-    unsigned long long pt0 = 0, pr0 = 0;
-    if constexpr (PROF) { pt0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
-    int t = 0;
-    for (; t + 2 < nt; ++t) tile_body(t, T_{}, T_{});
-    if (t + 1 < nt) { tile_body(t, T_{}, F_{}); ++t; }
-    tile_body(t, F_{}, F_{});
-    if constexpr (PROF) {
-      const unsigned long long pt1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
-        unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
-        o[0] = pt1 - pt0; o[1] = prof_w1; o[2] = prof_w2; o[3] = pr1 - pr0; o[4] = (unsigned long long)nt;
-        o[5] = 0; o[6] = 0; o[7] = pr0; o[8] = pr1; o[9] = blockIdx.x;
-        o[10] = prof_p1; o[11] = prof_p23; o[12] = prof_p4;
-      }
-    }
-  }
-#undef W4_PIN
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA (16 passes) -> VALU readers
-  // row-contiguous epilogue through the dead stages (see gemm_nt_w4_kernel): 64 rows x 128 fp32 columns per wave and pass
-  __builtin_amdgcn_s_barrier();
-  char* stg = smem + wave * 32768;
-  const int ncol0 = n0 + wc * 128;
-  auto half = [&](auto HF, auto MD_) {
-    constexpr int hf = decltype(HF)::value, md = decltype(MD_)::value;
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x16_t a = acc[hf * 2 + i2][j];
-          float v[4] = {a[q * 4 + 0], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
-          const int c = j * 8 + q * 2 + fhalf;
-          epi_pre4<md>(p, ncol0 + c * 4, v);
-          *(float4*)(stg + (i2 * 32 + frow) * 512 + ((c ^ frow) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int mbase = m0 + wr * 128 + hf * 64;
-    if (p.out_f32) {
-#pragma unroll 4
-      for (int ps = 0; ps < 32; ++ps) {
-        const int row = ps * 2 + (lane >> 5), c = lane & 31, m = mbase + row, n = ncol0 + c * 4;
-        float4 v = *(const float4*)(stg + row * 512 + ((c ^ (row & 31)) << 4));
-        if (m < p.M) {
-          if (p.R) {
-            if (p.r_f32) {
-              const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
-              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-            } else {
-              const uint2 r = *(const uint2*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
-              v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
-              v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
-            }
-          }
-          *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int ps = 0; ps < 16; ++ps) {
-        const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mbase + row, n = ncol0 + g * 8;
-        const float4 lo = *(const float4*)(stg + row * 512 + (((2 * g) ^ (row & 31)) << 4));
-        const float4 hi = *(const float4*)(stg + row * 512 + (((2 * g + 1) ^ (row & 31)) << 4));
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (m < p.M) {
-          if (p.R) {
-            if (p.r_f32) {
-              const float4 r0 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
-              const float4 r1 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n + 4);
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-            } else {
-              const uint4 r = *(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n);
-              v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-              v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-              v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xffff0000u);
-              v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xffff0000u);
-            }
-          }
-          uint4 o;
-          o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-          *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-        }
-      }
-    }
-    if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  epi_dispatch_plain(p, [&](auto MD_) {
-    half(std::integral_constant<int, 0>{}, MD_);
-    half(std::integral_constant<int, 1>{}, MD_);
-  });
-}
-
-// ------------------------------------------------------------------------------------------
 // gemm_nt "p8" kernel: the 256x256 / BK 64 / 8-wave (2x4, 128x64 per wave) geometry of the ping-pong kernel with FOUR
 // phases per K-tile instead of one.  A phase = read block (the ds_read_b128 of one 64x32 quadrant of the wave's C block,
 // TWO LDS-DMA pieces, a counted s_waitcnt vmcnt) | barrier | 16 MFMAs under s_setprio 1 | barrier.  The wave groups
@@ -1868,111 +1403,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 // MEASURED (M = 32362, one decoder layer's 8 wgrads): 2.60 ms vs 2.37 ms with the 128x128 kernel — the re-reads hit the L2 /
 // Infinity Cache (the slices of one row block run concurrently), and at ~250 VGPRs the wide kernel hides less latency:
 // dA(down) 0.32 vs 0.38 ms, but dB(*) 0.18-0.78 vs 0.13-0.71 ms.  Kept behind set_flags(use_tr bit 2), off by default.
-template <int ROWB>
-__device__ __forceinline__ const char* tn2_at(const char* tile, int row, int col) {
-  const int b = col * 2;
-  return tile + row * ROWB + ((((b >> 4) ^ ((row & 7) << 1))) << 4) + (b & 15);
-}
-template <bool TR, int ROWB>
-__device__ __forceinline__ bf16x8_t tn2_frag(const char* tile, int k0, int c0, int lane) {
-  union { bf16x8_t v; s16x4_t h[2]; uint16_t s[8]; } u;
-  const int g = lane >> 4, c = lane & 15;
-  if constexpr (TR) {
-    const int col = c0 + (c & 3) * 4;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn2_at<ROWB>(tile, k0 + g * 8 + (c >> 2), col)));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, tn2_at<ROWB>(tile, k0 + g * 8 + 4 + (c >> 2), col)));
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) u.s[j] = *(const uint16_t*)tn2_at<ROWB>(tile, k0 + g * 8 + j, c0 + c);
-  }
-  return u.v;
-}
-
-template <bool TR, int BN1, int BN2>
-__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmTNArgs p) {
-  constexpr int RB1 = BN1 * 2, RB2 = BN2 * 2;                       // LDS row bytes of the P / Q tile
-  constexpr int NP = (TK * BN1 * 2) / (256 * 16), NQ = (TK * BN2 * 2) / (256 * 16);   // 16-B pieces per thread and stage
-  constexpr int F1 = BN1 / 32, F2 = BN2 / 32;                       // 16-wide fragments per wave (2x2 waves)
-  __shared__ __attribute__((aligned(16))) char smem[TK * (RB1 + RB2)];
-  char* Ps = smem;
-  char* Qs = smem + TK * RB1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n2 = p.N2 / BN2;
-  const int t1 = blockIdx.x / tiles_n2, t2 = blockIdx.x % tiles_n2;
-  const int n1_0 = t1 * BN1, n2_0 = t2 * BN2;
-  const int chunk = (((p.M + gridDim.y - 1) / gridDim.y) + TK - 1) / TK * TK;
-  const int m_begin = blockIdx.y * chunk;
-  const int m_end = min(p.M, m_begin + chunk);
-  if (m_begin >= m_end) return;
-
-  const bf16_t* Q = p.Q + n2_0;
-  if (p.q_group_n1 > 0) Q += (size_t)(n1_0 / p.q_group_n1) * p.q_group_stride;
-  const bf16_t* P = p.P + n1_0;
-  // extents end at row m_end: later rows (they belong to the next split) read as zero
-  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, (int)((unsigned)m_end * (unsigned)p.ldp * 2u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, (int)((unsigned)m_end * (unsigned)p.ldq * 2u), 0x00020000);
-  constexpr int CP = BN1 / 8, CQ = BN2 / 8;                         // 16-B chunks per row
-  const unsigned pv_off = (unsigned)((tid / CP) * p.ldp + (tid % CP) * 8) * 2u, pv_step = (unsigned)((256 / CP) * p.ldp) * 2u;
-  const unsigned qv_off = (unsigned)((tid / CQ) * p.ldq + (tid % CQ) * 8) * 2u, qv_step = (unsigned)((256 / CQ) * p.ldq) * 2u;
-
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x4_t acc[F1][F2];
-#pragma unroll
-  for (int i = 0; i < F1; ++i)
-#pragma unroll
-    for (int j = 0; j < F2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  u32x4_t pv[NP], qv[NQ];
-  auto fetch = [&](int mb) {
-    const unsigned pb = (unsigned)mb * (unsigned)p.ldp * 2u, qb = (unsigned)mb * (unsigned)p.ldq * 2u;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rP, pv_off, pb + i * pv_step, 0);
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) qv[i] = __builtin_amdgcn_raw_buffer_load_b128(rQ, qv_off, qb + i * qv_step, 0);
-  };
-  fetch(m_begin);
-  for (int mb = m_begin; mb < m_end; mb += TK) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int row = tid / CP + i * (256 / CP), c16 = tid % CP;
-      *(u32x4_t*)(Ps + row * RB1 + ((c16 ^ ((row & 7) << 1)) << 4)) = pv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int row = tid / CQ + i * (256 / CQ), c16 = tid % CQ;
-      *(u32x4_t*)(Qs + row * RB2 + ((c16 ^ ((row & 7) << 1)) << 4)) = qv[i];
-    }
-    __syncthreads();
-    if (mb + TK < m_end) fetch(mb + TK);
-#pragma unroll
-    for (int kk = 0; kk < TK / 32; ++kk) {
-      bf16x8_t pf[F1], qf[F2];
-#pragma unroll
-      for (int i = 0; i < F1; ++i) pf[i] = tn2_frag<TR, RB1>(Ps, kk * 32, wm * (BN1 / 2) + i * 16, lane);
-#pragma unroll
-      for (int j = 0; j < F2; ++j) qf[j] = tn2_frag<TR, RB2>(Qs, kk * 32, wn * (BN2 / 2) + j * 16, lane);
-#pragma unroll
-      for (int i = 0; i < F1; ++i)
-#pragma unroll
-        for (int j = 0; j < F2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < F1; ++i)
-#pragma unroll
-    for (int j = 0; j < F2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n1 = n1_0 + wm * (BN1 / 2) + i * 16 + g * 4 + q;
-        const int n2 = n2_0 + wn * (BN2 / 2) + j * 16 + c;
-        atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[i][j][q] * p.alpha);
-      }
-}
-
 }  // namespace
 
 namespace {
@@ -2213,15 +1643,13 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
 }  // namespace
 
 static bool g_skinny8 = true;       // M <= 16 decode GEMMs: whole-cache-line form of the streaming kernel
-static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 8: 8-wave ping-pong; 15: M <= 64 streaming; 16/23/24/27/28/29/30/31: w4 family; 17: 8-wave 4-phase
+static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 8-wave 256x256 kernel (p8); 31: 4-wave 256x256 kernel (w4) forced; 15: M <= 64 streaming
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
-static int g_tn_wide = 0;      // use_tr bit 2 set: wide (256 x 128 / 128 x 256) gemm_tn tiles — measured slower overall, see gemm_tn2_kernel
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
   opadpo_set_attn_dma((use_tr & 2) != 0);
-  g_tn_wide = (use_tr & 4) != 0;
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
 }
@@ -2242,17 +1670,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-#define PP_ATTR(...) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE)
-    PP_ATTR(false);
-#undef PP_ATTR
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4m_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
@@ -2317,90 +1735,23 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
 #undef SK
     return hipGetLastError();
   }
-  // variant 10 (default, "auto"): the 256x256 ping-pong kernel when it yields at least ~1.5 rounds of blocks on the
-  // 256 CUs, the 128x128 kernel otherwise (skinny LoRA GEMMs, N not a multiple of 256).
+  // variant 10 (default, "auto"): a 256x256 kernel when it yields at least ~1.25 rounds of blocks on the 256 CUs (or fills its
+  // last round), the 128x128 kernel otherwise (skinny LoRA GEMMs, N not a multiple of 256).
   const bool off32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));   // buffer offsets are 32-bit
   const int pp_tiles = (a.N % P_BN == 0 && off32) ? ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN) : 0;
   // one 256x256 block per CU and round: below 1.25 rounds the big tile only pays when its last round fills the chip
   // (M = 32362: N = 512 -> 254 blocks, w4 1.10-1.18 PF/s vs 0.75-0.79 for the 128x128 kernel; N = 768 -> 381 blocks = 1.49
   // rounds, w4 1.10 vs 0.84; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
-  const bool plain = !a.bias && !a.act;                 // the w4 kernels are instantiated for alpha-only epilogues
-  if (!plain && pp_tiles > 0 && (g_gemm_variant == 10 ? pp_tiles >= 320 : (g_gemm_variant == 16 || (g_gemm_variant >= 18 && g_gemm_variant <= 31 && g_gemm_variant != 17)))) {
-    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
+  const bool plain = !a.bias && !a.act;                 // the 4-wave kernel is instantiated for alpha-only epilogues
   const int pp_slots = ((pp_tiles + 255) / 256) * 256;
-  const bool auto_pp = g_gemm_variant == 10 && plain && (pp_tiles >= 320 || (pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88));
-  if (g_gemm_variant == 17 && pp_tiles > 0) {
-    hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if ((g_gemm_variant == 27 || g_gemm_variant == 30) && pp_tiles > 0) {      // diagnostic: stamped schedule (27: w4, 30: w4m), summary on stderr (synchronous)
-    if (g_gemm_variant == 27) {
-      if (const char* e = getenv("OPADPO_W4_DIAG")) a.act |= atoi(e) << 9;
-      hipLaunchKernelGGL(gemm_nt_w4_kernel<10>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    } else {
-      hipLaunchKernelGGL(gemm_nt_w4m_kernel<true>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    }
-    if (hipStreamSynchronize(st) != hipSuccess) return hipGetLastError();
-    const int nw = (pp_tiles < W4_PROF_MAX_WG ? pp_tiles : W4_PROF_MAX_WG) * 4;
-    constexpr int PN = W4_PROF_N;
-    std::vector<unsigned long long> h((size_t)nw * PN);
-    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w4_prof), h.size() * 8) != hipSuccess) return hipGetLastError();
-    double cyc = 0, w1 = 0, w2 = 0, rt = 0, tiles = 0, pro = 0, epi = 0, life = 0, p1 = 0, p23 = 0, p4 = 0;
-    for (int i = 0; i < nw; ++i) {
-      cyc += h[i * PN]; w1 += h[i * PN + 1]; w2 += h[i * PN + 2]; rt += h[i * PN + 3]; tiles += h[i * PN + 4];
-      pro += h[i * PN + 5]; epi += h[i * PN + 6]; p1 += h[i * PN + 10]; p23 += h[i * PN + 11]; p4 += h[i * PN + 12]; life += (double)(h[i * PN + 8] - h[i * PN + 7]);
-    }
-    // gaps between consecutive workgroups on the same CU (wave 0 records; 100-MHz ticks)
-    std::vector<std::array<unsigned long long, 3>> wg;      // {cu key, start, end}
-    for (int i = 0; i < nw; i += 4) wg.push_back({h[i * PN + 9], h[i * PN + 7], h[i * PN + 8]});
-    std::sort(wg.begin(), wg.end());
-    double gap = 0; int ngap = 0, ncu = 0;
-    unsigned long long t_first = ~0ull, t_last = 0;
-    for (size_t i = 0; i < wg.size(); ++i) {
-      if (i == 0 || wg[i][0] != wg[i - 1][0]) ++ncu;
-      else { gap += (double)wg[i][1] - (double)wg[i - 1][2]; ++ngap; }
-      t_first = std::min(t_first, wg[i][1]); t_last = std::max(t_last, wg[i][2]);
-    }
-    const double mhz = cyc / rt * 100.0;
-    fprintf(stderr, "[w4 prof] M=%d N=%d K=%d blocks=%d on %d CUs, clock %.0f MHz | per K-tile %.0f cycles (MFMA floor 2048), wait1 %.0f, wait2 %.0f; P1 (40 MFMA + 16 LDS reads) %.0f, P2+P3 (60 MFMA + 13 DMA) %.0f, P4 (28 MFMA + 16 reads + 3 DMA) %.0f"
-            " | per block: prologue %.2f us, K-loop %.2f us, epilogue %.2f us, lifetime %.2f us, gap to next block on the CU %.2f us | span %.1f us\n",
-            a.M, a.N, a.K1 + a.K2, nw / 4, ncu, mhz, cyc / tiles, w1 / tiles, w2 / tiles, p1 / tiles, p23 / tiles, p4 / tiles, pro / nw / mhz, cyc / nw / mhz, epi / nw / mhz,
-            life / nw / 100.0, ngap ? gap / ngap / 100.0 : 0.0, (double)(t_last - t_first) / 100.0);
-    return hipSuccess;
-  }
-  if (g_gemm_variant == 31 && pp_tiles > 0) {      // long-lead w4 with M0 written one MFMA ahead of each DMA
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 29 && pp_tiles > 0) {      // w4 geometry, 32x32x16 MFMA
-    hipLaunchKernelGGL(gemm_nt_w4m_kernel<false>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 28 && pp_tiles > 0) {      // register-staged operands, one barrier per K-tile
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<11>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 23 && pp_tiles > 0) {
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<6>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 24 && pp_tiles > 0) {      // long-lead schedule without the MFMA between s_waitcnt and s_barrier (A/B)
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<7>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 16 && pp_tiles > 0) {
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<0>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (auto_pp && pp_tiles > 0) {      // default for large GEMMs: 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-    return hipGetLastError();
-  }
-  if (g_gemm_variant == 8 && pp_tiles > 0) {      // 8-wave ping-pong kernel
-    hipLaunchKernelGGL(gemm_nt_pp_kernel<false>, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
+  const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 ||
+                   (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
+  if (big && pp_tiles > 0) {
+    if (plain && g_gemm_variant != 17)      // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
+      hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+    else                                    // bias / activation epilogues (vision tower, projector): 8 waves x 128x64, 4 phases per K-tile
+      hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   const int tiles_x = ((a.M + BM - 1) / BM) * (a.N / BN);      // everything else (and variant 4): the 128x128 kernel
@@ -2411,27 +1762,13 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (a.N1 % 128 || a.N2 % 128) return hipErrorInvalidValue;
-  const bool g_use_tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : ::g_use_tr;       // per-call override (opadpo_ctx_set_flags)
-  // wide tiles: span 256 of the SMALL dimension so that the big operand is read once (twice / three times for 2r / 3r)
+  const bool use_tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : g_use_tr;       // per-call override (opadpo_ctx_set_flags)
+  const bool tn_w4 = a.use_tr >= 0 ? (a.use_tr & 8) == 0 : g_tn_w4 != 0;
   const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
-  int bn1 = 128, bn2 = 128;
-  if (g_tn_wide && off32 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
-    if (a.N2 % 256 == 0 && a.N2 <= a.N1) bn2 = 256;
-    else if (a.N1 % 256 == 0 && a.N1 < a.N2) bn1 = 256;
-  }
-  const int tiles = (a.N1 / bn1) * (a.N2 / bn2);
-  int splits = a.splits;
-  if (splits <= 0) {
-    splits = (1024 + tiles - 1) / tiles;
-    const int max_splits = (a.M + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-  }
-  if (g_tn_w4 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
+  if (tn_w4 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
       attr = true;
     }
     GemmTNArgs b = a;
@@ -2440,38 +1777,19 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
     if (b.splits > ksteps) b.splits = ksteps;
     const long long total = (long long)b.splits * tiles4 * ((ksteps + b.splits - 1) / b.splits);
     const dim3 gr((unsigned)(total < 256 ? total : 256));
-    static const bool prof = getenv("OPADPO_TN_PROF") != nullptr;
-    if (!prof) {
-      hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, b);
-      return hipGetLastError();
-    }
-    hipLaunchKernelGGL(gemm_tn_w4_kernel<true>, gr, dim3(256), 2 * P_STAGE, st, b);      // diagnostic: stamps, summary on stderr
-    if (hipStreamSynchronize(st) != hipSuccess) return hipGetLastError();
-    const int nw = (int)gr.x * 4;
-    std::vector<unsigned long long> h((size_t)nw * W4_PROF_N);
-    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w4_prof), h.size() * 8) != hipSuccess) return hipGetLastError();
-    double cyc = 0, w1 = 0, w2 = 0, rt = 0, nts = 0, epi = 0, p1 = 0, p23 = 0, p4 = 0;
-    for (int i = 0; i < nw; ++i) {
-      const unsigned long long* o = h.data() + (size_t)i * W4_PROF_N;
-      cyc += o[0]; w1 += o[1]; w2 += o[2]; rt += o[3]; nts += o[4]; epi += o[6]; p1 += o[10]; p23 += o[11]; p4 += o[12];
-    }
-    const double mhz = cyc / rt * 100.0;
-    fprintf(stderr, "[tn w4 prof] M=%d N1=%d N2=%d blocks=%d splits=%d clock %.0f MHz | per K-step %.0f cycles (MFMA floor 2048): P1 %.0f wait1 %.0f "
-            "P2+P3 %.0f wait2 %.0f P4 %.0f | per block: K-loops %.1f us, flush (atomics) %.1f us\n", a.M, a.N1, a.N2, (int)gr.x, b.splits, mhz,
-            cyc / nts, p1 / nts, w1 / nts, p23 / nts, w2 / nts, p4 / nts, cyc / nw / mhz, epi / nw / mhz);
-    return hipSuccess;
+    hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, b);
+    return hipGetLastError();
+  }
+  const int tiles = (a.N1 / 128) * (a.N2 / 128);
+  int splits = a.splits;
+  if (splits <= 0) {
+    splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (a.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
   }
   const dim3 grid(tiles, splits);
-  if (bn2 == 256) {
-    if (g_use_tr) hipLaunchKernelGGL((gemm_tn2_kernel<true, 128, 256>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_tn2_kernel<false, 128, 256>), grid, dim3(256), 0, st, a);
-  } else if (bn1 == 256) {
-    if (g_use_tr) hipLaunchKernelGGL((gemm_tn2_kernel<true, 256, 128>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_tn2_kernel<false, 256, 128>), grid, dim3(256), 0, st, a);
-  } else if (g_use_tr) {
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
-  }
+  if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }

@@ -36,6 +36,14 @@ def truncate_after_eos_with_padding(completions: torch.Tensor, eos_token_id: int
     return torch.tensor(rows, dtype=torch.long, device=completions.device)
 
 
+class _WeightsOnlyAdapter:
+    """A 'merged adapter' that only carries re-laid-out base weights (the SwiGLU-pair copy of gate|up): nothing trainable, no LoRA."""
+    trainable = False
+
+    def __init__(self, merged):
+        self.merged = merged
+
+
 class Generator:
     def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True, merge_adapter: bool = False,
                  fuse_swiglu: bool = False):
@@ -53,7 +61,7 @@ class Generator:
             F, H = d.ffn, d.hidden
             sw = [{"wgu_sw": torch.stack([w["wgu"][:F].view(F // 64, 64, H), w["wgu"][F:].view(F // 64, 64, H)], dim=1)
                    .reshape(2 * F, H).contiguous()} for w in engine.base.layers]
-            self.adapter = types.SimpleNamespace(merged=sw, trainable=False)
+            self.adapter = _WeightsOnlyAdapter(sw)
 
     @torch.no_grad()
     def generate(self, queries: torch.Tensor, query_attn_masks: torch.Tensor, images: Optional[torch.Tensor] = None, *,

@@ -127,15 +127,13 @@ def load() -> C.CDLL:
 
 
 def set_flags(use_glds=10, use_tr: bool = True) -> None:
-    """gemm_nt variant: 10 (default) auto = 4-wave 256x256 long-lead kernel (w4<12>) from 320 blocks or when one round fills
-    >= 88 % of the CUs, 128x128 kernel otherwise (bias / activation problems: 8-wave kernel from 320 blocks);
-    4 the 128x128 kernel everywhere, 8 the 8-wave ping-pong kernel, 15 force the M <= 64 streaming kernel,
-    16 w4 single-barrier schedule, 17 8-wave 4-phase kernel (p8), 23 / 24 long lead with the builtin DMA (with / without an MFMA
-    between wait and barrier), 27 stamped diagnostic (summary on stderr, synchronous), 28 register-staged operands,
-    29 32x32x16 MFMA, 31 = the default large-GEMM kernel forced.  True -> default.
-    use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V ring
-    (default: register-staged single buffer, 3 blocks per CU), bit 2 = wide gemm_tn tiles, bit 3 = 128x128 gemm_tn kernel
-    instead of the default 256x256 gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel)."""
+    """Process-default kernel variants for the op-level entry points (a context carries its own: opadpo_ctx_set_flags).
+    gemm_nt: 10 (default) auto = 4-wave 256x256 long-lead kernel (w4) from 320 blocks or when one round fills >= 88 % of the CUs,
+    128x128 kernel otherwise (bias / activation problems: 8-wave kernel from 320 blocks); 4 the 128x128 kernel everywhere,
+    17 the 8-wave 4-phase 256x256 kernel (p8), 31 the 4-wave kernel forced, 15 force the M <= 64 streaming kernel.  True -> default.
+    use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V
+    ring (default: register-staged single buffer, 3 blocks per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256
+    gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel)."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 

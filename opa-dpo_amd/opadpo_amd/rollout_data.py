@@ -82,6 +82,63 @@ def tokenize_with_image(prompt: str, tokenizer, image_token_index: int = IMAGE_T
     return ids
 
 
+IGNORE_INDEX = -100      # utils/constants.py
+
+
+def preprocess_v1(sources: Sequence[Sequence[dict]], tokenizer, has_image: bool = False, mask_target: bool = True,
+                  query_len: Optional[int] = None, response_len: Optional[int] = None) -> Dict:
+    """`preprocess_v1` of utils/common_utils.py:336-475 (the SFT data path: data_utils_sft.py:187-214 calls it per (query, response)
+    sample with mask_target=True; the rollout path with mask_target=False): conversations -> Vicuna-v1 prompt -> ids; labels = ids with,
+    when `mask_target`, BOS, every instruction part (`... ASSISTANT: `, counted as its token count - 2) and everything after the last
+    round set to IGNORE_INDEX; a sample whose round lengths do not add up to its token count is ignored entirely (all labels
+    IGNORE_INDEX, the reference prints a warning).  `validity[c]` = the LAST round fits query_len / response_len.
+    -> {input_ids [n, width], labels [n, width], validity [n]} (has_image: all prompts must tokenise to the same length, like the
+    reference's torch.stack; otherwise right-padded to the longest)."""
+    convs = [render_prompt(src) for src in sources]
+    if has_image:
+        rows = [tokenize_with_image(c, tokenizer) for c in convs]
+        if len({len(r) for r in rows}) != 1:
+            raise RuntimeError("stack expects each tensor to be equal size (has_image=True tokenises without padding)")
+        input_ids = torch.tensor(rows, dtype=torch.long)
+    else:
+        rows = [torch.as_tensor(tokenizer(c)["input_ids"]).view(-1).tolist() for c in convs]
+        width = min(max(len(r) for r in rows), getattr(tokenizer, "model_max_length", 1 << 30))
+        input_ids = torch.tensor([(r[:width] + [tokenizer.pad_token_id] * (width - len(r[:width]))) for r in rows], dtype=torch.long)
+    targets = input_ids.clone()
+    validity = [True] * len(convs)
+    sep = SEP + ROLES[1] + ": "
+    n_tok = (lambda t: len(tokenize_with_image(t, tokenizer))) if has_image else (lambda t: len(torch.as_tensor(tokenizer(t)["input_ids"]).view(-1)))
+    for c, (conversation, target) in enumerate(zip(convs, targets)):
+        total_len = int(target.ne(tokenizer.pad_token_id).sum())
+        cur_len = 1
+        if mask_target:
+            target[:cur_len] = IGNORE_INDEX
+        final_query_len = final_response_len = 0
+        for rou in conversation.split(SEP2):
+            if rou == "":
+                break
+            parts = rou.split(sep)
+            if len(parts) != 2:
+                break
+            parts[0] += sep
+            round_len = n_tok(rou)
+            instruction_len = n_tok(parts[0]) - 2
+            if mask_target:
+                target[cur_len: cur_len + instruction_len] = IGNORE_INDEX
+            final_query_len, final_response_len = cur_len, round_len
+            cur_len += round_len
+        if final_response_len == 0:
+            raise ValueError(f"Empty response: {conversation}")
+        validity[c] = (query_len is None or final_query_len <= query_len) and (response_len is None or final_response_len <= response_len)
+        if mask_target:
+            target[cur_len:] = IGNORE_INDEX
+        if cur_len < getattr(tokenizer, "model_max_length", 1 << 30) and cur_len != total_len:
+            if mask_target:
+                target[:] = IGNORE_INDEX
+            print(f"WARNING: tokenization mismatch: {cur_len} vs. {total_len}. (ignored)")
+    return dict(input_ids=input_ids, labels=targets, validity=validity)
+
+
 def build_query_ids(question: str, answer: str, tokenizer) -> torch.Tensor:
     """Prompt tokens of one row: answer turn blanked to a newline, templated, tokenised, last three tokens dropped."""
     conv = move_image_placeholder_first(form_conversation(question, answer))

@@ -41,7 +41,7 @@ def maxabs(got, want):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("glds", [31, 29, 28, 24, 23, 17, 16, 10, 8, 4])
+@pytest.mark.parametrize("glds", [31, 17, 10, 4])
 @pytest.mark.parametrize("M,N,K1,K2,groups", [(300, 256, 128, 0, 0), (1, 128, 64, 0, 0), (129, 384, 192, 128, 3),
                                               (1000, 1024, 512, 128, 2), (257, 128, 64, 64, 1), (515, 768, 64, 64, 3),
                                               (2, 256, 4096, 0, 0), (131, 512, 64 * 3, 64, 2), (700, 512, 64, 0, 0), (513, 256, 128, 128, 1)])
@@ -143,7 +143,7 @@ def test_gemm_nt_decode_strided_operands(L, M):
     assert float((Ob[M].float() - 3.0).abs().max()) == 0.0 and float((Ob[:M, :8].float() - 3.0).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", [10, 23, 17])
+@pytest.mark.parametrize("variant", [10, 31, 17])
 def test_gemm_nt_epilogue_large(L, variant):
     """Epilogues at a size the auto dispatch sends to the 256x256 kernels (>= 320 blocks, ragged M edge): the 4-wave kernel's
     row-contiguous staged paths (bf16 one pass; fp32 two passes with fp32 / bf16 residual, alpha != 1) and the routing of
@@ -172,15 +172,15 @@ def test_gemm_nt_epilogue_large(L, variant):
 
 
 def test_gemm_nt_256_kernels_race_screen(L):
-    """The three 256x256 kernels (ping-pong 8, 4-wave 16, 4-phase 17 = default for large GEMMs) accumulate every output in
-    the same k order, so their results must be BIT-identical; repeated on a shape with many K-tiles, a LoRA tail, a ragged M
+    """The two 256x256 kernels (4-wave long-lead w4 = 31 / default for large GEMMs, 8-wave 4-phase p8 = 17) accumulate every
+    output in the same k order, so their results must be BIT-identical; repeated on a shape with many K-tiles, a LoRA tail, a ragged M
     edge and more blocks than CUs, any LDS-DMA / barrier race in a schedule shows up as a differing tile."""
     M, N, K1, K2 = 3000, 5120, 4096, 256
     a1, b1 = rnd(M, K1, seed=11), rnd(N, K1, scale=0.05, seed=12)
     a2, b2 = rnd(M, K2, seed=13), rnd(N, K2, scale=0.05, seed=14)
     outs = {}
     for rep in range(6):
-        for v in (8, 16, 17, 23, 28, 29, 31, 10):
+        for v in (17, 31, 10):
             L.set_flags(v, True)
             o = torch.empty(M, N, dtype=BF, device=dev())
             L.gemm_nt(a1, b1, o, a2=a2, b2=b2)
@@ -190,12 +190,12 @@ def test_gemm_nt_256_kernels_race_screen(L):
             outs[key] = o
     L.set_flags(10, True)
     torch.cuda.synchronize()
-    assert torch.equal(outs[8], outs[16]) and torch.equal(outs[8], outs[17]) and torch.equal(outs[17], outs[10]) and torch.equal(outs[8], outs[23])
+    assert torch.equal(outs[31], outs[17]) and torch.equal(outs[17], outs[10])
     want = a1.float() @ b1.float().t() + a2.float() @ b2.float().t()
     assert relerr(outs[17], want) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [4, 8, 16, 17, 23, 10])
+@pytest.mark.parametrize("variant", [4, 17, 31, 10])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):
     L.set_flags(variant, True)
@@ -226,7 +226,7 @@ def test_gemm_nt_epilogue(L, act, variant):
     assert float(outw[:, :N].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("variant", [4, 8, 16, 17])
+@pytest.mark.parametrize("variant", [4, 17, 31])
 def test_gemm_nt_grouped_a1(L, variant):
     """block-diagonal dT_g = dY_g . B_g for fused projections in one launch (a1 groups)."""
     L.set_flags(variant, True)

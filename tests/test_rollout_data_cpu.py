@@ -150,3 +150,27 @@ def test_eval_prompt_and_question_chunks():
     assert sum((eg.question_chunk(qs, 4, k) for k in range(4)), []) == qs
     with pytest.raises(IndexError):
         eg.question_chunk(list(range(4)), 3, 2)          # ceil(4/3) = 2 -> only two chunks exist
+
+
+def test_preprocess_v1_label_masking_against_the_reference(golden_dir):
+    """rollout_data.preprocess_v1 vs the reference's own preprocess_v1 (utils/common_utils.py:336-475; SFT data path with
+    mask_target=True, data_utils_sft.py:187-214), run on the same conversations in the build container
+    (tests/golden/make_preprocess_golden.py: template / image tokenisation stubbed with this build's restatements)."""
+    import json
+    import os
+    from opadpo_amd.rollout_data import preprocess_v1
+    from toy_tokenizer import EosAwareTokenizer
+    cases = json.load(open(os.path.join(golden_dir, "ref_preprocess_v1.json")))
+    assert len(cases) == 18
+    seen_masked = seen_ignored = 0
+    for c in cases:
+        out = preprocess_v1(c["sources"], EosAwareTokenizer(), has_image=c["has_image"], mask_target=c["mask_target"],
+                            query_len=c["query_len"], response_len=c["response_len"])
+        assert out["input_ids"].tolist() == c["input_ids"], c["name"]
+        assert out["labels"].tolist() == c["labels"], (c["name"], c["mask_target"])
+        assert [bool(v) for v in out["validity"]] == c["validity"], (c["name"], c["query_len"])
+        if c["mask_target"]:
+            lab = out["labels"]
+            seen_masked += int(((lab == -100).any(1) & (lab != -100).any(1)).sum())
+            seen_ignored += int((lab == -100).all(1).sum())
+    assert seen_masked > 0, "the fixture must contain rows with instruction tokens masked and response tokens kept"

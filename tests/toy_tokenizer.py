@@ -67,3 +67,29 @@ def collator_instances():
         {"queries": "USER: 图 count the animals ASSISTANT:", "images": img + 1, "standard_response": "one dog",
          "original_generate_response": "two dogs", "AI_pseudo_response": "one dog runs", "AI_json_report": json.dumps(rep2)},
     ]
+
+
+class EosAwareTokenizer(ToyTokenizer):
+    """ToyTokenizer that, like the Llama sentencepiece model, turns the literal '</s>' into the single EOS id (also when it is glued
+    to a word) - the length bookkeeping of the reference's preprocess_v1 (round = BOS + words, closed by one '</s>' token) relies on it.
+    `tokenizer(text).input_ids` and `tokenizer(text)["input_ids"]` both work (plain Python lists for a single string)."""
+    model_max_length = 64
+
+    def _encode(self, text):
+        ids = [self.bos_token_id]
+        for w in text.replace("</s>", " </s> ").split():
+            ids.append(self.eos_token_id if w == "</s>" else super()._encode(w)[1])
+        return ids
+
+    def __call__(self, text, **kw):
+        if isinstance(text, str):
+            return _Ids(self._encode(text))
+        kw = {k: v for k, v in kw.items() if k in ("padding", "truncation", "max_length", "return_tensors")}
+        enc = super().__call__(text, **kw)
+        return _Ids(enc["input_ids"], enc["attention_mask"])
+
+
+class _Ids(dict):
+    def __init__(self, ids, mask=None):
+        super().__init__(input_ids=ids, attention_mask=mask)
+        self.input_ids, self.attention_mask = ids, mask

@@ -76,7 +76,7 @@ def main():
             a1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
             b1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
             out = torch.empty(n, n, dtype=BF, device=dev)
-            for variant in [int(v) for v in os.environ.get("GB_VARIANTS", "17,16,8,4,-1").split(",")]:
+            for variant in [int(v) for v in os.environ.get("GB_VARIANTS", "31,17,4,-1").split(",")]:
                 if variant >= 0:
                     L.set_flags(variant, True)
                     t = timeit(lambda: L.gemm_nt(a1, b1, out), iters=20, warm=5)
@@ -148,7 +148,7 @@ def main():
         torch.cuda.synchronize()
         return
     vlist = [int(v) for v in os.environ["GB_VARIANTS"].split(",")] if (only == "gemm" and os.environ.get("GB_VARIANTS")) else None
-    for glds in (vlist if vlist else ((31, 17, 8, 4) if not only else ((31, 17, 8, 4) if only == "gemm" else ((8, 17, 8, 17) if only == "pp" else ())))):
+    for glds in (vlist if vlist else ((31, 17, 4) if not only else ((31, 17, 4) if only == "gemm" else ((17, 31) if only == "pp" else ())))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
