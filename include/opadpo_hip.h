@@ -70,6 +70,20 @@ int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ld
                         uint16_t* C, int ldc, int M, int N, const float* cos_tab, const float* sin_tab, int L, int rope_cols,
                         int seg_prefix, int seg_len, void* stream);
 
+/* Decode projection for up to 64 tokens (rollout at 33..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
+ * no bias / residual / LoRA tail (adapter-free or merged adapter).  Both operands are streamed through a 4-stage LDS ring by
+ * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup.  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
+ * C[splits][M,N] (ldc = row stride of one slice) - K is split over `splits` workgroups (<= 0: chosen by the library, query it with
+ * opadpo_gemm_nt_decode_splits) and the consumer adds the slices (opadpo_rmsnorm_sum_fwd); mode 2: OPADPO_ACT_SWIGLU_PAIR weight
+ * layout -> bf16 C[M, N/2] = silu(gate) * up.  M <= 64, N % 128 == 0, K % 64 == 0. */
+int opadpo_gemm_nt_decode(const uint16_t* A, int lda, const uint16_t* B, int ldb, int K, void* C, int ldc, int mode, int M, int N, int splits,
+                          void* stream);
+int opadpo_gemm_nt_decode_splits(int N, int K, int splits);
+/* x_out = resid + sum_s partials[s] (fp32 [rows,H]; resid fp32 or bf16), y (nullable) = RMSNorm(x_out) * w in bf16, rstd (nullable):
+ * the residual add + LlamaRMSNorm behind a K-split decode projection; fixed summation order (deterministic). */
+int opadpo_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partials, int n_partials, size_t partial_stride, const uint16_t* w,
+                           float* x_out, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream);
+
 /* LoRA weight gradients: C[N1,N2] (fp32) += alpha * sum_m P[m,N1] * Q[m,N2]   (dB = dY^T t,
  * dA = dT^T x; autograd of peft lora_A / lora_B, rl_trainer.py:162).  Q column offset for output
  * row n1 is (n1 / q_group_n1) * q_group_stride.  N1 % 128 == 0, N2 % 128 == 0. splits<=0: auto. */
@@ -245,7 +259,8 @@ int opadpo_ctx_create(const opadpo_dims* dims, int device, opadpo_ctx** out);
 void opadpo_ctx_destroy(opadpo_ctx* ctx);
 const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
 int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
-/* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default */
+/* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default.  Context-only: use_tr bit 5 = keep the
+ * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);

@@ -69,6 +69,24 @@ int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ld
   return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt_rope");
 }
 
+int opadpo_gemm_nt_decode(const uint16_t* A, int lda, const uint16_t* B, int ldb, int K, void* C, int ldc, int mode, int M, int N, int splits,
+                          void* stream) {
+  if (M < 0 || M > 64) return bad("opadpo_gemm_nt_decode", "M must be 0..64 (one token per sequence)");
+  if (N <= 0 || N % 128 || K <= 0 || K % 64) return bad("opadpo_gemm_nt_decode", "N must be a multiple of 128, K of 64");
+  if (!A || !B || !C || lda % 8 || ldb % 8 || ldc % 4 || mode < 0 || mode > 2) return bad("opadpo_gemm_nt_decode", "null operand, misaligned leading dimension or bad mode");
+  GemmNTArgs a;
+  a.A1 = A; a.B1 = B; a.A2 = nullptr; a.B2 = nullptr; a.C = C; a.R = nullptr; a.bias = nullptr;
+  a.M = M; a.N = N; a.K1 = K; a.K2 = 0; a.lda1 = lda; a.ldb1 = ldb; a.lda2 = 0; a.ldb2 = 0; a.ldc = ldc; a.ldr = 0;
+  a.a2_group_n = 0; a.a2_group_stride = 0; a.a1_group_n = 0; a.a1_group_stride = 0; a.alpha = 1.f; a.act = 0; a.out_f32 = mode == 1; a.r_f32 = 0;
+  return done(launch_gemm_nt_dec64(a, mode, splits, S(stream)), "opadpo_gemm_nt_decode");
+}
+int opadpo_gemm_nt_decode_splits(int N, int K, int splits) { return (N > 0 && K >= 64) ? gemm_nt_dec64_splits(N, K, splits) : 1; }
+int opadpo_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partials, int n_partials, size_t partial_stride, const uint16_t* w,
+                           float* x_out, uint16_t* y, float* rstd, int rows, int H, float eps, void* stream) {
+  if (!resid || !w || !x_out) return bad("opadpo_rmsnorm_sum_fwd", "null operand");
+  return done(launch_rmsnorm_sum_fwd(resid, resid_f32, partials, n_partials, partial_stride, w, x_out, y, rstd, rows, H, eps, S(stream)),
+              "opadpo_rmsnorm_sum_fwd");
+}
 int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float* C, int ldc,
                    int M, int N1, int N2, int q_group_n1, int q_group_stride, float alpha, int splits,
                    void* stream) {

@@ -140,6 +140,7 @@ struct opadpo_ctx {
     int B = 0, Lp = 0, max_ctx = 0, adapter = 0, max_new = 0;
     bf16_t *kc, *vc; uint8_t* key_mask; float *x, *x2, *hs; bf16_t *hn, *n1, *qkv, *t_qkv, *att, *t_o, *n2, *t_gu, *gu, *act, *t_d, *emb;
     float *hb, *rstd, *logits; int32_t *cur_tok, *step_d, *pos_d; uint8_t* finished; void* ws; size_t ws_bytes;
+    float *part_o, *part_d; int split_o = 1, split_d = 1; bool use64 = false;      // K-split partial tiles of the 33..64-token decode GEMMs
     int32_t* history; float temperature; int top_k; float top_p; uint64_t seed; int eos_id, pad_id, suppress_eos;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t cap_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
   } dec;
@@ -763,13 +764,17 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
 }
 
 // ---- rollout: prefill + KV-cache decode (generate.py; online_generator.py:292-309) ----------------------------------------------
-static hipError_t decode_head(opadpo_ctx* c, const float* src_f32, hipStream_t st) {
+static hipError_t decode_head(opadpo_ctx* c, const float* src_f32, const float* partials, int n_partials, hipStream_t st) {
   opadpo_ctx::Decode& D = c->dec;
   const opadpo_dims& d = c->d;
   hipError_t e;
-  if ((e = launch_rmsnorm_fwd(src_f32, 1, c->norm, D.hn, D.rstd, D.B, d.hidden, d.rms_eps, st)) != hipSuccess) return e;
+  if (n_partials > 0) {
+    if ((e = launch_rmsnorm_sum_fwd(src_f32, 1, partials, n_partials, (size_t)D.B * d.hidden, c->norm, D.x2, D.hn, D.rstd, D.B, d.hidden, d.rms_eps, st)) != hipSuccess) return e;
+  } else if ((e = launch_rmsnorm_fwd(src_f32, 1, c->norm, D.hn, D.rstd, D.B, d.hidden, d.rms_eps, st)) != hipSuccess) return e;
   GemmNTArgs g = gemm(c, D.hn, d.hidden, c->lm_head, d.hidden, d.hidden, D.logits, d.vocab, 1, D.B, d.vocab); g.act |= OPADPO_GEMM_STREAM;
-  if ((e = run_gemm(c, g, st)) != hipSuccess) return e;
+  if (D.use64) e = launch_gemm_nt_dec64(g, 1, 1, st);
+  else e = run_gemm(c, g, st);
+  if (e != hipSuccess) return e;
   if (D.suppress_eos) {
     hipLaunchKernelGGL(set_column_f32_kernel, g1(D.B), dim3(256), 0, st, D.logits, d.vocab, D.B, D.eos_id, -INFINITY);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -791,6 +796,37 @@ static hipError_t decode_one(opadpo_ctx* c, hipStream_t st) {
   hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(64), 0, st, D.pos_d, 1);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = launch_gather_rows(c->embed, H, D.cur_tok, D.emb, B, H, st)) != hipSuccess) return e;
+  if (D.use64) {
+    // 33..64 tokens: LDS-ring decode GEMMs; x / hb = fp32 residual stream, part_o / part_d = K-slice partial tiles of the o / down
+    // projections, added (in slice order) by the RMSNorm that follows them
+    const int F = d.ffn;
+    const size_t pstride = (size_t)B * H;
+    auto dg = [&](const bf16_t* A, int lda, const bf16_t* W, int K, void* C, int ldc, int N, int mode, int splits) {
+      GemmNTArgs g = gemm(c, A, lda, W, K, K, C, ldc, mode == 1, B, N);
+      return launch_gemm_nt_dec64(g, mode, splits, st);
+    };
+    for (int i = 0; i < d.n_layers; ++i) {
+      const opadpo_layer_weights& w0 = c->layers[i];
+      const opadpo_layer_weights& w = ad.kind == 2 ? ad.merged[i] : w0;
+      if (i == 0) e = launch_rmsnorm_sum_fwd(D.emb, 0, nullptr, 0, 0, w0.ln1, D.x, D.n1, D.rstd, B, H, d.rms_eps, st);
+      else e = launch_rmsnorm_sum_fwd(D.hb, 1, D.part_d, D.split_d, pstride, w0.ln1, D.x, D.n1, D.rstd, B, H, d.rms_eps, st);
+      if (e != hipSuccess) return e;
+      if ((e = dg(D.n1, H, w.wqkv, H, D.qkv, 3 * H, 3 * H, 0, 1)) != hipSuccess) return e;
+      const size_t per_layer = (size_t)B * nh * D.max_ctx * hd;
+      if ((e = launch_attn_decode_fused(D.qkv, 3 * H, c->cosb, c->sinb, D.kc + i * per_layer, D.vc + i * per_layer, D.att, D.key_mask, B, nh, hd, D.pos_d,
+                                        D.max_ctx, 1.0f / sqrtf((float)hd), D.ws, D.ws_bytes, st)) != hipSuccess) return e;
+      if ((e = dg(D.att, H, w.wo, H, D.part_o, H, H, 1, D.split_o)) != hipSuccess) return e;
+      if ((e = launch_rmsnorm_sum_fwd(D.x, 1, D.part_o, D.split_o, pstride, w0.ln2, D.hb, D.n2, D.rstd, B, H, d.rms_eps, st)) != hipSuccess) return e;
+      if (ad.kind == 2 && ad.swiglu_pair) {
+        if ((e = dg(D.n2, H, w.wgu, H, D.act, F, 2 * F, 2, 1)) != hipSuccess) return e;
+      } else {
+        if ((e = dg(D.n2, H, w.wgu, H, D.gu, 2 * F, 2 * F, 0, 1)) != hipSuccess) return e;
+        if ((e = launch_silu_mul_fwd(D.gu, D.act, B, F, st)) != hipSuccess) return e;
+      }
+      if ((e = dg(D.act, F, w.wd, F, D.part_d, H, H, 1, D.split_d)) != hipSuccess) return e;
+    }
+    return decode_head(c, D.hb, D.part_d, D.split_d, st);
+  }
   const void* cur = D.emb; int cur_f32 = 0;
   float* nx = D.x;
   LayerBufs b; b.n1 = D.n1; b.qkv = D.qkv; b.t_qkv = D.t_qkv; b.attn = D.att; b.t_o = D.t_o; b.n2 = D.n2; b.t_gu = D.t_gu; b.gu = D.gu; b.act = D.act;
@@ -825,7 +861,7 @@ static hipError_t decode_one(opadpo_ctx* c, hipStream_t st) {
     cur = nx; cur_f32 = 1;
     nx = (nx == D.x) ? D.x2 : D.x;
   }
-  return decode_head(c, (const float*)cur, st);
+  return decode_head(c, (const float*)cur, nullptr, 0, st);
 }
 
 int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const uint16_t* feats, int B, int Q,
@@ -848,6 +884,12 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   D.history = history; D.temperature = temperature; D.top_k = top_k; D.top_p = top_p; D.seed = seed; D.eos_id = eos_id; D.pad_id = pad_id;
   D.suppress_eos = suppress_eos;
   D.ws_bytes = attn_decode_workspace_bytes(B, nh, hd, max_ctx);
+  // 33..64 sequences without LoRA tails (adapter-free or merged adapter): the LDS-ring decode GEMM (gemm_nt_dec64_kernel), the o / down
+  // projections K-split into fp32 partial tiles that the following RMSNorm adds.  OPADPO_DEC64_MIN (diagnostics): smallest batch taking it.
+  static const int dec64_min = getenv("OPADPO_DEC64_MIN") ? atoi(getenv("OPADPO_DEC64_MIN")) : 33;
+  D.use64 = B >= dec64_min && B <= 64 && ad.kind != 1 && H <= 256 * 8 * 3 && F % 64 == 0 && !(c->use_tr >= 0 && (c->use_tr & 32));
+  D.split_o = D.use64 ? gemm_nt_dec64_splits(H, H, 0) : 1;
+  D.split_d = D.use64 ? gemm_nt_dec64_splits(H, F, 0) : 1;
   auto layout = [&](void* base) {
     Carve cv(base);
     const size_t kvn = (size_t)d.n_layers * B * nh * max_ctx * hd;
@@ -859,6 +901,8 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
     D.rstd = cv.take<float>(B); D.emb = cv.take<bf16_t>((size_t)B * H); D.logits = cv.take<float>((size_t)B * V);
     D.cur_tok = cv.take<int32_t>(B); D.finished = cv.take<uint8_t>(B); D.step_d = cv.take<int32_t>(1); D.pos_d = cv.take<int32_t>(1);
     D.ws = cv.take<uint8_t>(std::max<size_t>(D.ws_bytes, 4));
+    D.part_o = cv.take<float>(D.use64 ? (size_t)D.split_o * B * H : 1);
+    D.part_d = cv.take<float>(D.use64 ? (size_t)D.split_d * B * H : 1);
     return cv.off;
   };
   D.bytes = layout(nullptr);
@@ -912,7 +956,7 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
     CKD(hipMemcpyAsync(history, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     CKD(hipStreamSynchronize(st));
   }
-  CKD(decode_head(c, D.hs, st));                  // token 0 from the prefill logits
+  CKD(decode_head(c, D.hs, nullptr, 0, st));      // token 0 from the prefill logits
 #undef CKD
   ctx_free(c, parena, pbytes);
   return 0;

@@ -491,6 +491,49 @@ __global__ __launch_bounds__(256) void f32_to_bf16_strided_kernel(const float* i
   }
 }
 
+// x_out = resid + sum_s partials[s] (fp32), y = RMSNorm(x_out) * w (bf16): the residual add + RMSNorm that follows a K-split decode
+// projection (gemm_nt_dec64_kernel MODE 1 writes one fp32 partial tile per K-slice; adding them here keeps the sum order fixed -
+// deterministic, no atomics - and costs no launch).  One block per row, row held in registers between the two passes.
+template <bool RF>
+__global__ __launch_bounds__(256) void rmsnorm_sum_fwd_kernel(const void* resid, const float* partials, int n_partials, size_t partial_stride,
+                                                               const bf16_t* w, float* x_out, bf16_t* y, float* rstd, int H, float eps) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  float f[3][8], g[3][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int i = threadIdx.x * 8 + it * 2048;
+    if (i < H) {
+      load8<RF>(resid, row * H + i, f[it]);
+      unpack8(*(const uint4*)(w + i), g[it]);
+      for (int sidx = 0; sidx < n_partials; ++sidx) {
+        const float* pp = partials + (size_t)sidx * partial_stride + row * H + i;
+        const float4 a = *(const float4*)pp, b = *(const float4*)(pp + 4);
+        f[it][0] += a.x; f[it][1] += a.y; f[it][2] += a.z; f[it][3] += a.w;
+        f[it][4] += b.x; f[it][5] += b.y; f[it][6] += b.z; f[it][7] += b.w;
+      }
+      *(float4*)(x_out + row * H + i) = make_float4(f[it][0], f[it][1], f[it][2], f[it][3]);
+      *(float4*)(x_out + row * H + i + 4) = make_float4(f[it][4], f[it][5], f[it][6], f[it][7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += f[it][j] * f[it][j];
+    }
+  }
+  ss = block_sum_256(ss, red);
+  const float r = rsqrtf(ss / H + eps);
+  if (rstd && threadIdx.x == 0) rstd[row] = r;
+  if (!y) return;
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int i = threadIdx.x * 8 + it * 2048;
+    if (i < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[it][j] = f[it][j] * r * g[it][j];
+      *(uint4*)(y + row * H + i) = pack8(f[it]);
+    }
+  }
+}
+
 inline int ew_grid(size_t total_threads) {
   size_t b = (total_threads + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -505,6 +548,14 @@ hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t*
   if (H % 8) return hipErrorInvalidValue;
   if (x_f32) hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
   else hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partials, int n_partials, size_t partial_stride, const bf16_t* w,
+                                  float* x_out, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st) {
+  if (rows <= 0) return hipSuccess;
+  if (H % 8 || H > 256 * 8 * 3 || n_partials < 0 || (n_partials > 0 && !partials) || !x_out) return hipErrorInvalidValue;
+  if (resid_f32) hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<true>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps);
+  else hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps);
   return hipGetLastError();
 }
 hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,

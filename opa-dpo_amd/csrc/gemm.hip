@@ -1288,6 +1288,139 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny8_kernel(GemmNTArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemm_nt "dec64" kernel: the decode GEMM for 33..64 tokens (rollout at 64 sequences per device, BASELINE.json configs[4]).
+// The 16/32-row streaming kernels above keep one token fragment per MFMA in flight and re-read the whole activation K-range
+// per 16 weight rows: at 64 tokens that is 4 B of L2 activation traffic per weight byte and 1-2 KB of weights in flight per
+// wave - 1.4-2.2 TB/s.  Here a workgroup (4 waves) owns 64 weight rows x 64 tokens x ONE K-slice:
+//   * BOTH operands go through LDS by direct-to-LDS DMA (buffer_load ... lds), whole 128-byte lines per row, into a 4-stage
+//     ring of 16 KiB (8 KiB weights + 8 KiB activations per 64-deep k-tile): 48 KiB in flight per workgroup, two workgroups
+//     per CU, no registers spent on staging; 1 byte of activations per weight byte;
+//   * wave w multiplies its 16 weight rows with all MF token fragments (2 x MF MFMAs per k-tile; the matrix pipe idles, the
+//     kernel's job is the HBM stream);
+//   * K is split over gridDim.y workgroups where N alone gives too few (o / down projection: N = 4096 -> 64 column tiles x 4
+//     K-slices); a slice writes its fp32 partial tile, the consumer (rmsnorm_sum_fwd: the residual add + RMSNorm that follows
+//     every such projection) adds the slices - deterministic, no atomics, no extra launch.
+// MODE 0: bf16 C[M,N]; 1: fp32 C[split][M,N] (ldc = N of one slice; logits when gridDim.y == 1); 2: SwiGLU pair - weight rows
+// per 128 are [64 gate | 64 up] (OPADPO_ACT_SWIGLU_PAIR), a workgroup takes 32 gate rows and the 32 up rows 64 further:
+// bf16 C[M, N/2] = silu(gate) * up on the bf16-rounded values (same formula as silu_mul_fwd_kernel).
+// ---------------------------------------------------------------------------------------------------
+constexpr int D_BN = 64, D_BK = 64, D_NS = 4, D_HALF = 8192, D_STAGE = 16384;
+
+template <int MF, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bt = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
+  const int nt = p.K1 / D_BK;
+  const int per = (nt + splits - 1) / splits;
+  const int t0 = split * per, t1 = min(nt, t0 + per);
+  // weight rows of this workgroup: 64 consecutive rows, or (MODE 2) 32 gate rows + the 32 up rows 64 further
+  const int n0 = MODE == 2 ? (bt >> 1) * 128 + (bt & 1) * 32 : bt * D_BN;
+  auto wrow = [&](int r) { return MODE == 2 ? n0 + (r < 32 ? r : 32 + r) : n0 + r; };      // r >= 32 -> n0 + 64 + (r - 32)
+  // DMA pieces: piece q (0..7) of an operand = rows q*8 .. q*8+7 x 128 B; wave w issues pieces 2w, 2w+1 of both operands.
+  // LDS image: row r at r*128, 16-byte chunk c stored at position c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments);
+  // the DMA writes lane-linear, so the swizzle is applied on the SOURCE side: lane (row q*8 + (l >> 3), position l & 7)
+  // fetches global chunk (l & 7) ^ ((row >> 1) & 7).
+  const int prow = lane >> 3, ppos = lane & 7;
+  unsigned voffW[2], voffA[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + prow;
+    const int ch = ppos ^ ((r >> 1) & 7);
+    voffW[j] = (unsigned)wrow(r) * (unsigned)p.ldb1 * 2u + ch * 16u;
+    voffA[j] = (unsigned)min(r, p.M - 1) * (unsigned)p.lda1 * 2u + ch * 16u;
+  }
+  auto uni = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uni(p.A1), 0, (int)0xffffffffu, 0x00020000);
+  auto issue = [&](int t) {
+    char* st = smem + ((t - t0) % D_NS) * D_STAGE;
+    const int k2 = t * D_BK * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave * 2 + j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(void, st + piece * 1024), 16, voffW[j], k2, 0, 2);            // aux 2 = nt: streamed once
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, st + D_HALF + piece * 1024), 16, voffA[j], k2, 0, 0);
+    }
+  };
+  f32x4_t acc[MF];
+#pragma unroll
+  for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fc = lane >> 4;
+  const int wr = wave * 16 + fr;
+  const int wsw = (wr >> 1) & 7, asw = (fr >> 1) & 7;            // token rows f*16 + fr: (row >> 1) & 7 == (fr >> 1) & 7
+#pragma unroll
+  for (int s = 0; s < D_NS - 1; ++s)
+    if (t0 + s < t1) issue(t0 + s);
+  for (int t = t0; t < t1; ++t) {
+    // stage t landed: this wave's pieces of stages t+1 .. t+NS-2 may stay in flight (4 pieces each)
+    if (t1 - t - 1 >= D_NS - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // everyone's pieces of stage t are in; everyone is done reading stage t-1
+    if (t + D_NS - 1 < t1) issue(t + D_NS - 1);          // into the slot stage t-1 occupied
+    const char* st = smem + ((t - t0) % D_NS) * D_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8_t wf = *(const bf16x8_t*)(st + wr * 128 + (((kk * 4 + fc) ^ wsw) << 4));
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        const bf16x8_t af = *(const bf16x8_t*)(st + D_HALF + (f * 16 + fr) * 128 + (((kk * 4 + fc) ^ asw) << 4));
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[f], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds C[token f*16 + fr][4 consecutive columns fc*4 .. +3 of the wave's 16 weight rows]
+  if constexpr (MODE == 2) {
+    __syncthreads();                                           // ring is dead: reuse it for the gate / up exchange
+    float* ex = (float*)smem;                                  // [2 up waves][MF][64 lanes][4]
+    if (wave >= 2) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f) *(f32x4_t*)(ex + (((wave - 2) * MF + f) * 64 + lane) * 4) = acc[f];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        const int m = f * 16 + fr;
+        if (m >= p.M) continue;
+        const f32x4_t u = *(const f32x4_t*)(ex + ((wave * MF + f) * 64 + lane) * 4);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gt = bf2f(f2bf(acc[f][e])), up = bf2f(f2bf(u[e]));
+          o[e] = gt / (1.0f + __expf(-gt)) * up;
+        }
+        uint2 stv;
+        stv.x = pack_bf2(o[0], o[1]);
+        stv.y = pack_bf2(o[2], o[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + (bt >> 1) * 64 + (bt & 1) * 32 + wave * 16 + fc * 4) = stv;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int f = 0; f < MF; ++f) {
+    const int m = f * 16 + fr;
+    if (m >= p.M) continue;
+    const int n = n0 + wave * 16 + fc * 4;
+    if constexpr (MODE == 1) {
+      *(float4*)((float*)p.C + ((size_t)split * p.M + m) * p.ldc + n) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+    } else {
+      uint2 stv;
+      stv.x = pack_bf2(acc[f][0], acc[f][1]);
+      stv.y = pack_bf2(acc[f][2], acc[f][3]);
+      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = stv;
+    }
+  }
+}
+
+
 
 // [TK][128] bf16 tiles (256-byte rows) with the 16-byte-chunk swizzle chunk ^= (row & 7) << 1, which is
 // conflict-free for ds_read_b64_tr_b16 (the 32 lanes of a half-wave touch 8 rows x 32 B = all 64 banks).
@@ -1792,4 +1925,44 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (use_tr) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
   return hipGetLastError();
+}
+
+// decode GEMM for up to 64 tokens: C = A[M,K] . B[N,K]^T, no bias / residual / LoRA tail (a merged or adapter-free rollout).
+// mode 0: bf16 C[M,N]; 1: fp32, `splits` K-slices -> C[splits][M,N] partial tiles (the consumer adds them: launch_rmsnorm_sum_fwd);
+// 2: SwiGLU pair -> bf16 C[M, N/2].  splits <= 0: chosen so that about two workgroups per CU exist.
+hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipStream_t st) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.M > 64 || a.N % 128 || a.K1 % D_BK || a.K1 <= 0 || a.K2 != 0 || a.lda1 % 8 || a.ldb1 % 8 || mode < 0 || mode > 2) return hipErrorInvalidValue;
+  if ((double)a.M * a.lda1 * 2 >= 4.0e9 || (double)a.N * a.ldb1 * 2 >= 4.0e9) return hipErrorInvalidValue;          // 32-bit buffer offsets
+  const int nt = a.K1 / D_BK, tiles = a.N / D_BN;
+  if (mode != 1) splits = 1;
+  if (splits <= 0) {
+    splits = (448 + tiles - 1) / tiles;
+    if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
+  }
+  if (splits > nt) splits = nt;
+  static bool attr = false;
+  if (!attr) {
+#define D_ATTR(MF_, MD_) (void)hipFuncSetAttribute((const void*)gemm_nt_dec64_kernel<MF_, MD_>, hipFuncAttributeMaxDynamicSharedMemorySize, D_NS * D_STAGE)
+    D_ATTR(1, 0); D_ATTR(2, 0); D_ATTR(3, 0); D_ATTR(4, 0); D_ATTR(1, 1); D_ATTR(2, 1); D_ATTR(3, 1); D_ATTR(4, 1);
+    D_ATTR(1, 2); D_ATTR(2, 2); D_ATTR(3, 2); D_ATTR(4, 2);
+#undef D_ATTR
+    attr = true;
+  }
+  const dim3 gr(tiles, splits), bl(256);
+  const int mf = (a.M + 15) / 16;
+#define D_GO(MF_, MD_) hipLaunchKernelGGL((gemm_nt_dec64_kernel<MF_, MD_>), gr, bl, D_NS * D_STAGE, st, a)
+#define D_MODE(MD_) do { if (mf == 1) D_GO(1, MD_); else if (mf == 2) D_GO(2, MD_); else if (mf == 3) D_GO(3, MD_); else D_GO(4, MD_); } while (0)
+  if (mode == 0) D_MODE(0); else if (mode == 1) D_MODE(1); else D_MODE(2);
+#undef D_MODE
+#undef D_GO
+  return hipGetLastError();
+}
+int gemm_nt_dec64_splits(int N, int K, int splits) {
+  const int nt = K / D_BK, tiles = N / D_BN;
+  if (splits <= 0) {
+    splits = (448 + tiles - 1) / tiles;
+    if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
+  }
+  return splits > nt ? nt : splits;
 }

@@ -178,7 +178,9 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
     if check_grads:
         blocks = _grad_blocks(d, pol_ad, ol)
         REPORT[f"{tag}_grad_blocks"] = blocks
-        REPORT[f"{tag}_loss_rel"] = abs(float(loss) - float(oloss)) / abs(float(oloss))
+        # the weighted sum can cancel: error relative to the sum of |terms|
+        scale = sum(float((pol_f32[k + "_logprobs"].detach().abs() * wts[k].abs()).sum()) for k in resp)
+        REPORT[f"{tag}_loss_rel"] = abs(float(loss.detach()) - float(oloss.detach())) / scale
     _dump()
     print(f"[{tag}] rows={M}", json.dumps(worst))
     for name, floor in (("ref_merged_vs_emu_merged", "floor_ref_emuA_vs_emuB"), ("policy_vs_emu", "floor_policy_emuA_vs_emuB"),
@@ -205,7 +207,7 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
         lim = 3e-2 if d.n_layers == 1 else 5e-2
         bad = {k: (round(v[0], 4), round(v[1], 4)) for k, v in blocks.items() if not (v[0] < lim and abs(v[1] - 1.0) < 5e-3)}
         assert not bad, f"{tag}: LoRA gradient blocks beyond {lim} relative Frobenius error / 5e-3 projection error: {bad}"
-        assert REPORT[f"{tag}_loss_rel"] < 2e-3
+        assert REPORT[f"{tag}_loss_rel"] < 1e-3
     eng.release()
     del eng
     torch.cuda.empty_cache()
@@ -245,6 +247,8 @@ def test_rollout_batch64_7b_width():
     kw = dict(hidden=4096, n_layers=2, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
               v_heads=2, v_ffn=256, image_size=336, patch=14, lora_r=256, lora_alpha=512.0)
     d, od, W, eng, dev, LR = _model(kw, std=0.03)
+    from opadpo_amd.ctx import CtxEngine
+    eng = CtxEngine(eng.base)           # the product path: prefill, KV cache, hipGraph and the 33..64-token decode GEMMs below the C ABI
     B, Q, N = 64, 128, 48
     assert d.n_patches == 576
     g = torch.Generator().manual_seed(8)
@@ -287,6 +291,17 @@ def test_rollout_batch64_7b_width():
         nxt = greedy[rows, step]
         ids = torch.cat([ids, nxt[:, None]], 1)
         mask = torch.cat([mask, torch.ones(len(rows), 1, dtype=torch.bool)], 1)
+    # the LDS-ring decode GEMM (default from 33 sequences) against the 16/32-row streaming kernels (context flag bit 5): two
+    # summation orders of the same projections - greedy tokens agree except at near-ties of the top-2 logits
+    old = CtxEngine(eng.base)
+    old.set_flags(use_tr=1 | 32)
+    greedy_old = Generator(old, None, use_graph=True).generate(queries, qmask, image_feats=feats, max_new_tokens=N, top_k=1, top_p=1.0,
+                                                                seed=1, suppress_eos=True).cpu()
+    first_diff = [int((greedy[b] != greedy_old[b]).nonzero()[0]) if bool((greedy[b] != greedy_old[b]).any()) else N for b in range(B)]
+    same_rows = sum(1 for v in first_diff if v == N)
+    REPORT["rollout_b64_dec64_vs_streaming"] = {"identical_rows": same_rows, "rows": B, "min_first_difference_step": min(first_diff)}
+    assert same_rows >= B // 2, f"only {same_rows} of {B} greedy rows agree between the two decode GEMM families"
+    old.close()
     REPORT["rollout_b64_checked"] = {"rows": rows, "steps": n_chk, "near_ties_resolved_to_second": close, "ctx_max": Q + d.n_patches - 1 + N}
     _dump()
-    eng.release()
+    eng.close()

@@ -969,3 +969,67 @@ def test_gemm_nt_rope(L, S, Lp, seg, lora):
     tol = 2.0 ** -7 * want.float().abs() + 1e-6                         # one bf16 ulp
     assert bool((d <= tol).all()), f"max excess {(d - tol).max().item()}"
     assert float((d > 0).float().mean()) < 0.02                        # and almost everywhere identical
+
+
+@pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
+@pytest.mark.parametrize("shape", [(4096, 4096), (4096, 11008), (12288, 4096), (1024, 512)])
+def test_gemm_nt_decode_modes(L, M, shape):
+    """opadpo_gemm_nt_decode (LDS-ring decode GEMM, 64 weight rows x <= 64 tokens x one K-slice per workgroup): bf16 output, fp32
+    K-split partial tiles (their sum in slice order) and the SwiGLU-pair epilogue, against torch fp32; rows >= M untouched."""
+    import ctypes as C
+    N, K = shape
+    lib = L.load()
+    a, w = rnd(M, K, scale=0.5, seed=1), rnd(N, K, scale=0.05, seed=2)
+    want = a.float() @ w.float().t()
+    ob = torch.full((M + 2, N), 7.0, dtype=BF, device=dev())
+    L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(ob), N, 0, M, N, 1, L.stream())
+    assert relerr(ob[:M], want) < 6e-3 and float((ob[M:].float() - 7.0).abs().max()) == 0.0
+    for splits in (0, 1, 3):
+        S = lib.opadpo_gemm_nt_decode_splits(N, K, splits)
+        assert 1 <= S <= K // 64
+        part = torch.full((S, M, N), 3.0, device=dev())
+        L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(part), N, 1, M, N, splits, L.stream())
+        assert relerr(part.sum(0), want) < 1e-5, (splits, S)
+        if S > 1:
+            assert float(part[0].abs().max()) > 0 and relerr(part[0], want) > 1e-2      # really split
+    # SwiGLU pair: rows per 128 = [64 gate | 64 up]
+    F = N // 2
+    z = want.view(M, F // 64, 2, 64)
+    zb = z.to(BF).float()
+    oa = torch.full((M + 1, F), 5.0, dtype=BF, device=dev())
+    L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(oa), F, 2, M, N, 1, L.stream())
+    assert relerr(oa[:M], (torch.nn.functional.silu(zb[:, :, 0]) * zb[:, :, 1]).reshape(M, F)) < 2e-2
+    assert float((oa[M:].float() - 5.0).abs().max()) == 0.0
+    # strided operands (rows inside wider buffers)
+    abig, wbig = rnd(M, K + 64, scale=0.5, seed=3), rnd(N, K + 128, scale=0.05, seed=4)
+    o2 = torch.empty(M, N, dtype=BF, device=dev())
+    L.call("opadpo_gemm_nt_decode", L.ptr(abig), K + 64, L.ptr(wbig), K + 128, K, L.ptr(o2), N, 0, M, N, 1, L.stream())
+    assert relerr(o2, abig[:, :K].float() @ wbig[:, :K].float().t()) < 6e-3
+    # repeated runs are bit-identical (DMA ring / barrier race screen)
+    o3 = torch.empty_like(o2)
+    for _ in range(5):
+        L.call("opadpo_gemm_nt_decode", L.ptr(abig), K + 64, L.ptr(wbig), K + 128, K, L.ptr(o3), N, 0, M, N, 1, L.stream())
+        assert torch.equal(o2, o3)
+
+
+@pytest.mark.parametrize("resid_f32", [True, False])
+def test_rmsnorm_sum_fwd(L, resid_f32):
+    rows, H, S = 37, 4096, 4
+    g = torch.Generator().manual_seed(5)
+    resid = torch.randn(rows, H, generator=g).to(dev())
+    if not resid_f32:
+        resid = resid.to(BF)
+    part = torch.randn(S, rows, H, generator=g).to(dev())
+    w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev()).to(BF)
+    x_out = torch.empty(rows, H, device=dev())
+    y = torch.empty(rows, H, dtype=BF, device=dev())
+    rstd = torch.empty(rows, device=dev())
+    for n in (S, 0):
+        L.call("opadpo_rmsnorm_sum_fwd", L.ptr(resid), int(resid_f32), L.ptr(part) if n else None, n, rows * H, L.ptr(w), L.ptr(x_out), L.ptr(y),
+               L.ptr(rstd), rows, H, 1e-5, L.stream())
+        want_x = resid.float()
+        for s_ in range(n):
+            want_x = want_x + part[s_]
+        assert torch.equal(x_out, want_x), "the slices are added in order on top of the residual: exact in fp32"
+        r = torch.rsqrt(want_x.pow(2).mean(-1, keepdim=True) + 1e-5)
+        assert relerr(y, want_x * r * w.float()) < 5e-3 and relerr(rstd, r.squeeze(-1)) < 1e-5
