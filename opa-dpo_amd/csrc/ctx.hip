@@ -884,9 +884,9 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   D.history = history; D.temperature = temperature; D.top_k = top_k; D.top_p = top_p; D.seed = seed; D.eos_id = eos_id; D.pad_id = pad_id;
   D.suppress_eos = suppress_eos;
   D.ws_bytes = attn_decode_workspace_bytes(B, nh, hd, max_ctx);
-  // 33..64 sequences without LoRA tails (adapter-free or merged adapter): the LDS-ring decode GEMM (gemm_nt_dec64_kernel), the o / down
+  // 25..64 sequences without LoRA tails (adapter-free or merged adapter): the LDS-ring decode GEMM (gemm_nt_dec64_kernel), the o / down
   // projections K-split into fp32 partial tiles that the following RMSNorm adds.  OPADPO_DEC64_MIN (diagnostics): smallest batch taking it.
-  static const int dec64_min = getenv("OPADPO_DEC64_MIN") ? atoi(getenv("OPADPO_DEC64_MIN")) : 33;
+  static const int dec64_min = getenv("OPADPO_DEC64_MIN") ? atoi(getenv("OPADPO_DEC64_MIN")) : 25;
   D.use64 = B >= dec64_min && B <= 64 && ad.kind != 1 && H <= 256 * 8 * 3 && F % 64 == 0 && !(c->use_tr >= 0 && (c->use_tr & 32));
   D.split_o = D.use64 ? gemm_nt_dec64_splits(H, H, 0) : 1;
   D.split_d = D.use64 ? gemm_nt_dec64_splits(H, F, 0) : 1;

@@ -1293,9 +1293,10 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny8_kernel(GemmNTArgs p) {
 // The 16/32-row streaming kernels above keep one token fragment per MFMA in flight and re-read the whole activation K-range
 // per 16 weight rows: at 64 tokens that is 4 B of L2 activation traffic per weight byte and 1-2 KB of weights in flight per
 // wave - 1.4-2.2 TB/s.  Here a workgroup (4 waves) owns 64 weight rows x 64 tokens x ONE K-slice:
-//   * BOTH operands go through LDS by direct-to-LDS DMA (buffer_load ... lds), whole 128-byte lines per row, into a 4-stage
-//     ring of 16 KiB (8 KiB weights + 8 KiB activations per 64-deep k-tile): 48 KiB in flight per workgroup, two workgroups
-//     per CU, no registers spent on staging; 1 byte of activations per weight byte;
+//   * BOTH operands go through LDS by direct-to-LDS DMA (buffer_load ... lds), whole 128-byte lines per row, into a ring of
+//     16-KiB stages (8 KiB weights + 8 KiB activations per 64-deep k-tile): 4 stages = 48 KiB in flight per workgroup with two
+//     workgroups per CU, or 8 stages = 112 KiB with one per CU when the grid has at most one workgroup per CU anyway (q|k|v:
+//     192); no registers spent on staging; 1 byte of activations per weight byte;
 //   * wave w multiplies its 16 weight rows with all MF token fragments (2 x MF MFMAs per k-tile; the matrix pipe idles, the
 //     kernel's job is the HBM stream);
 //   * K is split over gridDim.y workgroups where N alone gives too few (o / down projection: N = 4096 -> 64 column tiles x 4
@@ -1305,10 +1306,13 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny8_kernel(GemmNTArgs p) {
 // per 128 are [64 gate | 64 up] (OPADPO_ACT_SWIGLU_PAIR), a workgroup takes 32 gate rows and the 32 up rows 64 further:
 // bf16 C[M, N/2] = silu(gate) * up on the bf16-rounded values (same formula as silu_mul_fwd_kernel).
 // ---------------------------------------------------------------------------------------------------
-constexpr int D_BN = 64, D_BK = 64, D_NS = 4, D_HALF = 8192, D_STAGE = 16384;
+constexpr int D_BN = 64, D_BK = 64, D_HALF = 8192, D_STAGE = 16384;
 
-template <int MF, int MODE>
+// KW = 2 (MODE 0 only): 32 weight rows per workgroup, waves 0,1 take the first 32 k of every tile and waves 2,3 the second (partials
+// meet in LDS once, at the end) - twice the workgroups for a projection whose 64-row tiles do not fill the chip (q|k|v: 192 -> 384).
+template <int MF, int MODE, int D_NS, int KW = 1>      // D_NS = ring depth: 4 (two workgroups per CU) or 8 (one per CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
+  static_assert(KW == 1 || MODE == 0, "K-split inside the workgroup: bf16 output only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1317,20 +1321,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
   const int per = (nt + splits - 1) / splits;
   const int t0 = split * per, t1 = min(nt, t0 + per);
   // weight rows of this workgroup: 64 consecutive rows, or (MODE 2) 32 gate rows + the 32 up rows 64 further
-  const int n0 = MODE == 2 ? (bt >> 1) * 128 + (bt & 1) * 32 : bt * D_BN;
+  const int n0 = MODE == 2 ? (bt >> 1) * 128 + (bt & 1) * 32 : bt * (D_BN / KW);
   auto wrow = [&](int r) { return MODE == 2 ? n0 + (r < 32 ? r : 32 + r) : n0 + r; };      // r >= 32 -> n0 + 64 + (r - 32)
   // DMA pieces: piece q (0..7) of an operand = rows q*8 .. q*8+7 x 128 B; wave w issues pieces 2w, 2w+1 of both operands.
   // LDS image: row r at r*128, 16-byte chunk c stored at position c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 fragments);
   // the DMA writes lane-linear, so the swizzle is applied on the SOURCE side: lane (row q*8 + (l >> 3), position l & 7)
   // fetches global chunk (l & 7) ^ ((row >> 1) & 7).
   const int prow = lane >> 3, ppos = lane & 7;
+  constexpr int WP = 2 / KW;                     // weight pieces per wave and stage (KW = 2: wave w issues piece w = rows 8w..8w+7)
   unsigned voffW[2], voffA[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = (wave * 2 + j) * 8 + prow;
     const int ch = ppos ^ ((r >> 1) & 7);
-    voffW[j] = (unsigned)wrow(r) * (unsigned)p.ldb1 * 2u + ch * 16u;
     voffA[j] = (unsigned)min(r, p.M - 1) * (unsigned)p.lda1 * 2u + ch * 16u;
+    const int rw = (wave * WP + j) * 8 + prow;
+    voffW[j] = (unsigned)wrow(rw) * (unsigned)p.ldb1 * 2u + (ppos ^ ((rw >> 1) & 7)) * 16u;
   }
   auto uni = [](const void* q) -> void* {
     const unsigned long long v = (unsigned long long)q;
@@ -1345,7 +1351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece = wave * 2 + j;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(void, st + piece * 1024), 16, voffW[j], k2, 0, 2);            // aux 2 = nt: streamed once
+      if (j < WP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(void, st + (wave * WP + j) * 1024), 16, voffW[j], k2, 0, 2);      // aux 2 = nt: streamed once
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, st + D_HALF + piece * 1024), 16, voffA[j], k2, 0, 0);
     }
   };
@@ -1353,20 +1359,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
 #pragma unroll
   for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fc = lane >> 4;
-  const int wr = wave * 16 + fr;
+  const int wr = (KW == 2 ? (wave & 1) : wave) * 16 + fr;
   const int wsw = (wr >> 1) & 7, asw = (fr >> 1) & 7;            // token rows f*16 + fr: (row >> 1) & 7 == (fr >> 1) & 7
 #pragma unroll
   for (int s = 0; s < D_NS - 1; ++s)
     if (t0 + s < t1) issue(t0 + s);
   for (int t = t0; t < t1; ++t) {
-    // stage t landed: this wave's pieces of stages t+1 .. t+NS-2 may stay in flight (4 pieces each)
-    if (t1 - t - 1 >= D_NS - 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage t landed: this wave's pieces of stages t+1 .. t+NS-2 may stay in flight (2 + WP pieces each)
+    if (t1 - t - 1 >= D_NS - 2) {
+      if constexpr (D_NS == 8 && KW == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if constexpr (D_NS == 8) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if constexpr (KW == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();                  // everyone's pieces of stage t are in; everyone is done reading stage t-1
     if (t + D_NS - 1 < t1) issue(t + D_NS - 1);          // into the slot stage t-1 occupied
     const char* st = smem + ((t - t0) % D_NS) * D_STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if (KW == 2 && kk != (wave >> 1)) continue;
       const bf16x8_t wf = *(const bf16x8_t*)(st + wr * 128 + (((kk * 4 + fc) ^ wsw) << 4));
 #pragma unroll
       for (int f = 0; f < MF; ++f) {
@@ -1404,11 +1417,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
     }
     return;
   }
+  if constexpr (KW == 2) {                                     // the two k-halves of a 16-row group meet in LDS
+    __syncthreads();
+    float* ex = (float*)smem;
+    if (wave >= 2) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f) *(f32x4_t*)(ex + (((wave - 2) * MF + f) * 64 + lane) * 4) = acc[f];
+    }
+    __syncthreads();
+    if (wave >= 2) return;
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[f] += *(const f32x4_t*)(ex + ((wave * MF + f) * 64 + lane) * 4);
+  }
 #pragma unroll
   for (int f = 0; f < MF; ++f) {
     const int m = f * 16 + fr;
     if (m >= p.M) continue;
-    const int n = n0 + wave * 16 + fc * 4;
+    const int n = n0 + (KW == 2 ? (wave & 1) : wave) * 16 + fc * 4;
     if constexpr (MODE == 1) {
       *(float4*)((float*)p.C + ((size_t)split * p.M + m) * p.ldc + n) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
     } else {
@@ -1930,28 +1955,43 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
 // decode GEMM for up to 64 tokens: C = A[M,K] . B[N,K]^T, no bias / residual / LoRA tail (a merged or adapter-free rollout).
 // mode 0: bf16 C[M,N]; 1: fp32, `splits` K-slices -> C[splits][M,N] partial tiles (the consumer adds them: launch_rmsnorm_sum_fwd);
 // 2: SwiGLU pair -> bf16 C[M, N/2].  splits <= 0: chosen so that about two workgroups per CU exist.
+int gemm_nt_dec64_splits(int N, int K, int splits);
 hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (a.M > 64 || a.N % 128 || a.K1 % D_BK || a.K1 <= 0 || a.K2 != 0 || a.lda1 % 8 || a.ldb1 % 8 || mode < 0 || mode > 2) return hipErrorInvalidValue;
   if ((double)a.M * a.lda1 * 2 >= 4.0e9 || (double)a.N * a.ldb1 * 2 >= 4.0e9) return hipErrorInvalidValue;          // 32-bit buffer offsets
   const int nt = a.K1 / D_BK, tiles = a.N / D_BN;
   if (mode != 1) splits = 1;
-  if (splits <= 0) {
-    splits = (448 + tiles - 1) / tiles;
-    if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
-  }
-  if (splits > nt) splits = nt;
-  static bool attr = false;
-  if (!attr) {
-#define D_ATTR(MF_, MD_) (void)hipFuncSetAttribute((const void*)gemm_nt_dec64_kernel<MF_, MD_>, hipFuncAttributeMaxDynamicSharedMemorySize, D_NS * D_STAGE)
-    D_ATTR(1, 0); D_ATTR(2, 0); D_ATTR(3, 0); D_ATTR(4, 0); D_ATTR(1, 1); D_ATTR(2, 1); D_ATTR(3, 1); D_ATTR(4, 1);
-    D_ATTR(1, 2); D_ATTR(2, 2); D_ATTR(3, 2); D_ATTR(4, 2);
-#undef D_ATTR
-    attr = true;
+  splits = gemm_nt_dec64_splits(a.N, a.K1, splits);
+  const int mf = (a.M + 15) / 16;
+  static const int kw2_max = getenv("OPADPO_DEC64_KW2") ? atoi(getenv("OPADPO_DEC64_KW2")) : 256;      // diagnostics
+  if (mode == 0 && tiles <= kw2_max) {      // 32-row workgroups: twice the blocks for a projection that does not fill the chip
+    static bool at[5] = {false, false, false, false, false};
+    const dim3 g2(2 * tiles), b2(256);
+#define D_GO2(MF_)                                                                                                                    \
+  do {                                                                                                                                \
+    if (!at[MF_]) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64_kernel<MF_, 0, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D_STAGE); at[MF_] = true; } \
+    hipLaunchKernelGGL((gemm_nt_dec64_kernel<MF_, 0, 4, 2>), g2, b2, 4 * D_STAGE, st, a);                                             \
+  } while (0)
+    if (mf == 1) D_GO2(1); else if (mf == 2) D_GO2(2); else if (mf == 3) D_GO2(3); else D_GO2(4);
+#undef D_GO2
+    return hipGetLastError();
   }
   const dim3 gr(tiles, splits), bl(256);
-  const int mf = (a.M + 15) / 16;
-#define D_GO(MF_, MD_) hipLaunchKernelGGL((gemm_nt_dec64_kernel<MF_, MD_>), gr, bl, D_NS * D_STAGE, st, a)
+  static const int deep_max = getenv("OPADPO_DEC64_DEEP") ? atoi(getenv("OPADPO_DEC64_DEEP")) : 256;      // diagnostics
+  const bool deep = tiles * splits <= deep_max;       // at most one workgroup per CU: a deeper ring instead of a second workgroup
+#define D_GO(MF_, MD_)                                                                                                             \
+  do {                                                                                                                             \
+    if (deep) {                                                                                                                    \
+      static bool at8 = false;                                                                                                     \
+      if (!at8) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64_kernel<MF_, MD_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * D_STAGE); at8 = true; } \
+      hipLaunchKernelGGL((gemm_nt_dec64_kernel<MF_, MD_, 8>), gr, bl, 8 * D_STAGE, st, a);                                         \
+    } else {                                                                                                                       \
+      static bool at4 = false;                                                                                                     \
+      if (!at4) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64_kernel<MF_, MD_, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * D_STAGE); at4 = true; } \
+      hipLaunchKernelGGL((gemm_nt_dec64_kernel<MF_, MD_, 4>), gr, bl, 4 * D_STAGE, st, a);                                         \
+    }                                                                                                                              \
+  } while (0)
 #define D_MODE(MD_) do { if (mf == 1) D_GO(1, MD_); else if (mf == 2) D_GO(2, MD_); else if (mf == 3) D_GO(3, MD_); else D_GO(4, MD_); } while (0)
   if (mode == 0) D_MODE(0); else if (mode == 1) D_MODE(1); else D_MODE(2);
 #undef D_MODE
@@ -1961,7 +2001,8 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
 int gemm_nt_dec64_splits(int N, int K, int splits) {
   const int nt = K / D_BK, tiles = N / D_BN;
   if (splits <= 0) {
-    splits = (448 + tiles - 1) / tiles;
+    static const int target = getenv("OPADPO_DEC64_BLOCKS") ? atoi(getenv("OPADPO_DEC64_BLOCKS")) : 512;      // diagnostics
+    splits = (target + tiles - 1) / tiles;
     if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
   }
   return splits > nt ? nt : splits;

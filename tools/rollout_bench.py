@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(REPO, "opa-dpo_amd"))
 from opadpo_amd import lib as L  # noqa: E402
 from opadpo_amd.dims import LlavaDims  # noqa: E402
 from opadpo_amd.generate import Generator  # noqa: E402
+from opadpo_amd.ctx import CtxEngine  # noqa: E402
 from opadpo_amd.model import BaseWeights, LlavaEngine  # noqa: E402
 from opadpo_amd.synth import init_weights, synth_pairs  # noqa: E402
 
@@ -27,7 +28,8 @@ def main():
     B = int(os.environ.get("RB_BATCH", 8))
     steps = int(os.environ.get("RB_STEPS", 48))
     Q = 128 if model == "7b" else 16
-    eng = LlavaEngine(BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=False))
+    base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=False)
+    eng = LlavaEngine(base) if os.environ.get("RB_OP_LEVEL") == "1" else CtxEngine(base)      # default: the context path (opadpo_decode_*)
     p = synth_pairs(d, B, Q, 8, seed=0, device=dev)
     lora = int(os.environ.get("RB_LORA", 0))       # 0: no adapter (the shipped rollout config), 1: frozen adapter, 2: frozen adapter merged
     ad = None
