@@ -90,6 +90,12 @@ int opadpo_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partia
 int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float* C, int ldc,
                    int M, int N1, int N2, int q_group_n1, int q_group_stride, float alpha, int splits,
                    void* stream);
+/* Up to 8 such products that share M (the 8 LoRA wgrads of one decoder layer) as ONE launch: their 256x256 tile lists are
+ * concatenated, so a workgroup's run is long and the fp32-atomic flushes are rare (an r-wide output launched alone is cut into 16
+ * K-chunks whose flush takes as long as their K-loop).  Host arrays of n entries; problems that do not fit the 256x256 kernel
+ * (N1, N2, q_group_n1 % 256) make the call fall back to n single launches. */
+int opadpo_gemm_tn_group(int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C, const int* ldc,
+                         int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha, void* stream);
 
 /* ---- attention (flash-attn 2.5.3 LlamaFlashAttention2 / CLIP eager attention) -------------------
  * q,k,v: element (s,pos,head,d) at ptr[(s*L+pos)*ld + head*hd + d]; o/dout with ldo.

@@ -99,6 +99,21 @@ int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float
   return done(launch_gemm_tn(a, S(stream)), "opadpo_gemm_tn");
 }
 
+int opadpo_gemm_tn_group(int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C, const int* ldc,
+                         int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha, void* stream) {
+  if (n < 0 || n > 8 || (n && (!P || !ldp || !Q || !ldq || !C || !ldc || !N1 || !N2))) return bad("opadpo_gemm_tn_group", "0..8 problems, non-null arrays");
+  GemmTNArgs list[8];
+  for (int i = 0; i < n; ++i) {
+    if (N1[i] <= 0 || N2[i] <= 0 || N1[i] % 128 || N2[i] % 128) return bad("opadpo_gemm_tn_group", "N1/N2 must be positive multiples of 128");
+    if (!P[i] || !Q[i] || !C[i] || ldp[i] % 8 || ldq[i] % 8) return bad("opadpo_gemm_tn_group", "null operand or misaligned leading dimension");
+    GemmTNArgs& a = list[i];
+    a.P = P[i]; a.Q = Q[i]; a.C = C[i]; a.M = M; a.N1 = N1[i]; a.N2 = N2[i]; a.ldp = ldp[i]; a.ldq = ldq[i]; a.ldc = ldc[i];
+    a.q_group_n1 = q_group_n1 ? q_group_n1[i] : 0; a.q_group_stride = q_group_stride ? q_group_stride[i] : 0; a.alpha = alpha; a.splits = 0;
+    if (a.q_group_n1 && a.q_group_n1 % 128) return bad("opadpo_gemm_tn_group", "q_group_n1 must be a multiple of 128");
+  }
+  return done(launch_gemm_tn_group(list, n, S(stream)), "opadpo_gemm_tn_group");
+}
+
 int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
                     float* lse, const uint8_t* key_mask, int S_, int L, int nh, int hd, int causal, float scale,
                     int seg_prefix, int seg_len, void* stream) {

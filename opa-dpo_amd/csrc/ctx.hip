@@ -690,7 +690,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   { Carve cv(nullptr); cv.take<bf16_t>((size_t)R * V); cv.take<bf16_t>((size_t)R * H); cv.take<float>((size_t)R * H); cv.take<float>(MH); cv.take<bf16_t>(MH);
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
-    cv.take<bf16_t>((size_t)M * 3 * r); need = cv.off; }
+    cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); need = cv.off; }
   const bool first = layer_hi == d.n_layers - 1;
   if (!first && (c->ws_bytes < need || !c->ws)) return cbad(c, __func__, "ranged backward must start at the top layer");
   void* base = ctx_ws(c, need, st);
@@ -701,6 +701,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   bf16_t* d_n = cv.take<bf16_t>(MH); bf16_t* d_act = cv.take<bf16_t>((size_t)M * F); bf16_t* d_gu = cv.take<bf16_t>((size_t)M * 2 * F);
   bf16_t* d_attn = cv.take<bf16_t>(MH); bf16_t* dqkv = cv.take<bf16_t>((size_t)M * 3 * H); float* delta = cv.take<float>((size_t)S * nh * Lp);
   bf16_t* dt_r = cv.take<bf16_t>((size_t)M * r); bf16_t* dt_2r = cv.take<bf16_t>((size_t)M * 2 * r); bf16_t* dt_3r = cv.take<bf16_t>((size_t)M * 3 * r);
+  bf16_t* dt_ra = cv.take<bf16_t>((size_t)M * r);        // dT of the o projection (dt_r keeps the down projection's until the grouped wgrad)
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");
@@ -718,10 +719,14 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     const bf16_t* wt = ad.work_t + (size_t)i * o.layer;
     float* gr = ad.grad + (size_t)i * o.layer;
     const LayerBufs b = slot(d, sv, i);
+    // the 8 LoRA wgrads of the layer are collected and run as ONE grouped launch (launch_gemm_tn_group) once the last of their
+    // operands exists: every operand stays untouched until then (dt_ra is the second dT buffer that makes that true)
+    GemmTNArgs wg[8];
+    int nwg = 0;
     auto tn = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, float* Cg, int ldc, int N1, int N2, int qgn, int qgs) {
-      GemmTNArgs t; t.P = Pm; t.Q = Q; t.C = Cg; t.M = M; t.N1 = N1; t.N2 = N2; t.ldp = ldp; t.ldq = ldq; t.ldc = ldc;
+      GemmTNArgs& t = wg[nwg++]; t.P = Pm; t.Q = Q; t.C = Cg; t.M = M; t.N1 = N1; t.N2 = N2; t.ldp = ldp; t.ldq = ldq; t.ldc = ldc;
       t.q_group_n1 = qgn; t.q_group_stride = qgs; t.alpha = 1.f; t.splits = 0; t.use_tr = c->use_tr;
-      return launch_gemm_tn(t, st);
+      return hipSuccess;
     };
     // ---- MLP ----
     { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
@@ -735,10 +740,10 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, d_gu, 2 * F, w.wgu_t, 2 * F, 2 * F, d_n, H, 0, M, H); tail(g, dt_2r, 2 * r, wt + o.a_gu, 2 * r, 2 * r); CK(run_gemm(c, g, st)); }
     CK(launch_rmsnorm_bwd(d_n, b.h, 1, w.ln2, b.rstd2, dX, 1, d_h, d_hb, M, H, st));
     // ---- attention ----
-    { GemmNTArgs g = gemm(c, d_hb, H, wt + o.b_o, H, H, dt_r, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
+    { GemmNTArgs g = gemm(c, d_hb, H, wt + o.b_o, H, H, dt_ra, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
     CK(tn(d_hb, H, b.t_o, r, gr + o.b_o, r, H, r, 0, 0));
-    CK(tn(dt_r, r, b.attn, H, gr + o.a_o, H, r, H, 0, 0));
-    { GemmNTArgs g = gemm(c, d_hb, H, w.wo_t, H, H, d_attn, H, 0, M, H); tail(g, dt_r, r, wt + o.a_o, r, r); CK(run_gemm(c, g, st)); }
+    CK(tn(dt_ra, r, b.attn, H, gr + o.a_o, H, r, H, 0, 0));
+    { GemmNTArgs g = gemm(c, d_hb, H, w.wo_t, H, H, d_attn, H, 0, M, H); tail(g, dt_ra, r, wt + o.a_o, r, r); CK(run_gemm(c, g, st)); }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = b.qkv; a.k = b.qkv + H; a.v = b.qkv + 2 * H; a.o = b.attn; a.lse = b.lse; a.key_mask = sv->key_mask;
@@ -750,6 +755,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0));
+    CK(launch_gemm_tn_group(wg, nwg, st));
     if (i > 0 || d_feats) {          // layer-0 input is the frozen embedding / image features: no further dgrad in the DPO stage
       { GemmNTArgs g = gemm(c, dqkv, 3 * H, w.wqkv_t, 3 * H, 3 * H, d_n, H, 0, M, H); tail(g, dt_3r, 3 * r, wt + o.a_qkv, 3 * r, 3 * r); CK(run_gemm(c, g, st)); }
       CK(launch_rmsnorm_bwd(d_n, sv->x + (size_t)i * MH, 1, w.ln1, b.rstd1, d_h, 1, dX, dXb, M, H, st));

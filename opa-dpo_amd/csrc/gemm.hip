@@ -1596,15 +1596,18 @@ __device__ __forceinline__ int tn3_off(int row, int col) {
 //   output.  PROF = s_memtime stamps (OPADPO_TN_PROF=1), summary on stderr.
 // ------------------------------------------------------------------------------------------
 template <bool PROF>
-__global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
+__global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n2 = p.N2 / 256, tiles = (p.N1 / 256) * tiles_n2;
-  const int ksteps = (p.M + 63) / 64;
-  const int chunk_len = (ksteps + p.splits - 1) / p.splits;
-  const long long total = (long long)p.splits * tiles * chunk_len;
+  // a GROUP of problems sharing M (the 8 LoRA wgrads of a decoder layer): their 256x256 tiles form one list, so the runs of a
+  // launch are long (whole layer: 305 tiles x 506 K-steps over 256 blocks) and a block flushes 2-3 tiles of atomics per ~600
+  // K-steps instead of one per 32 (r-wide outputs launched alone: 16 tiles -> 16 K-chunks, the flush as long as the K-loop)
+  const int tiles = G.tile_end[G.n - 1];
+  const int ksteps = (G.g[0].M + 63) / 64;
+  const int chunk_len = (ksteps + G.splits - 1) / G.splits;
+  const long long total = (long long)G.splits * tiles * chunk_len;
   const long long per = (total + gridDim.x - 1) / gridDim.x;
   const int lrun = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
   long long run_s = (long long)lrun * per;
@@ -1628,7 +1631,13 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNArgs p) {
 
   while (run_s < run_e) {
     const long long cidx = run_s / chunk_len;
-    const int kin = (int)(run_s % chunk_len), sidx = (int)(cidx / tiles), tile = (int)(cidx % tiles);
+    const int kin = (int)(run_s % chunk_len), sidx = (int)(cidx / tiles), gtile = (int)(cidx % tiles);
+    int pi = 0;
+    while (pi + 1 < G.n && gtile >= G.tile_end[pi]) ++pi;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const GemmTNArgs& p = G.g[pi];
+    const int tile = gtile - (pi ? G.tile_end[pi - 1] : 0);
+    const int tiles_n2 = p.N2 / 256;
     const int seg = (int)min((long long)(chunk_len - kin), run_e - run_s);      // K-steps of this segment inside the padded chunk
     run_s += seg;
     const int ks0 = sidx * chunk_len + kin;
@@ -1929,13 +1938,15 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
       attr = true;
     }
-    GemmTNArgs b = a;
+    GemmTNGroup G;
+    G.g[0] = a; G.n = 1;
     const int tiles4 = (a.N1 / 256) * (a.N2 / 256), ksteps = (a.M + 63) / 64;
-    b.splits = (256 + tiles4 - 1) / tiles4;                      // K-chunks: about one run per CU and chunk-tile
-    if (b.splits > ksteps) b.splits = ksteps;
-    const long long total = (long long)b.splits * tiles4 * ((ksteps + b.splits - 1) / b.splits);
+    G.tile_end[0] = tiles4;
+    G.splits = (256 + tiles4 - 1) / tiles4;                      // K-chunks: about one run per CU and chunk-tile
+    if (G.splits > ksteps) G.splits = ksteps;
+    const long long total = (long long)G.splits * tiles4 * ((ksteps + G.splits - 1) / G.splits);
     const dim3 gr((unsigned)(total < 256 ? total : 256));
-    hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, b);
+    hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, G);
     return hipGetLastError();
   }
   const int tiles = (a.N1 / 128) * (a.N2 / 128);
@@ -2006,4 +2017,42 @@ int gemm_nt_dec64_splits(int N, int K, int splits) {
     if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
   }
   return splits > nt ? nt : splits;
+}
+
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  bool ok = n <= 8 && g_tn_w4;
+  for (int i = 0; i < n && ok; ++i) {
+    const GemmTNArgs& a = list[i];
+    const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
+    ok = a.M == list[0].M && a.M > 0 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0) &&
+         (a.use_tr < 0 || (a.use_tr & 8) == 0);
+  }
+  if (!ok) {                                   // not groupable: one launch per problem
+    for (int i = 0; i < n; ++i) {
+      const hipError_t e = launch_gemm_tn(list[i], st);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    attr = true;
+  }
+  GemmTNGroup G;
+  G.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    G.g[i] = list[i];
+    tiles += (list[i].N1 / 256) * (list[i].N2 / 256);
+    G.tile_end[i] = tiles;
+  }
+  const int ksteps = (list[0].M + 63) / 64;
+  G.splits = (256 + tiles - 1) / tiles;
+  if (G.splits > ksteps) G.splits = ksteps;
+  const long long total = (long long)G.splits * tiles * ((ksteps + G.splits - 1) / G.splits);
+  const dim3 gr((unsigned)(total < 256 ? total : 256));
+  hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, G);
+  return hipGetLastError();
 }

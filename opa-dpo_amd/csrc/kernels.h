@@ -58,12 +58,23 @@ struct AttnArgs {
   int use_tr;                                           // per-call override of the transposed-LDS-read switch; < 0 = process default
 };
 
+// up to 8 gemm_tn problems with the same M run as ONE launch of the 256x256 kernel (tile lists concatenated)
+struct GemmTNGroup {
+  GemmTNArgs g[8];
+  int n;
+  int splits;
+  int tile_end[8];      // cumulative 256x256 tile counts
+};
+
 void opadpo_set_flags_impl(int use_glds, int use_tr);
 bool opadpo_flag_tr();
 void opadpo_set_attn_dma(bool on);
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
+// all problems must share M and be eligible for the 256x256 kernel (N1, N2 % 256 == 0, q_group_n1 % 256 == 0); otherwise the
+// problems are launched one by one
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st);
 
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st);

@@ -30,6 +30,7 @@ SIGNATURES = {
     "opadpo_gemm_nt_decode_splits": [_i, _i, _i],
     "opadpo_rmsnorm_sum_fwd": [_p, _i, _p, _i, _sz, _p, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "opadpo_gemm_tn_group": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p],
     "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],

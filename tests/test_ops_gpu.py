@@ -1033,3 +1033,50 @@ def test_rmsnorm_sum_fwd(L, resid_f32):
         assert torch.equal(x_out, want_x), "the slices are added in order on top of the residual: exact in fp32"
         r = torch.rsqrt(want_x.pow(2).mean(-1, keepdim=True) + 1e-5)
         assert relerr(y, want_x * r * w.float()) < 5e-3 and relerr(rstd, r.squeeze(-1)) < 1e-5
+
+
+def test_gemm_tn_group_equals_single_launches(L):
+    """opadpo_gemm_tn_group: the 8 LoRA wgrads of a decoder layer (7B shapes, M = 3000) as ONE launch of the 256x256 kernel ==
+    8 single launches (fp32 atomics: same sums up to accumulation order) == torch fp32; a group with a problem the big kernel
+    cannot take (N2 = 128) falls back to single launches."""
+    import ctypes as C
+    M, H, F, r = 3000, 1024, 2816, 256
+    g = torch.Generator().manual_seed(3)
+    mk = lambda n: (torch.randn(M, n, generator=g) * 0.3).to(BF).to(dev())
+    dY, t_d, dt_r, act, d_gu, t_gu, dt_2r, n2 = mk(H), mk(r), mk(r), mk(F), mk(2 * F), mk(2 * r), mk(2 * r), mk(H)
+    # (P, Q, N1, N2, q_group_n1, q_group_stride): b_d, a_d, b_gu (grouped Q columns), a_gu, and three more of the same kinds
+    probs = [(dY, t_d, H, r, 0, 0), (dt_r, act, r, F, 0, 0), (d_gu, t_gu, 2 * F, r, F, r), (dt_2r, n2, 2 * r, H, 0, 0),
+             (dY, t_d, H, r, 0, 0), (dt_r, n2, r, H, 0, 0), (dt_2r, act, 2 * r, F, 0, 0)]
+
+    def run(group):
+        outs = [torch.zeros(n1, n2_, device=dev()) for _, _, n1, n2_, _, _ in probs]
+        if group:
+            n = len(probs)
+            arr = lambda vals, T: (T * n)(*vals)
+            L.call("opadpo_gemm_tn_group", n, arr([p_[0].data_ptr() for p_ in probs], C.c_void_p), arr([p_[0].stride(0) for p_ in probs], C.c_int),
+                   arr([p_[1].data_ptr() for p_ in probs], C.c_void_p), arr([p_[1].stride(0) for p_ in probs], C.c_int),
+                   arr([o.data_ptr() for o in outs], C.c_void_p), arr([o.stride(0) for o in outs], C.c_int), M,
+                   arr([p_[2] for p_ in probs], C.c_int), arr([p_[3] for p_ in probs], C.c_int), arr([p_[4] for p_ in probs], C.c_int),
+                   arr([p_[5] for p_ in probs], C.c_int), 1.0, L.stream())
+        else:
+            for (P, Q, n1, n2_, qg, qs), o in zip(probs, outs):
+                L.gemm_tn(P, Q, o, q_group_n1=qg, q_group_stride=qs)
+        torch.cuda.synchronize()
+        return outs
+
+    single, grouped = run(False), run(True)
+    for (P, Q, n1, n2_, qg, qs), a, b in zip(probs, single, grouped):
+        if qg:
+            want = torch.cat([P[:, i * qg:(i + 1) * qg].float().t() @ Q[:, i * qs:i * qs + n2_].float() for i in range(n1 // qg)], 0)
+        else:
+            want = P.float().t() @ Q[:, :n2_].float()
+        assert relerr(b, want) < 1e-4 and relerr(a, b) < 1e-5
+    # not groupable (N2 = 128): falls back, same numbers
+    P, Q = mk(256), mk(128)
+    o1, o2 = torch.zeros(256, 128, device=dev()), torch.zeros(256, 128, device=dev())
+    L.gemm_tn(P, Q, o1)
+    one = lambda v, T: (T * 1)(v)
+    L.call("opadpo_gemm_tn_group", 1, one(P.data_ptr(), C.c_void_p), one(256, C.c_int), one(Q.data_ptr(), C.c_void_p), one(128, C.c_int),
+           one(o2.data_ptr(), C.c_void_p), one(128, C.c_int), M, one(256, C.c_int), one(128, C.c_int), None, None, 1.0, L.stream())
+    torch.cuda.synchronize()
+    assert relerr(o2, o1) < 1e-5 and relerr(o1, P.float().t() @ Q.float()) < 1e-4
