@@ -31,6 +31,10 @@ extern "C" {
                                  * silu(gate) * up (SwiGLU of modeling_llama.LlamaMLP fused into the gate|up projection; used
                                  * for the merged, no-grad reference pass and, with OPADPO_GEMM_STREAM, for decode with a
                                  * merged adapter).  Needs N % 256 == 0, bf16 C, no bias / residual / LoRA tail, alpha = 1. */
+#define OPADPO_ATTN_SKIP_MASKED_Q 2 /* OR into `causal` of opadpo_attn_fwd / _bwd: a tile of 64 query positions that are ALL masked as keys
+                                    * (the trailing padding of a right-padded response) writes zeros (forward: O, backward: dQ) and is left
+                                    * out of the dK / dV accumulation - exact for the LLM, where such rows are padding whose outputs nobody
+                                    * reads and whose output gradient is zero; needs key_mask */
 #define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
                                   * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
 

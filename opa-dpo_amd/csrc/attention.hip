@@ -222,6 +222,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int L = p.L;
   const int qpos = q0 + w * 16 + c;
   const int qrow = min(qpos, L - 1);
+  // causal bit 1 (OPADPO_ATTN_SKIP_MASKED_Q): a q tile whose 64 positions are ALL masked as keys is padding (the trailing pad of a
+  // right-padded response, 22 % of the rows of a synthetic seq512 pair): nothing downstream reads those rows (they are masked as
+  // keys, their labels are pad, their gradient is exactly zero), so the tile writes zeros and leaves.
+  if ((p.causal & 2) && p.key_mask) {
+    const int qp_ = q0 + lane;
+    const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+    if (__ballot(mq != 0) == 0) {
+      if (qpos < L) {
+        bf16_t* op = p.o + ((size_t)s * L + qpos) * p.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) *(uint2*)(op + d * 16 + g * 4) = make_uint2(0u, 0u);
+        if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = NEG_BIG;
+      }
+      return;
+    }
+  }
 
   bf16x8_t qf[KK];
   {
@@ -428,7 +444,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   f32x4_t dk[DF], dv[DF];
 #pragma unroll
   for (int d = 0; d < DF; ++d) { dk[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  // causal bit 1 (OPADPO_ATTN_SKIP_MASKED_Q): q tiles whose 64 positions are all masked as keys are padding, their dO is exactly
+  // zero -> they contribute nothing to dK / dV and are left out of the loop.  Bit t of `live` = q tile t has a valid position
+  // (wave w scans tiles w, w+4, ...; one 64-byte read per tile).
+  unsigned long long* const live_s = (unsigned long long*)(smem + 4 * TILE + 1024 + 80);
+  const bool skip_q = (p.causal & 2) && p.key_mask && (L + 63) / 64 <= 64;
+  if (skip_q) {
+    unsigned long long mine = 0;
+    for (int t = w; t < (L + 63) / 64; t += 4) {
+      const int qp_ = t * 64 + lane;
+      const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+      if (__ballot(mq != 0) != 0) mine |= 1ull << t;
+    }
+    if (lane == 0) live_s[w] = mine;
+  }
   __syncthreads();
+  const unsigned long long live = skip_q ? (live_s[0] | live_s[1] | live_s[2] | live_s[3]) : ~0ull;
   const bool key_ok = Ms[w * 16 + c] != 0;
   const bool keys_clean = !Ms[64];
   const float scale2 = p.scale * 1.4426950408889634f;
@@ -457,10 +488,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
       dlt_r = p.delta[li];
     }
   };
-  const int qt0 = p.causal ? kt : 0;
+  auto next_live = [&](int t) {              // first live q tile >= t (n_qt when there is none)
+    if (t >= n_qt) return n_qt;
+    if (!skip_q) return t;
+    const unsigned long long m = live >> t;
+    return m ? min(n_qt, t + (int)__builtin_ctzll(m)) : n_qt;
+  };
+  const int qt0 = next_live(p.causal ? kt : 0);
   if (qt0 < n_qt) stage(0, qt0 * 64);
   int cur = 0;
-  for (int qt = qt0; qt < n_qt; ++qt) {
+  for (int qt = qt0, qn; qt < n_qt; qt = qn) {
+    qn = next_live(qt + 1);
     const int q0 = qt * 64;
     const char* Qs = smem + cur * 2 * TILE;
     const char* dOs = Qs + TILE;
@@ -472,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();          // tile qt landed for everyone; everyone is done with the other buffer
-    if (qt + 1 < n_qt) stage(cur ^ 1, q0 + 64);
+    if (qn < n_qt) stage(cur ^ 1, qn * 64);
     cur ^= 1;
 
     f32x4_t sc[4], dp[4];
@@ -558,6 +596,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const int L = p.L;
   const int qpos = q0 + w * 16 + c;
   const int qrow = min(qpos, L - 1);
+  if ((p.causal & 2) && p.key_mask) {          // all-padding q tile (see attn_fwd_kernel): its dQ is exactly zero
+    const int qp_ = q0 + lane;
+    const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+    if (__ballot(mq != 0) == 0) {
+      if (qpos < L) {
+        if (p.dq) {
+          bf16_t* dqp = p.dq + ((size_t)s * L + qpos) * p.ld + h * HD;
+#pragma unroll
+          for (int d = 0; d < DF; ++d) *(uint2*)(dqp + d * 16 + g * 4) = make_uint2(0u, 0u);
+        }
+        if (p.dq_acc) {
+          float* dqa = p.dq_acc + ((size_t)s * L + qpos) * (size_t)(p.nh * HD) + h * HD;
+#pragma unroll
+          for (int d = 0; d < DF; ++d) *(float4*)(dqa + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      return;
+    }
+  }
 
   bf16x8_t qf[KK], dof[KK];
   {
@@ -700,14 +757,14 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   const bool tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : opadpo_flag_tr();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80 + 64);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 1024 + 80 + 64);
     attr_set = true;
   }
   if ((double)a.L * a.ld * 2 >= 2.0e9 || (double)a.L * a.ldo * 2 >= 2.0e9) return hipErrorInvalidValue;   // 32-bit buffer extents
 #define LAUNCH_BWD(HD_, TR_)                                                                              \
   hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((unsigned)((total + 4 * (512 / HD_) - 1) / (4 * (512 / HD_)))), dim3(256), 0, st, a); \
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 4 * 64 * HD_ * 2 + 1024 + 80, st, a); \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 4 * 64 * HD_ * 2 + 1024 + 80 + 64, st, a); \
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
   if (a.hd == 128) {
     if (tr) { LAUNCH_BWD(128, true); } else { LAUNCH_BWD(128, false); }

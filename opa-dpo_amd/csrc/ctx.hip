@@ -353,7 +353,7 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = b.qkv; a.k = b.qkv + H; a.v = b.qkv + 2 * H; a.o = b.attn; a.lse = b.lse; a.key_mask = key_mask;
-  a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1; a.scale = 1.0f / sqrtf((float)hd);
+  a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1 | OPADPO_ATTN_SKIP_MASKED_Q; a.scale = 1.0f / sqrtf((float)hd);
   a.seg_prefix = seg0; a.seg_len = seg1; a.use_tr = c->use_tr;
   if ((e = launch_attn_fwd(a, st)) != hipSuccess) return e;
   if (lw) {
@@ -747,7 +747,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = b.qkv; a.k = b.qkv + H; a.v = b.qkv + 2 * H; a.o = b.attn; a.lse = b.lse; a.key_mask = sv->key_mask;
-    a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1; a.scale = 1.0f / sqrtf((float)hd);
+    a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1 | OPADPO_ATTN_SKIP_MASKED_Q; a.scale = 1.0f / sqrtf((float)hd);
     a.dout = d_attn; a.dq_acc = nullptr; a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H; a.delta = delta;
     a.seg_prefix = sv->seg_prefix; a.seg_len = sv->seg_len; a.use_tr = c->use_tr;
     CK(launch_attn_bwd(a, st));

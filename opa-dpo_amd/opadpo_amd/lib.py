@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopadpo_hip.so")
 
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SWIGLU_PAIR = 0, 1, 2, 3
+CAUSAL_SKIP_MASKED_Q = 3      # `causal` of opadpo_attn_fwd / _bwd: 1 = causal, | 2 = OPADPO_ATTN_SKIP_MASKED_Q (all-padding q tiles write zeros)
 
 _p = C.c_void_p
 _i = C.c_int

@@ -431,7 +431,7 @@ class LlavaEngine:
         if kv_hook is not None:
             kv_hook(i, qkv)
         L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(attn), H,
-               L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, 1, hd ** -0.5, seg[0], seg[1], st)
+               L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, L.CAUSAL_SKIP_MASKED_Q, hd ** -0.5, seg[0], seg[1], st)
         if adapter is not None:
             L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
             L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
@@ -583,7 +583,7 @@ class LlavaEngine:
             qkv = sv.qkv[i]
             L.call("opadpo_attn_bwd", L.ptr(qkv), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, L.ptr(sv.attn[i]),
                    L.ptr(d_attn), H, L.ptr(sv.lse[i]), L.ptr(sv.key_mask), L.ptr(dqkv), dqkv.data_ptr() + 2 * H,
-                   dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, 1, hd ** -0.5, seg[0], seg[1], st)
+                   dqkv.data_ptr() + 4 * H, None, L.ptr(delta), S, Lp, nh, hd, L.CAUSAL_SKIP_MASKED_Q, hd ** -0.5, seg[0], seg[1], st)
             _dbg(f"L{i} d_attn", d_attn); _dbg(f"L{i} attn", sv.attn[i]); _dbg(f"L{i} lse", sv.lse[i]); _dbg(f"L{i} delta", delta)
             _dbg(f"L{i} dq", dqkv[:, :H]); _dbg(f"L{i} dk", dqkv[:, H:2 * H]); _dbg(f"L{i} dv", dqkv[:, 2 * H:])
             L.call("opadpo_rope", L.ptr(dqkv), 3 * H, L.ptr(cos), L.ptr(sin), M, Lp, 2 * nh, hd, 1, None, seg[0], seg[1], st)

@@ -1080,3 +1080,50 @@ def test_gemm_tn_group_equals_single_launches(L):
            one(o2.data_ptr(), C.c_void_p), one(128, C.c_int), M, one(256, C.c_int), one(128, C.c_int), None, None, 1.0, L.stream())
     torch.cuda.synchronize()
     assert relerr(o2, o1) < 1e-5 and relerr(o1, P.float().t() @ Q.float()) < 1e-4
+
+
+@pytest.mark.parametrize("seg", [(0, 0), (200, 140)])
+def test_attn_skip_masked_q_tiles(L, seg):
+    """causal | OPADPO_ATTN_SKIP_MASKED_Q: q tiles of 64 positions that are all masked as keys (trailing padding) write zeros and are
+    skipped in the backward; every other row, and every gradient (with zero dO on the padding rows, what the LLM backward produces),
+    is BIT-identical to the plain causal kernels."""
+    L.set_flags(True, True)
+    S, Ln, nh, hd = 3, 480, 2, 128
+    H = nh * hd
+    qkv = rnd(S * Ln, 3 * H, scale=0.7, seed=21)
+    dout = rnd(S * Ln, H, scale=1.0, seed=22)
+    km = torch.ones(S, Ln, dtype=torch.uint8, device=dev())
+    km[0, :9] = 0                      # left padding (partial tile)
+    km[0, 300:340] = 0                 # a masked stretch that does not cover a whole tile
+    km[1, 250:340] = 0                 # covers tile [256, 320) entirely (inside segment 0 when packed: 200 + 140 = 340)
+    km[1, 400:] = 0                    # trailing padding: tiles [448, 480) dead, [384, 448) partially
+    km[2, 128:] = 0                    # almost everything is padding
+    dout.view(S, Ln, H)[km == 0] = 0   # padding rows carry no output gradient
+    st = L.stream()
+    scale = hd ** -0.5
+    res = {}
+    for causal in (1, L.CAUSAL_SKIP_MASKED_Q):
+        o = torch.full((S * Ln, H), 9.0, dtype=BF, device=dev())
+        lse = torch.zeros(S, nh, Ln, device=dev())
+        L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+               lse.data_ptr(), L.ptr(km), S, Ln, nh, hd, causal, scale, seg[0], seg[1], st)
+        dqkv = torch.full((S * Ln, 3 * H), 5.0, dtype=BF, device=dev())
+        delta = torch.zeros(S, nh, Ln, device=dev())
+        L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+               dout.data_ptr(), H, lse.data_ptr(), L.ptr(km), dqkv.data_ptr(), dqkv.data_ptr() + 2 * H,
+               dqkv.data_ptr() + 4 * H, None, delta.data_ptr(), S, Ln, nh, hd, causal, scale, seg[0], seg[1], st)
+        torch.cuda.synchronize()
+        res[causal] = (o.view(S, Ln, H), dqkv.view(S, Ln, 3 * H))
+    (o1, g1), (o3, g3) = res[1], res[L.CAUSAL_SKIP_MASKED_Q]
+    valid = km.bool()
+    assert torch.equal(o1[valid], o3[valid]), "valid rows must not change"
+    dead_tiles = 0
+    for s_ in range(S):
+        for t0 in range(0, Ln, 64):
+            if not bool(valid[s_, t0:t0 + 64].any()):
+                dead_tiles += 1
+                assert float(o3[s_, t0:t0 + 64].float().abs().max()) == 0.0
+                assert float(g3[s_, t0:t0 + 64, :H].float().abs().max()) == 0.0          # dQ of a dead tile
+    assert dead_tiles >= 7
+    assert torch.equal(g1[valid], g3[valid]), "gradients of valid rows must be bit-identical"
+    assert torch.equal(g1[:, :, H:], g3[:, :, H:]), "dK / dV must be bit-identical (the skipped q tiles contribute exact zeros)"
