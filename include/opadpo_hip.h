@@ -301,10 +301,14 @@ int opadpo_vision_encode(opadpo_ctx* ctx, const uint16_t* pixels, int B, uint16_
  * [query | response_0 | .. | response_{K-1}] of n_txt ids each (one OPADPO_IMAGE_TOKEN per row; K > 1: the responses share one pass
  * over the image + query prefix).  feat_row[s] = which image's features row s uses; image_mask [S,576] (nullable) = CoPO
  * 'attention' key mask.  logp / ent: [K*S*T] fp32 in the reference's stacking order [k][s][t].  train = 1 keeps the activations
- * (handle in *saved); train = 0 releases them (*saved = NULL). */
+ * (handle in *saved); train = 0 releases them (*saved = NULL).
+ * row_plan (HOST memory, nullable): int32 [S][K+1] = per row the number of LEADING masked query positions to drop and the valid
+ * length of every response (positions behind it are padding).  When given, the pass runs on RAGGED rows: padding positions are not
+ * rows of any GEMM / norm / SwiGLU / RoPE / attention tile (the reference computes them and throws the result away: 24 % of the rows
+ * of a synthetic seq512 pair), outputs on valid tokens are unchanged, pad cells still read -0.0 / 0.  NULL = the padded layout. */
 int opadpo_seq_logprobs_fwd(opadpo_ctx* ctx, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const int32_t* feat_row,
                             const uint8_t* image_mask, const uint16_t* feats, int S, int n_txt, int T, int K, float temperature, int train,
-                            float* logp, float* ent, opadpo_saved** saved, void* stream);
+                            float* logp, float* ent, opadpo_saved** saved, const int32_t* row_plan, void* stream);
 /* accelerator.backward(loss): accumulates d loss / d LoRA into the adapter's flat fp32 grad buffer for decoder layers
  * layer_hi .. layer_lo (top-down).  The first call of a backward starts at n_layers - 1 (it runs the head backward from dlogp
  * [K*S*T] and the optional entropy gradient dent); later calls continue below - a data-parallel host launches the exchange of a

@@ -83,9 +83,9 @@ struct TileSrc {
   __amdgpu_buffer_rsrc_t rsrc;
   int voff;      // bytes: (row tid / CPR) * ld + head * HD + (tid % CPR) * 8 elements
   int row_step;  // bytes between the row groups of consecutive passes
-  __device__ __forceinline__ TileSrc(const bf16_t* src, int ld, int s, int L, int head, int tid) {
+  __device__ __forceinline__ TileSrc(const bf16_t* src, int ld, size_t row0, int L, int head, int tid) {
     constexpr int CPR = HD / 8;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)s * L * ld), 0, L * ld * 2, 0x00020000);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + row0 * ld), 0, L * ld * 2, 0x00020000);
     voff = ((tid / CPR) * ld + head * HD + (tid % CPR) * 8) * 2;
     row_step = (256 / CPR) * ld * 2;
   }
@@ -131,13 +131,13 @@ template <int HD>
 struct TileDma {
   __amdgpu_buffer_rsrc_t rsrc;
   int voff, row_step, w;
-  __device__ __forceinline__ TileDma(const bf16_t* src, int ld, int s, int L, int head, int tid) {
+  __device__ __forceinline__ TileDma(const bf16_t* src, int ld, size_t row0, int L, int head, int tid) {
     constexpr int CPR = HD / 8, RPI = 64 / CPR;     // 16-B chunks per row, rows per wave instruction
     const int lane = tid & 63;
     w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = w * RPI + lane / CPR;             // row inside the 4*RPI-row group of one pass
     const int c = (lane % CPR) ^ swz_mask<HD>(r);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)s * L * ld), 0, L * ld * 2, 0x00020000);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + row0 * ld), 0, L * ld * 2, 0x00020000);
     voff = (r * ld + head * HD + c * 8) * 2;
     row_step = 4 * RPI * ld * 2;
   }
@@ -151,10 +151,10 @@ struct TileDma {
 };
 
 // key-mask bytes of one K/V tile -> Ms[0..63]; Ms[64] = 1 when any key of the tile is masked or past L (block-uniform)
-__device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, int s, int L, int k0, int tid) {
+__device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask, size_t row0, int L, int k0, int tid) {
   if (tid < 64) {
     const int kp = k0 + tid;
-    const uint8_t m = (kp < L) ? (key_mask ? key_mask[(size_t)s * L + kp] : (uint8_t)1) : (uint8_t)0;
+    const uint8_t m = (kp < L) ? (key_mask ? key_mask[row0 + kp] : (uint8_t)1) : (uint8_t)0;
     Ms[tid] = m;
     const uint64_t dead = __ballot(m == 0);
     if (tid == 0) Ms[64] = dead != 0;
@@ -167,23 +167,66 @@ __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask,
 // [seg_prefix, start of segment a) are excluded on top of the causal / key masks.  Causality makes the prefix states
 // independent of the responses, so this equals running prefix+response_a as separate sequences (what the reference does,
 // rl_models.py:95-112) while computing the prefix ONCE.  K/V tiles that lie wholly inside the excluded range are skipped.
-__device__ __forceinline__ int seg_xlo(const AttnArgs& p) { return p.seg_len > 0 ? p.seg_prefix : 0x7fffffff; }
-__device__ __forceinline__ int seg_qstart(const AttnArgs& p, int qpos) {     // first key of the query's own segment
-  if (p.seg_len <= 0) return 0x7fffffff;
-  return qpos >= p.seg_prefix + p.seg_len ? p.seg_prefix + ((qpos - p.seg_prefix) / p.seg_len) * p.seg_len : p.seg_prefix;
+// Geometry of one sequence.  Padded layout: S rows of p.L positions, responses of p.seg_len positions after p.seg_prefix.  RAGGED
+// layout (p.seq_meta != NULL; padding rows removed from every row-wise operator of the model): sequence s occupies rows
+// [meta[0], meta[0] + L_s) of the flat [rows, ld] buffers and meta[1 .. 1 + n_seg] are its segment boundaries b_0 (= end of the
+// prefix) .. b_nseg (= L_s), all relative to the sequence start - prefix and response lengths differ per sequence.
+struct Geo {
+  size_t row0;
+  int L;
+  const int32_t* b;          // ragged: boundaries b[0..nseg]; padded: nullptr
+  int nseg, pfx, slen;
+};
+__device__ __forceinline__ Geo load_geo(const AttnArgs& p, int s) {
+  Geo g;
+  if (p.seq_meta) {
+    const int32_t* m = p.seq_meta + (size_t)s * p.meta_stride;
+    g.row0 = (size_t)m[0]; g.b = m + 1; g.nseg = p.n_seg; g.L = m[1 + p.n_seg]; g.pfx = m[1]; g.slen = 0;
+  } else {
+    g.row0 = (size_t)s * p.L; g.L = p.L; g.b = nullptr; g.nseg = p.seg_len > 0 ? 1 : 0; g.pfx = p.seg_prefix; g.slen = p.seg_len;
+  }
+  return g;
+}
+__device__ __forceinline__ bool seg_on(const Geo& g) { return g.b ? g.nseg > 0 : g.slen > 0; }
+// first key of the response area (keys from here to the start of the query's own segment are excluded)
+__device__ __forceinline__ int seg_xlo(const Geo& g) { return seg_on(g) ? g.pfx : 0x7fffffff; }
+// start of the segment position `pos` lies in (the prefix end for prefix positions and for segment 0)
+__device__ __forceinline__ int seg_qstart(const Geo& g, int pos) {
+  if (!seg_on(g)) return 0x7fffffff;
+  if (g.b) {
+    int st = g.pfx;
+    for (int a = 1; a < g.nseg; ++a) if (pos >= g.b[a]) st = g.b[a];
+    return st;
+  }
+  return pos >= g.pfx + g.slen ? g.pfx + ((pos - g.pfx) / g.slen) * g.slen : g.pfx;
+}
+// end of the segment position `pos` (>= prefix end) lies in
+__device__ __forceinline__ int seg_end(const Geo& g, int pos) {
+  if (g.b) {
+    int e = g.b[g.nseg];
+    for (int a = g.nseg - 1; a >= 1; --a) if (pos < g.b[a]) e = g.b[a];
+    return e;
+  }
+  return g.pfx + ((pos - g.pfx) / g.slen + 1) * g.slen;
 }
 struct SegSkip {       // block-uniform: K/V tiles [lo, hi) are excluded for every row of the q tile starting at q0
   int lo, hi;
-  __device__ __forceinline__ SegSkip(const AttnArgs& p, int q0, int n_kt) : lo(n_kt), hi(n_kt) {
-    if (p.seg_len > 0 && q0 >= p.seg_prefix + p.seg_len) {
-      const int qs = p.seg_prefix + ((q0 - p.seg_prefix) / p.seg_len) * p.seg_len;
-      const int l = (p.seg_prefix + 63) / 64, h = qs / 64;
-      if (h > l) { lo = l; hi = h; }
+  __device__ __forceinline__ SegSkip(const Geo& g, int q0, int n_kt) : lo(n_kt), hi(n_kt) {
+    if (seg_on(g)) {
+      const int qs = seg_qstart(g, q0);
+      if (qs > g.pfx) {
+        const int l = (g.pfx + 63) / 64, h = qs / 64;
+        if (h > l) { lo = l; hi = h; }
+      }
     }
   }
   __device__ __forceinline__ int first() const { return lo == 0 ? hi : 0; }
   __device__ __forceinline__ int next(int kt) const { const int n = kt + 1; return (n >= lo && n < hi) ? hi : n; }
 };
+// lse / delta element of (sequence s, head h, position pos): padded [S, nh, L]; ragged [nh, rows_total] (row-major over the flat rows)
+__device__ __forceinline__ size_t stat_idx(const AttnArgs& p, const Geo& g, int s, int h, int pos) {
+  return p.seq_meta ? (size_t)h * p.rows_total + g.row0 + pos : ((size_t)s * p.nh + h) * p.L + pos;
+}
 
 // ------------------------------------------------------------------------------------------------
 // DMA: K/V tiles land in a double-buffered LDS ring through direct-to-LDS loads, one barrier per tile (the tile of the
@@ -219,7 +262,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   attn_block_map(p, n_qt, qi, h, s);
   const int qt = n_qt - 1 - qi;   // heavier (later) causal tiles first
   const int q0 = qt * 64;
-  const int L = p.L;
+  const Geo ge = load_geo(p, s);
+  const int L = ge.L;
+  if (q0 >= L) return;                      // ragged rows: this sequence is shorter than the longest one
   const int qpos = q0 + w * 16 + c;
   const int qrow = min(qpos, L - 1);
   // causal bit 1 (OPADPO_ATTN_SKIP_MASKED_Q): a q tile whose 64 positions are ALL masked as keys is padding (the trailing pad of a
@@ -227,13 +272,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   // keys, their labels are pad, their gradient is exactly zero), so the tile writes zeros and leaves.
   if ((p.causal & 2) && p.key_mask) {
     const int qp_ = q0 + lane;
-    const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+    const uint8_t mq = qp_ < L ? p.key_mask[ge.row0 + qp_] : (uint8_t)0;
     if (__ballot(mq != 0) == 0) {
       if (qpos < L) {
-        bf16_t* op = p.o + ((size_t)s * L + qpos) * p.ldo + h * HD;
+        bf16_t* op = p.o + (ge.row0 + qpos) * p.ldo + h * HD;
 #pragma unroll
         for (int d = 0; d < DF; ++d) *(uint2*)(op + d * 16 + g * 4) = make_uint2(0u, 0u);
-        if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = NEG_BIG;
+        if (g == 0 && p.lse) p.lse[stat_idx(p, ge, s, h, qpos)] = NEG_BIG;
       }
       return;
     }
@@ -241,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
   bf16x8_t qf[KK];
   {
-    const bf16_t* qp = p.q + ((size_t)s * L + qrow) * p.ld + h * HD;
+    const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       uint4 v = *(const uint4*)(qp + kk * 32 + g * 8);
@@ -254,17 +299,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   float m_run = NEG_BIG, l_run = 0.f;
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
-  const SegSkip sk(p, q0, n_kt);
-  const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
-  const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;     // end of the excluded key range of the tile's LAST row
+  const SegSkip sk(ge, q0, n_kt);
+  const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
+  const int xhi_blk = seg_on(ge) ? seg_qstart(ge, q0 + 63) : 0;     // end of the excluded key range of the tile's LAST row
   const float scale2 = p.scale * 1.4426950408889634f;
-  const TileSrc<HD> ksrc(p.k, p.ld, s, L, h, tid), vsrc(p.v, p.ld, s, L, h, tid);
-  const TileDma<HD> kdma(p.k, p.ld, s, L, h, tid), vdma(p.v, p.ld, s, L, h, tid);
+  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
+  const TileDma<HD> kdma(p.k, p.ld, ge.row0, L, h, tid), vdma(p.v, p.ld, ge.row0, L, h, tid);
   TileRegs<HD> kreg, vreg;
   if constexpr (DMA) {
     kdma.issue(smem, p.ld, sk.first() * 64);
     vdma.issue(smem + TILE, p.ld, sk.first() * 64);
-    stage_mask(ms_base, p.key_mask, s, L, sk.first() * 64, tid);
+    stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   } else {
     tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
     tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
@@ -282,13 +327,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       if (nxt < n_kt) {
         kdma.issue(smem + (cur ^ 1) * 2 * TILE, p.ld, nxt * 64);
         vdma.issue(smem + (cur ^ 1) * 2 * TILE + TILE, p.ld, nxt * 64);
-        stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, s, L, nxt * 64, tid);
+        stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
       }
       cur ^= 1;
     } else {
       tile_commit<HD>(Ks, kreg, tid);
       tile_commit<HD>(Vs, vreg, tid);
-      stage_mask(Ms, p.key_mask, s, L, k0, tid);
+      stage_mask(Ms, p.key_mask, ge.row0, L, k0, tid);
       __syncthreads();
       if (nxt < n_kt) {      // next tile's global loads fly while this one is consumed
         tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   l_run += __shfl_xor(l_run, 32, 64);
   if (qpos < L) {
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16_t* op = p.o + ((size_t)s * L + qpos) * p.ldo + h * HD;
+    bf16_t* op = p.o + (ge.row0 + qpos) * p.ldo + h * HD;
 #pragma unroll
     for (int d = 0; d < DF; ++d) {
       uint2 v;
@@ -377,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       v.y = pack_bf2(o[d][2] * inv, o[d][3] * inv);
       *(uint2*)(op + d * 16 + g * 4) = v;
     }
-    if (g == 0 && p.lse) p.lse[((size_t)s * p.nh + h) * L + qpos] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
+    if (g == 0 && p.lse) p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
   }
 }
 
@@ -389,7 +434,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
   constexpr int HPW = 64 / LPH;                             // heads per wave
   const int lane = threadIdx.x & 63;
   const size_t unit = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HPW + lane / LPH;      // (row, head) index
-  const size_t total = (size_t)p.S * p.L * p.nh;
+  const size_t total = (p.seq_meta ? (size_t)p.rows_total : (size_t)p.S * p.L) * p.nh;
   const bool live = unit < total;
   const size_t row = live ? unit / p.nh : 0;
   const int h = live ? (int)(unit % p.nh) : 0, i0 = (lane % LPH) * 8;
@@ -404,8 +449,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
 #pragma unroll
   for (int off = LPH / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (live && lane % LPH == 0) {
-    const size_t sq = row / p.L, pos = row % p.L;
-    p.delta[(sq * p.nh + h) * p.L + pos] = acc;
+    if (p.seq_meta) {
+      p.delta[(size_t)h * p.rows_total + row] = acc;        // ragged: [nh, rows_total]
+    } else {
+      const size_t sq = row / p.L, pos = row % p.L;
+      p.delta[(sq * p.nh + h) * p.L + pos] = acc;
+    }
   }
 }
 
@@ -423,16 +472,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   const int c = lane & 15, g = lane >> 4;
   int s, h, kt;
   attn_block_map(p, (p.L + 63) / 64, kt, h, s);
-  const int L = p.L;
+  const Geo ge = load_geo(p, s);
+  const int L = ge.L;
   const int k0 = kt * 64;
+  if (k0 >= L) return;
   const int kpos = k0 + w * 16 + c;          // this lane's key (as fragment row / output row)
   const int krow = min(kpos, L - 1);
 
-  stage_mask(Ms, p.key_mask, s, L, k0, tid);
+  stage_mask(Ms, p.key_mask, ge.row0, L, k0, tid);
   bf16x8_t kf[KK], vf[KK];
   {
-    const bf16_t* kp_ = p.k + ((size_t)s * L + krow) * p.ld + h * HD;
-    const bf16_t* vp_ = p.v + ((size_t)s * L + krow) * p.ld + h * HD;
+    const bf16_t* kp_ = p.k + (ge.row0 + krow) * p.ld + h * HD;
+    const bf16_t* vp_ = p.v + (ge.row0 + krow) * p.ld + h * HD;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       uint4 a = *(const uint4*)(kp_ + kk * 32 + g * 8);
@@ -453,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     unsigned long long mine = 0;
     for (int t = w; t < (L + 63) / 64; t += 4) {
       const int qp_ = t * 64 + lane;
-      const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+      const uint8_t mq = qp_ < L ? p.key_mask[ge.row0 + qp_] : (uint8_t)0;
       if (__ballot(mq != 0) != 0) mine |= 1ull << t;
     }
     if (lane == 0) live_s[w] = mine;
@@ -467,23 +518,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
   int n_qt = (L + 63) / 64;
   int kend = 0x7fffffff;                     // packed responses: a key in segment a is visible to queries < end of segment a
   int kend_min = 0x7fffffff;                 // smallest kend over the keys of the tile (block-uniform)
-  if (p.seg_len > 0 && k0 + 63 >= p.seg_prefix)
-    kend_min = p.seg_prefix + ((max(k0, p.seg_prefix) - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
-  if (p.seg_len > 0) {
-    if (kpos >= p.seg_prefix) kend = p.seg_prefix + ((kpos - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
-    if (k0 >= p.seg_prefix) {                // whole tile inside the response area: later segments never see it
-      const int q_cut = p.seg_prefix + ((min(k0 + 63, L - 1) - p.seg_prefix) / p.seg_len + 1) * p.seg_len;
+  if (seg_on(ge) && k0 + 63 >= ge.pfx) kend_min = seg_end(ge, max(k0, ge.pfx));
+  if (seg_on(ge)) {
+    if (kpos >= ge.pfx) kend = seg_end(ge, min(kpos, L - 1));
+    if (k0 >= ge.pfx) {                      // whole tile inside the response area: later segments never see it
+      const int q_cut = seg_end(ge, min(k0 + 63, L - 1));
       n_qt = min(n_qt, (q_cut + 63) / 64);
     }
   }
-  const TileDma<HD> qdma(p.q, p.ld, s, L, h, tid), dodma(p.dout, p.ldo, s, L, h, tid);
+  const TileDma<HD> qdma(p.q, p.ld, ge.row0, L, h, tid), dodma(p.dout, p.ldo, ge.row0, L, h, tid);
   float lse_r = 0.f, dlt_r = 0.f;      // wave 0: lse / delta of the tile in flight (written to LDS one iteration later, so
                                        // that nobody waits on these loads right behind the DMA issue)
   auto stage = [&](int buf, int q0) {
     qdma.issue(smem + buf * 2 * TILE, p.ld, q0);
     dodma.issue(smem + buf * 2 * TILE + TILE, p.ldo, q0);
     if (tid < 64) {
-      const size_t li = ((size_t)s * p.nh + h) * L + min(q0 + tid, L - 1);
+      const size_t li = stat_idx(p, ge, s, h, min(q0 + tid, L - 1));
       lse_r = p.lse[li] * 1.4426950408889634f;      // log2 units
       dlt_r = p.delta[li];
     }
@@ -565,8 +615,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
     }
   }
   if (kpos < L) {
-    bf16_t* dkp = p.dk + ((size_t)s * L + kpos) * p.ld + h * HD;
-    bf16_t* dvp = p.dv + ((size_t)s * L + kpos) * p.ld + h * HD;
+    bf16_t* dkp = p.dk + (ge.row0 + kpos) * p.ld + h * HD;
+    bf16_t* dvp = p.dv + (ge.row0 + kpos) * p.ld + h * HD;
 #pragma unroll
     for (int d = 0; d < DF; ++d) {
       uint2 a, b;
@@ -593,21 +643,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   attn_block_map(p, n_qt, qi, h, s);
   const int qt = n_qt - 1 - qi;
   const int q0 = qt * 64;
-  const int L = p.L;
+  const Geo ge = load_geo(p, s);
+  const int L = ge.L;
+  if (q0 >= L) return;
   const int qpos = q0 + w * 16 + c;
   const int qrow = min(qpos, L - 1);
   if ((p.causal & 2) && p.key_mask) {          // all-padding q tile (see attn_fwd_kernel): its dQ is exactly zero
     const int qp_ = q0 + lane;
-    const uint8_t mq = qp_ < L ? p.key_mask[(size_t)s * L + qp_] : (uint8_t)0;
+    const uint8_t mq = qp_ < L ? p.key_mask[ge.row0 + qp_] : (uint8_t)0;
     if (__ballot(mq != 0) == 0) {
       if (qpos < L) {
         if (p.dq) {
-          bf16_t* dqp = p.dq + ((size_t)s * L + qpos) * p.ld + h * HD;
+          bf16_t* dqp = p.dq + (ge.row0 + qpos) * p.ld + h * HD;
 #pragma unroll
           for (int d = 0; d < DF; ++d) *(uint2*)(dqp + d * 16 + g * 4) = make_uint2(0u, 0u);
         }
         if (p.dq_acc) {
-          float* dqa = p.dq_acc + ((size_t)s * L + qpos) * (size_t)(p.nh * HD) + h * HD;
+          float* dqa = p.dq_acc + (ge.row0 + qpos) * (size_t)(p.nh * HD) + h * HD;
 #pragma unroll
           for (int d = 0; d < DF; ++d) *(float4*)(dqa + d * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -618,8 +670,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 
   bf16x8_t qf[KK], dof[KK];
   {
-    const bf16_t* qp = p.q + ((size_t)s * L + qrow) * p.ld + h * HD;
-    const bf16_t* dp_ = p.dout + ((size_t)s * L + qrow) * p.ldo + h * HD;
+    const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD;
+    const bf16_t* dp_ = p.dout + (ge.row0 + qrow) * p.ldo + h * HD;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       uint4 a = *(const uint4*)(qp + kk * 32 + g * 8);
@@ -628,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       dof[kk] = *(bf16x8_t*)&b;
     }
   }
-  const size_t li = ((size_t)s * p.nh + h) * L + qrow;
+  const size_t li = stat_idx(p, ge, s, h, qrow);
   const float lse2 = p.lse[li] * 1.4426950408889634f, dlt = p.delta[li];     // log2 units -> bare v_exp_f32
   const float scale2 = p.scale * 1.4426950408889634f;
   f32x4_t dq[DF];
@@ -636,10 +688,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   for (int d = 0; d < DF; ++d) dq[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int n_kt = p.causal ? (min(L, q0 + 64) + 63) / 64 : (L + 63) / 64;
-  const SegSkip sk(p, q0, n_kt);
-  const int xlo = seg_xlo(p), xhi = seg_qstart(p, qpos);
-  const int xhi_blk = p.seg_len > 0 ? seg_qstart(p, q0 + 63) : 0;
-  const TileSrc<HD> ksrc(p.k, p.ld, s, L, h, tid), vsrc(p.v, p.ld, s, L, h, tid);
+  const SegSkip sk(ge, q0, n_kt);
+  const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
+  const int xhi_blk = seg_on(ge) ? seg_qstart(ge, q0 + 63) : 0;
+  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
   TileRegs<HD> kreg, vreg;
   tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
   tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
@@ -648,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const int k0 = kt * 64;
     tile_commit<HD>(Ks, kreg, tid);
     tile_commit<HD>(Vs, vreg, tid);
-    stage_mask(Ms, p.key_mask, s, L, k0, tid);
+    stage_mask(Ms, p.key_mask, ge.row0, L, k0, tid);
     __syncthreads();
     if (nxt < n_kt) {
       tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
@@ -703,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
   if (qpos < L) {
     if (p.dq) {
-      bf16_t* dst = p.dq + ((size_t)s * L + qpos) * p.ld + h * HD;
+      bf16_t* dst = p.dq + (ge.row0 + qpos) * p.ld + h * HD;
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
         uint2 v;
@@ -713,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       }
     }
     if (p.dq_acc) {   // optional fp32 copy (diagnostics / tests)
-      float* dst = p.dq_acc + ((size_t)s * L + qpos) * (p.nh * HD) + h * HD;
+      float* dst = p.dq_acc + (ge.row0 + qpos) * (p.nh * HD) + h * HD;
 #pragma unroll
       for (int d = 0; d < DF; ++d) *(float4*)(dst + d * 16 + g * 4) = make_float4(dq[d][0], dq[d][1], dq[d][2], dq[d][3]);
     }
@@ -752,7 +804,7 @@ hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
 hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
-  const int total = a.S * a.L * a.nh;
+  const int total = (a.seq_meta ? a.rows_total : a.S * a.L) * a.nh;
   const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
   const bool tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : opadpo_flag_tr();
   static bool attr_set = false;

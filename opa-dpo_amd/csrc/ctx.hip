@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include "common.h"
 #include "kernels.h"
 
 namespace {
@@ -84,6 +85,72 @@ __global__ __launch_bounds__(256) void splice_grad_kernel(const float* dX, const
   for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dst + c, src[c]);
 }
 
+// ---- ragged rows: the padding rows (left pad of the query, right pad of every response) are removed from the flat [rows, H]
+// buffers of a pass, so no GEMM / norm / SwiGLU / RoPE row is spent on padding.  Per sequence (meta row, META_STRIDE(K) ints):
+// [row_start, b_0 .. b_K, lead] - b_0 = end of the prefix, b_a = start of response a, b_K = rows of the sequence (relative), lead =
+// dropped left-pad positions.  Padded position of compact row r: r < b_0 -> lead + r; response a, token t = r - b_a -> pfx + a*T + t.
+struct MetaBlob { int32_t v[960]; };
+__global__ void write_meta_kernel(MetaBlob blob, int32_t* dst, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = blob.v[i];
+}
+__global__ __launch_bounds__(256) void embed_splice_ragged_kernel(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
+                                                                  const int32_t* feat_row, const uint8_t* image_mask, float* x, uint8_t* key_mask,
+                                                                  int32_t* row_pos, const int32_t* meta, int stride, int K, int T, int n_txt, int P, int H,
+                                                                  int image_token) {
+  __shared__ int img_pos;
+  const int s = blockIdx.y, r = blockIdx.x;
+  const int32_t* m = meta + (size_t)s * stride;
+  const int n_rows = m[1 + K];
+  if (r >= n_rows) return;
+  if (threadIdx.x == 0) img_pos = n_txt;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_txt; i += 256)
+    if (ids[(size_t)s * n_txt + i] == image_token) img_pos = i;
+  __syncthreads();
+  const int ip = img_pos, pfx = n_txt - K * T + P - 1, lead = m[2 + K];
+  int pos, rpos;                                   // padded position of the row, RoPE position (responses restart at the prefix end)
+  if (r < m[1]) { pos = lead + r; rpos = pos; }
+  else {
+    int a = 0;
+    for (int j = 1; j < K; ++j) if (r >= m[1 + j]) a = j;
+    pos = pfx + a * T + (r - m[1 + a]);
+    rpos = pfx + (r - m[1 + a]);
+  }
+  const bf16_t* src;
+  uint8_t mk;
+  if (pos < ip) {
+    src = embed + (size_t)max(ids[(size_t)s * n_txt + pos], 0) * H;
+    mk = text_mask[(size_t)s * n_txt + pos];
+  } else if (pos < ip + P && ip < n_txt) {
+    src = feats + ((size_t)feat_row[s] * P + (pos - ip)) * H;
+    mk = image_mask ? image_mask[(size_t)s * P + (pos - ip)] : (uint8_t)1;
+  } else {
+    const int t = min(pos - (ip < n_txt ? P - 1 : 0), n_txt - 1);
+    src = embed + (size_t)max(ids[(size_t)s * n_txt + t], 0) * H;
+    mk = text_mask[(size_t)s * n_txt + t];
+  }
+  const size_t row = (size_t)m[0] + r;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    float f[8];
+    unpack8(*(const uint4*)(src + i), f);
+    *(float4*)(x + row * H + i) = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(x + row * H + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  if (threadIdx.x == 0) { key_mask[row] = mk; row_pos[row] = rpos; }
+}
+// rows[k,s,t]: the compact row that predicts token t of response k (token 0: the last prefix row; token t: row t-1 of the response,
+// clamped into its valid rows - a label behind the valid tokens is pad and its log-prob is -0.0 whatever row is read)
+__global__ void head_index_ragged_kernel(const int32_t* ids, const int32_t* meta, int stride, int S, int n_txt, int K, int T, int32_t* rows,
+                                         int32_t* labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * S * T) return;
+  const int t = i % T, s = (i / T) % S, k = i / (T * S);
+  const int32_t* m = meta + (size_t)s * stride;
+  const int b0 = m[1], bk = m[1 + k], vk = m[2 + k] - bk;
+  rows[i] = m[0] + ((t == 0 || vk == 0) ? b0 - 1 : bk + min(t, vk) - 1);
+  labels[i] = ids[(size_t)s * n_txt + (n_txt - K * T) + k * T + t];
+}
+
 inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -101,6 +168,9 @@ struct opadpo_saved {
   uint8_t* key_mask; float* hs; bf16_t* hn; float* rstd_f; float* logits; float* lse_head; float* ent;
   int32_t *rows, *labels;
   const int32_t* ids = nullptr; const int32_t* feat_row = nullptr;   // borrowed (SFT splice backward only)
+  // ragged rows (padding removed): M = valid rows of the batch, L = longest sequence; meta / row_pos live in the arena
+  int ragged = 0, meta_stride = 0, S_pad_rows = 0;
+  int32_t *meta = nullptr, *row_pos = nullptr;
 };
 
 struct opadpo_ctx {
@@ -324,11 +394,13 @@ hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const fl
   return run_gemm(c, g4, st);
 }
 
+struct Rag { const int32_t* meta; int stride, n_seg, rows; const int32_t* row_pos; };      // ragged rows of a pass (nullptr = padded)
+
 hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* x, float* xo, const LayerBufs& b, int S, int Lp,
-                     const uint8_t* key_mask, int seg0, int seg1, bf16_t* kc, bf16_t* vc, int max_ctx, hipStream_t st) {
+                     const uint8_t* key_mask, int seg0, int seg1, bf16_t* kc, bf16_t* vc, int max_ctx, hipStream_t st, const Rag* rg = nullptr) {
   const opadpo_dims& d = c->d;
   const int H = d.hidden, r = d.lora_r, nh = d.n_heads, hd = d.head_dim;
-  const int M = S * Lp;
+  const int M = rg ? rg->rows : S * Lp;
   const float s = d.lora_alpha / d.lora_r;
   const opadpo_layer_weights& w0 = c->layers[i];
   const opadpo_layer_weights& w = ad.kind == 2 ? ad.merged[i] : w0;
@@ -345,7 +417,7 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
     GemmNTArgs g2 = gemm(c, b.n1, H, w.wqkv, H, H, b.qkv, 3 * H, 0, M, 3 * H);
     if ((e = run_gemm(c, g2, st)) != hipSuccess) return e;
   }
-  if ((e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st)) != hipSuccess) return e;
+  if ((e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st, rg ? rg->row_pos : nullptr)) != hipSuccess) return e;
   if (kc) {                                        // rollout prefill: post-RoPE k, v -> head-major KV cache
     hipLaunchKernelGGL(kv_fill_kernel, dim3(std::min<size_t>(4096, ((size_t)M * nh * (hd / 8) + 255) / 256)), dim3(256), 0, st, b.qkv, kc, vc, S, Lp, nh, hd, max_ctx);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -355,6 +427,7 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   a.q = b.qkv; a.k = b.qkv + H; a.v = b.qkv + 2 * H; a.o = b.attn; a.lse = b.lse; a.key_mask = key_mask;
   a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1 | OPADPO_ATTN_SKIP_MASKED_Q; a.scale = 1.0f / sqrtf((float)hd);
   a.seg_prefix = seg0; a.seg_len = seg1; a.use_tr = c->use_tr;
+  if (rg) { a.seq_meta = rg->meta; a.meta_stride = rg->stride; a.n_seg = rg->n_seg; a.rows_total = rg->rows; a.seg_prefix = 0; a.seg_len = 0; }
   if ((e = launch_attn_fwd(a, st)) != hipSuccess) return e;
   if (lw) {
     GemmNTArgs g3 = gemm(c, b.attn, H, lw + o.a_o, H, H, b.t_o, r, 0, M, r); g3.alpha = s;
@@ -395,6 +468,8 @@ size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   sv->ent = cv.take<float>(R);
   sv->rows = cv.take<int32_t>(R);
   sv->labels = cv.take<int32_t>(R);
+  sv->meta = cv.take<int32_t>(sv->ragged ? (size_t)sv->S * sv->meta_stride : 1);
+  sv->row_pos = cv.take<int32_t>(sv->ragged ? M : 1);
   return cv.off;
 }
 
@@ -603,7 +678,7 @@ int opadpo_vision_encode(opadpo_ctx* c, const uint16_t* pixels, int B, uint16_t*
 // ---- sequence log-probs forward (model.py seq_logprobs_fwd; rl_models.py:114-132) ---------------------------------------------
 int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const int32_t* feat_row,
                             const uint8_t* image_mask, const uint16_t* feats, int S, int n_txt, int T, int K, float temperature, int train,
-                            float* logp, float* ent, opadpo_saved** saved_out, void* stream) {
+                            float* logp, float* ent, opadpo_saved** saved_out, const int32_t* row_plan, void* stream) {
   if (!c) return (int)hipErrorInvalidValue;
   if (!weights_ready(c)) return cbad(c, __func__, "LLM weights not set");
   if (adapter_id < 0 || adapter_id >= OPADPO_MAX_ADAPTERS) return cbad(c, __func__, "adapter id out of range");
@@ -624,6 +699,27 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   const int pfx = Lp - K * T;
   sv->seg_prefix = K > 1 ? pfx : 0; sv->seg_len = K > 1 ? T : 0;
   sv->ids = ids; sv->feat_row = feat_row;
+  // ragged rows: row_plan (HOST, [S][K+1]) = per sequence the number of dropped left-pad positions and the valid length of every
+  // response (trailing pad dropped); the valid rows of the batch become the M of every row-wise kernel of the pass
+  MetaBlob blob;
+  if (row_plan) {
+    const int stride = K + 3;
+    if (S * stride > (int)(sizeof(blob.v) / sizeof(int32_t)) || K > 8) { delete sv; return cbad(c, __func__, "row_plan: too many sequences / responses for the ragged layout"); }
+    int row = 0, lmax = 0;
+    for (int q = 0; q < S; ++q) {
+      const int32_t* rp = row_plan + (size_t)q * (K + 1);
+      int32_t* m = blob.v + q * stride;
+      if (rp[0] < 0 || rp[0] >= pfx) { delete sv; return cbad(c, __func__, "row_plan: dropped left padding must leave a non-empty prefix"); }
+      m[0] = row; m[1] = pfx - rp[0]; m[2 + K] = rp[0];
+      for (int k = 0; k < K; ++k) {
+        if (rp[1 + k] < 0 || rp[1 + k] > T) { delete sv; return cbad(c, __func__, "row_plan: response length outside [0, T]"); }
+        m[2 + k] = m[1 + k] + rp[1 + k];
+      }
+      row += m[1 + K];
+      lmax = std::max(lmax, (int)m[1 + K]);
+    }
+    sv->ragged = 1; sv->meta_stride = stride; sv->M = row; sv->L = lmax;
+  }
   sv->bytes = saved_layout(d, sv, nullptr);
   sv->arena = ctx_alloc(c, sv->bytes, st);
   if (!sv->arena) { delete sv; return cfail(c, hipErrorOutOfMemory, "opadpo_seq_logprobs_fwd (activation arena)"); }
@@ -635,16 +731,27 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
     hipError_t e_ = (expr);                                                         \
     if (e_ != hipSuccess) { saved_destroy(c, sv); return cfail(c, e_, __func__); }  \
   } while (0)
-  CKS(launch_embed_splice(ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x, 1, sv->key_mask, S, n_txt, P, H, OPADPO_IMAGE_TOKEN, st));
+  Rag rag{sv->meta, sv->meta_stride, K, sv->M, sv->row_pos};
+  const Rag* rg = sv->ragged ? &rag : nullptr;
+  if (rg) {
+    hipLaunchKernelGGL(write_meta_kernel, dim3(1), dim3(256), 0, st, blob, sv->meta, S * sv->meta_stride);
+    CKS(hipGetLastError());
+    hipLaunchKernelGGL(embed_splice_ragged_kernel, dim3(sv->L, S), dim3(256), 0, st, ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x,
+                       sv->key_mask, sv->row_pos, sv->meta, sv->meta_stride, K, T, n_txt, P, H, OPADPO_IMAGE_TOKEN);
+    CKS(hipGetLastError());
+  } else {
+    CKS(launch_embed_splice(ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x, 1, sv->key_mask, S, n_txt, P, H, OPADPO_IMAGE_TOKEN, st));
+  }
   for (int i = 0; i < d.n_layers; ++i) {
     const int k = train ? i : 0;
     const float* x = sv->x + (size_t)(train ? i : (i & 1)) * MH;
     float* xo = sv->x + (size_t)(train ? i + 1 : ((i + 1) & 1)) * MH;
-    CKS(layer_fwd(c, i, ad, x, xo, slot(d, sv, k), S, Lp, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st));
+    CKS(layer_fwd(c, i, ad, x, xo, slot(d, sv, k), S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg));
   }
   const float* xf = sv->x + (size_t)(train ? d.n_layers : (d.n_layers & 1)) * MH;
   const int R = sv->R;
-  hipLaunchKernelGGL(head_index_kernel, g1(R), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
+  if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(R), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels);
+  else hipLaunchKernelGGL(head_index_kernel, g1(R), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
   CKS(hipGetLastError());
   CKS(launch_gather_rows((const bf16_t*)xf, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));       // fp32 rows = 2H bf16 units
   CKS(launch_rmsnorm_fwd(sv->hs, 1, c->norm, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
@@ -679,6 +786,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   if (!sv->train) return cbad(c, __func__, "activations were not saved for backward (train = 0)");
   const opadpo_dims& d = c->d;
   if (layer_hi >= d.n_layers || layer_lo < 0 || layer_lo > layer_hi) return cbad(c, __func__, "bad layer range");
+  if (sv->ragged && d_feats) return cbad(c, __func__, "d_feats (OPA-SFT splice backward) needs the padded layout: pass row_plan = NULL to the forward");
   const opadpo_ctx::Adapter& ad = c->adapters[sv->adapter];
   if (ad.kind != 1 || !ad.grad || !ad.work_t) return cbad(c, __func__, "adapter lost its gradient / transposed buffers");
   hipStream_t st = (hipStream_t)stream;
@@ -709,7 +817,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dz, V, c->lm_head_t, V, V, d_hn, H, 0, R, H); CK(run_gemm(c, g, st)); }
     CK(launch_rmsnorm_bwd(d_hn, sv->hs, 1, c->norm, sv->rstd_f, nullptr, 0, d_hs, nullptr, R, H, st));
     CK(hipMemsetAsync(dX, 0, MH * sizeof(float), st));
-    if (sv->K > 1) CK(launch_scatter_add_rows_f32(d_hs, sv->rows, dX, H, R, H, st));     // the last prefix row feeds token 0 of every response
+    if (sv->K > 1 || sv->ragged) CK(launch_scatter_add_rows_f32(d_hs, sv->rows, dX, H, R, H, st));     // rows repeat: the last prefix row feeds token 0 of every response (ragged: pad labels share a clamped row)
     else CK(launch_scatter_rows((const bf16_t*)d_hs, sv->rows, (bf16_t*)dX, 2 * H, R, 2 * H, st));
     CK(launch_f32_to_bf16(dX, dXb, MH, st));
   }
@@ -750,8 +858,9 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     a.S = S; a.L = Lp; a.nh = nh; a.hd = hd; a.ld = 3 * H; a.ldo = H; a.causal = 1 | OPADPO_ATTN_SKIP_MASKED_Q; a.scale = 1.0f / sqrtf((float)hd);
     a.dout = d_attn; a.dq_acc = nullptr; a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H; a.delta = delta;
     a.seg_prefix = sv->seg_prefix; a.seg_len = sv->seg_len; a.use_tr = c->use_tr;
+    if (sv->ragged) { a.seq_meta = sv->meta; a.meta_stride = sv->meta_stride; a.n_seg = sv->K; a.rows_total = M; a.seg_prefix = 0; a.seg_len = 0; }
     CK(launch_attn_bwd(a, st));
-    CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st));
+    CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr));
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0));

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
 // forward: x' = x*cos + rot(x)*sin ; inverse (gradient): g' = g*cos - rot(g)*sin  with rot(x) = [-x2, x1]
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const float* cosb, const float* sinb,
                                                     size_t total, int L, int n_heads, int hd, int inverse, const int32_t* pos_base,
-                                                    int seg_prefix, int seg_len) {
+                                                    int seg_prefix, int seg_len, const int32_t* row_pos) {
   const int half = hd / 2;
   const int pos0 = pos_base ? pos_base[0] : 0;     // device-resident position offset (graph-replayed decode step)
   const int per_row = n_heads * (half / 8);     // 8 (x1,x2) pairs per thread
@@ -159,9 +159,14 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const flo
     const size_t row = idx / per_row;
     const int rem = (int)(idx % per_row);
     const int head = rem / (half / 8), i0 = (rem % (half / 8)) * 8;
-    int pos = pos0 + (int)(row % L);
-    // packed responses sharing a prefix: every response restarts at position seg_prefix
-    if (seg_len > 0 && pos >= seg_prefix + seg_len) pos -= ((pos - seg_prefix) / seg_len) * seg_len;
+    int pos;
+    if (row_pos) {                       // ragged rows (padding removed): the position of every row is given
+      pos = row_pos[row];
+    } else {
+      pos = pos0 + (int)(row % L);
+      // packed responses sharing a prefix: every response restarts at position seg_prefix
+      if (seg_len > 0 && pos >= seg_prefix + seg_len) pos -= ((pos - seg_prefix) / seg_len) * seg_len;
+    }
     bf16_t* base = qk + row * ld + head * hd;
     float x1[8], x2[8];
     unpack8(*(const uint4*)(base + i0), x1);
@@ -596,11 +601,11 @@ hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_
   return hipGetLastError();
 }
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st) {
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos) {
   if (rows <= 0) return hipSuccess;
   if (hd % 16) return hipErrorInvalidValue;
   const size_t total = (size_t)rows * n_heads * (hd / 16);
-  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len, row_pos);
   return hipGetLastError();
 }
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {

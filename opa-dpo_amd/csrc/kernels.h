@@ -56,6 +56,12 @@ struct AttnArgs {
   bf16_t* dq; bf16_t* dk; bf16_t* dv;                   // ld addressing (same as q / k / v)
   float* delta;                                         // [S, nh, L] scratch
   int use_tr;                                           // per-call override of the transposed-LDS-read switch; < 0 = process default
+  // RAGGED rows (nullable; opadpo_ctx only): the padding rows are removed from the flat [rows, ld] buffers.  seq_meta[s * meta_stride
+  // + 0] = first row of sequence s, [1 .. 1 + n_seg] = boundaries relative to it: b_0 = end of the prefix (= start of response 0),
+  // b_a = start of response a, b_nseg = length of the sequence.  L = longest sequence (grid), lse / delta are [nh, rows_total],
+  // key_mask is per row.
+  const int32_t* seq_meta;
+  int meta_stride, n_seg, rows_total;
 };
 
 // up to 8 gemm_tn problems with the same M run as ONE launch of the 256x256 kernel (tile lists concatenated)
@@ -92,7 +98,7 @@ hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t*
 hipError_t launch_act_fwd(const bf16_t* z, bf16_t* out, size_t n, int act, hipStream_t st);
 hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_t n, int act, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st);
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos = nullptr);
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,

@@ -74,8 +74,11 @@ class CtxSaved:
 
 
 class CtxEngine(LlavaEngine):
-    def __init__(self, base: BaseWeights, torch_allocator: bool = True):
+    def __init__(self, base: BaseWeights, torch_allocator: bool = True, ragged: bool = True):
+        """ragged: run the LLM passes on the valid rows only (SeqBatch.row_plan: left pad of the query and right pad of every response
+        are not rows of any kernel); False keeps the reference's padded rows."""
         super().__init__(base)
+        self.ragged = ragged
         lib = L.load()
         d = base.dims
         self._dims = Dims(d.hidden, d.n_layers, d.n_heads, d.head_dim, d.ffn, d.vocab, d.rms_eps, d.rope_theta, d.v_hidden, d.v_used_layers,
@@ -229,8 +232,10 @@ class CtxEngine(LlavaEngine):
         ent = torch.empty(R, dtype=torch.float32, device=self.dev)
         handle = C.c_void_p()
         feats = feats.contiguous()
+        plan = getattr(batch, "row_plan", None) if self.ragged else None       # CPU int32 [S, K+1] (policy.build_batch) or None = padded rows
         self._call("opadpo_seq_logprobs_fwd", slot, _ptr(batch.ids), _ptr(batch.text_mask), _ptr(batch.feat_row), _ptr(batch.image_mask),
-                   _ptr(feats), S, n_txt, T, K, float(temperature), int(train), _ptr(logp), _ptr(ent), C.byref(handle), L.stream())
+                   _ptr(feats), S, n_txt, T, K, float(temperature), int(train), _ptr(logp), _ptr(ent), C.byref(handle),
+                   plan.data_ptr() if plan is not None else None, L.stream())
         sv = CtxSaved(self, handle.value, batch) if train else None
         return logp.view(K * S, T), ent.view(K * S, T), sv
 

@@ -77,7 +77,7 @@ SIGNATURES.update({
     "opadpo_ctx_set_adapter": [_p, _i, _p, _p, _p],
     "opadpo_ctx_set_merged_adapter": [_p, _i, _p, _i, _i],
     "opadpo_vision_encode": [_p, _p, _i, _p, _p],
-    "opadpo_seq_logprobs_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p],
+    "opadpo_seq_logprobs_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p],
     "opadpo_seq_logprobs_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "opadpo_saved_release": [_p, _p],
     "opadpo_decode_begin": [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _f, _u64, _i, _i, _i, _p, _p],

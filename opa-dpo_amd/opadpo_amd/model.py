@@ -286,6 +286,8 @@ class SeqBatch:
     T: int                     # response length
     K: int = 1                 # responses packed per row: ids = [query | response_0 | ... | response_{K-1}] sharing one
                                # pass over the image + query prefix (K = 1: one response per row, the reference's layout)
+    row_plan: Optional[torch.Tensor] = None     # CPU int32 [S, K+1]: dropped leading pad positions, valid length of every response
+                                                # (opadpo_seq_logprobs_fwd's ragged rows; None = padded rows)
 
 
 class Saved:

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .dims import PAD_ID
+from .dims import IMAGE_TOKEN_INDEX, PAD_ID
 from .model import LlavaEngine, LoraAdapter, SeqBatch
 
 
@@ -91,6 +91,14 @@ class AutoregressivePolicy(torch.nn.Module):
         K = len(keys)
         T = responses[keys[0]].shape[1]
         assert T == self.response_len, "policy slices with args.response_len (rl_models.py:121-123, Quirk Q7)"
+        plan_q = plan_r = None
+        if getattr(self.engine, "ragged", False):
+            # ragged rows (ctx.CtxEngine): leading masked query positions before the image token and the trailing padding of every
+            # response are not rows of the pass.  Two small reductions on the device + ONE host read per batch (cached on the batch).
+            img_pos = (queries == IMAGE_TOKEN_INDEX).int().argmax(dim=1)
+            lead = torch.minimum((qmask_txt.int().cumsum(1) == 0).sum(1), img_pos)
+            vlen = [T - ((responses[k].to(dev) != PAD_ID).flip(1).int().cumsum(1) == 0).sum(1) for k in keys]
+            plan_q, plan_r = lead.to(torch.int32), [v.to(torch.int32) for v in vlen]
         if self.pack_responses and K > 1:
             batch = SeqBatch(
                 ids=torch.cat([queries] + [responses[k].to(dev) for k in keys], 1).to(torch.int32).contiguous(),
@@ -98,6 +106,8 @@ class AutoregressivePolicy(torch.nn.Module):
                 feat_row=torch.arange(B, device=dev, dtype=torch.int32),
                 image_mask=None if image_mask is None else image_mask.to(torch.uint8).contiguous(),
                 T=T, K=K)
+            if plan_q is not None:
+                batch.row_plan = torch.stack([plan_q] + plan_r, 1).cpu().contiguous()
             return keys, batch
         batch = SeqBatch(
             ids=torch.cat(ids, 0).to(torch.int32).contiguous(),
@@ -105,6 +115,8 @@ class AutoregressivePolicy(torch.nn.Module):
             feat_row=torch.arange(B, device=dev, dtype=torch.int32).repeat(K).contiguous(),
             image_mask=None if image_mask is None else image_mask.to(torch.uint8).repeat(K, 1).contiguous(),
             T=T)
+        if plan_q is not None:          # stacked layout: K sequences per sample, one response each
+            batch.row_plan = torch.stack([plan_q.repeat(K), torch.cat(plan_r, 0)], 1).cpu().contiguous()
         return keys, batch
 
     def forward(self, images: Optional[torch.Tensor] = None, queries: torch.Tensor = None,

@@ -93,7 +93,7 @@ def test_context_lifecycle_and_errors_need_no_gpu(built_lib):
     assert lib.opadpo_ctx_create(ctypes.byref(good), 0, ctypes.byref(h)) == 0 and h.value
     assert lib.opadpo_ctx_set_flags(h, 4, 1) == 0
     # forward before the weights were handed over: refused with text
-    rc = lib.opadpo_seq_logprobs_fwd(h, 0, None, None, None, None, None, 1, 8, 2, 1, 1.0, 0, None, None, None, None)
+    rc = lib.opadpo_seq_logprobs_fwd(h, 0, None, None, None, None, None, 1, 8, 2, 1, 1.0, 0, None, None, None, None, None)
     assert rc != 0 and b"weights not set" in lib.opadpo_ctx_last_error(h)
     assert lib.opadpo_ctx_set_adapter(h, 99, None, None, None) != 0 and b"out of range" in lib.opadpo_ctx_last_error(h)
     assert lib.opadpo_decode_step(h, None) != 0 and b"no active rollout" in lib.opadpo_ctx_last_error(h)

@@ -22,13 +22,14 @@ def env():
     dev = torch.device("cuda:0")
     d = LlavaDims.tiny()
     base = BaseWeights(d, init_weights(d, seed=0, std=0.05, device=dev), dev, need_backward=True)
-    op, cx = LlavaEngine(base), CtxEngine(base)
+    op, cx, cxr = LlavaEngine(base), CtxEngine(base, ragged=False), CtxEngine(base)      # op-level, context on padded rows, context on ragged rows (default)
     sd_pol, sd_ref = init_lora(d, seed=1, b_std=0.03, device=dev), init_lora(d, seed=2, b_std=0.03, device=dev)
     ads = dict(pol=LoraAdapter(d, sd_pol, dev, True), ref=LoraAdapter(d, sd_ref, dev, False), merged=LoraAdapter(d, sd_ref, dev, False))
     ads["merged"].merge_into_base(base)
     p = synth_pairs(d, 3, 16, 24, seed=5, device=dev)
-    yield dict(d=d, dev=dev, base=base, op=op, cx=cx, ads=ads, p=p)
+    yield dict(d=d, dev=dev, base=base, op=op, cx=cx, cxr=cxr, ads=ads, p=p)
     cx.close()
+    cxr.close()
 
 
 def _policy(eng, ad, T, pack):
@@ -160,7 +161,7 @@ def test_wide_7b_forward_is_bit_identical():
     d = LlavaDims(hidden=4096, n_layers=2, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2, v_heads=2, v_ffn=256,
                   image_size=56, patch=14)
     base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
-    op, cx = LlavaEngine(base), CtxEngine(base)
+    op, cx = LlavaEngine(base), CtxEngine(base, ragged=False)
     ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, True)
     p = synth_pairs(d, 6, 128, 384, seed=7, device=dev)
     g = torch.Generator().manual_seed(1)
@@ -176,3 +177,79 @@ def test_wide_7b_forward_is_bit_identical():
     assert float((res[0][2] - res[1][2]).norm() / res[0][2].norm()) < 1e-5
     cx.close()
     op.release()
+
+
+@pytest.mark.parametrize("pack", [True, False])
+@pytest.mark.parametrize("which", ["ref", "merged", "pol"])
+def test_ragged_rows_equal_padded_rows(env, which, pack):
+    """Default context path: the padding rows (left pad of the query, right pad of every response) are not rows of any kernel.
+    Valid tokens: same log-probs / entropies as the padded layout up to the attention's tile partition (rows move relative to the
+    64-row tiles: fp32 summation order -> occasional bf16 rounding flips); pad cells: exactly -0.0 / 0; LoRA gradients agree."""
+    ad, p = env["ads"][which], env["p"]
+    assert int((p["chosen"] == 0).sum()) > 0 and int((~p["queries_attn_masks"]).sum()) > 0, "the batch must contain padding"
+    outs = []
+    for eng in (env["cx"], env["cxr"]):
+        with torch.no_grad():
+            outs.append(_policy(eng, ad, 24, pack)(**_kw(p, eng), temperature=0.9))
+    torch.cuda.synchronize()
+    for key, ids in (("chosen_response", p["chosen"]), ("rejected_response", p["rejected"])):
+        valid = ids != 0
+        a, b = outs[0][key + "_logprobs"], outs[1][key + "_logprobs"]
+        assert bool((b[~valid] == 0).all()) and bool((outs[1][key + "_entropies"][~valid] == 0).all())
+        rel = ((a - b).abs()[valid] / a.abs()[valid].clamp_min(1e-3))
+        assert float(rel.mean()) < 5e-4 and float(rel.max()) < 1e-2, (float(rel.mean()), float(rel.max()))
+        assert float((outs[0][key + "_entropies"] - outs[1][key + "_entropies"]).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("pack", [True, False])
+def test_ragged_rows_backward(env, pack):
+    ad, p = env["ads"]["pol"], env["p"]
+    g = torch.Generator().manual_seed(3)
+    w = {k: torch.randn(3, 24, generator=g).to(env["dev"]) for k in ("chosen_response", "rejected_response")}
+    res = []
+    for eng, hook in ((env["cx"], None), (env["cxr"], None), (env["cxr"], "ranged")):
+        ad.grad.zero_()
+        pol = _policy(eng, ad, 24, pack)
+        pol.layer_done_hook = (lambda i: None) if hook else None
+        out = pol(**_kw(p, eng))
+        sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+        torch.cuda.synchronize()
+        res.append(ad.grad.clone())
+    for j in (1, 2):
+        rel = float((res[j] - res[0]).norm() / res[0].norm())
+        assert rel < 1e-2, f"ragged backward (variant {j}) vs padded backward: rel {rel}"
+    assert float((res[1] - res[2]).norm() / res[1].norm()) < 1e-5
+    ad.grad.zero_()
+
+
+def test_ragged_rows_edge_cases(env):
+    """No padding at all, a response that is only EOS, a query left-padded down to [image, one token], CoPO 'attention' key mask
+    (interior masked image rows stay rows): ragged == padded on the valid tokens."""
+    d, dev = env["d"], env["dev"]
+    B, Q, T = 3, 10, 7
+    g = torch.Generator().manual_seed(77)
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g).to(BF).to(dev)
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    queries[0, 0] = -200
+    queries[1, :Q - 2] = 0; qmask[1, :Q - 2] = False
+    queries[1, Q - 2] = -200
+    queries[2, Q - 1] = -200
+    a = torch.randint(3, d.vocab, (B, T), generator=g)
+    a[0, 0] = 2; a[0, 1:] = 0
+    b = torch.randint(3, d.vocab, (B, T), generator=g)
+    b[:, 3] = 2; b[:, 4:] = 0
+    resp = {"standard_response": a, "original_generate_response": b}
+    im = torch.ones(B, d.n_patches, dtype=torch.bool)
+    im[0, :5] = False; im[1, 3] = False; im[2, d.n_patches - 4:] = False
+    for qm in (qmask, torch.cat([im, qmask], 1)):
+        outs = []
+        for eng in (env["cx"], env["cxr"]):
+            with torch.no_grad():
+                outs.append(_policy(eng, env["ads"]["ref"], T, True)(images=images, queries=queries, queries_attn_masks=qm, **resp))
+        torch.cuda.synchronize()
+        for k, ids in resp.items():
+            valid = (ids != 0).to(dev)
+            x, y = outs[0][k + "_logprobs"], outs[1][k + "_logprobs"]
+            assert bool(torch.isfinite(y).all()) and bool((y[~valid] == 0).all())
+            assert float((x - y).abs()[valid].max()) < 3e-2, (k, float((x - y).abs()[valid].max()))
