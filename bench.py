@@ -5,10 +5,13 @@ L = 1087 LLM positions), synthetic image+text batches, random-init weights of th
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One STEP = one optimizer step on every rank: `accum` (default 1) micro-batches of `pairs` (default 15) (image, chosen, rejected)
+One STEP = one optimizer step on every rank: `accum` (default 1) micro-batches of `pairs` (default 22) (image, chosen, rejected)
 pairs -> vision encode (once per image) -> frozen-reference forward (no grad) -> policy forward (activations
-resident) -> token-level DPO loss -> LoRA backward -> [RCCL exchange of the flat LoRA gradient] -> global-norm
-clip + AdamW -> refresh of the transposed LoRA copies.  Nothing is skipped or cached across steps.
+resident) -> token-level DPO loss -> LoRA backward (the RCCL exchange of a finished bucket of layers starts inside it) ->
+global-norm clip + AdamW -> refresh of the transposed LoRA copies.  Nothing is skipped or cached across steps; the micro-batches
+cycle through a pool of 8 different synthetic batches (SURVEY.md §8d lengths).  Default engine: the sequence-level C entry points
+(opadpo_ctx) on RAGGED rows - padding positions are not rows of any kernel (`--padded` keeps the reference's padded rows,
+`--op-level` the Python sequencing of single-kernel calls).
 Weak scaling: per-GPU work is fixed, value = total pairs of all ranks / max-over-ranks time.
 """
 import argparse
@@ -175,6 +178,8 @@ def main():
     ap.add_argument("--model", default=os.environ.get("OPADPO_BENCH_MODEL", "7b"), choices=["7b", "13b", "tiny"])
     ap.add_argument("--optimizer-mode", default="zero1", choices=["allreduce", "zero1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-pool", type=int, default=8, help="number of different synthetic micro-batches cycled over the steps")
+    ap.add_argument("--padded", action="store_true", help="keep the reference's padded rows (padding positions computed and thrown away) instead of ragged rows")
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
@@ -212,7 +217,8 @@ def main():
     W = init_weights(d, seed=0, device=dev)
     base = BaseWeights(d, W, dev, need_backward=True)
     del W
-    eng = LlavaEngine(base) if args.op_level else CtxEngine(base)      # default: ONE C call per pass (opadpo_seq_logprobs_fwd / _bwd)
+    eng = LlavaEngine(base) if args.op_level else CtxEngine(base, ragged=not args.padded)      # default: ONE C call per pass (opadpo_seq_logprobs_fwd / _bwd)
+    ragged = getattr(eng, "ragged", False)
     pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
     if not args.no_merge_ref:      # frozen adapter: s*B@A folded once into a second bf16 copy of the projections (PEFT-style merge)
@@ -229,9 +235,16 @@ def main():
             if b.lo == pos:
                 opt.launch_bucket(bi)
     largs = DPOArgs()
-    batches = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(args.accum)]
+    # a POOL of different synthetic micro-batches, cycled over the steps: with ragged rows the cost of a step depends on the valid
+    # lengths of its batch (SURVEY.md §8d draws them per pair), so one fixed batch would be a biased sample
+    n_pool = max(1, args.batch_pool) * args.accum
+    pool = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(n_pool)]
+    step_no = [0]
 
     def step():
+        k0 = (step_no[0] * args.accum) % n_pool
+        step_no[0] += 1
+        batches = pool[k0:k0 + args.accum]
         for mi, b in enumerate(batches):
             feats = eng.encode_images(b["images"])
             kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
@@ -280,6 +293,20 @@ def main():
         fl_ref = pair_flops(d, q_len, t_len)                      # reference formulation: 4 full sequences per pair
         merged = not args.no_merge_ref
         fl = pair_flops_packed(d, q_len, t_len, 2, ref_merged=merged) if pack else fl_ref - (2 * 2 * lora_param_count(d) * (q_len + t_len + d.n_patches - 1) if merged else 0)     # what this run executes
+        rows_per_pair = (q_len + d.n_patches - 1 + 2 * t_len) if pack else 2 * (q_len + t_len + d.n_patches - 1)
+        if ragged and pack:      # padding positions are not rows: FLOPs and rows from the valid lengths of this rank's batches
+            from opadpo_amd.dims import pair_flops_ragged
+            tot, rows_tot, n = 0.0, 0, 0
+            for b in pool:
+                lead = (b["queries_attn_masks"].int().cumsum(1) == 0).sum(1).tolist()
+                vc = (t_len - ((b["chosen"] != 0).flip(1).int().cumsum(1) == 0).sum(1)).tolist()
+                vr = (t_len - ((b["rejected"] != 0).flip(1).int().cumsum(1) == 0).sum(1)).tolist()
+                for l_, c_, r_ in zip(lead, vc, vr):
+                    pr = q_len + d.n_patches - 1 - l_
+                    tot += pair_flops_ragged(d, pr, [c_, r_], ref_merged=merged)
+                    rows_tot += pr + c_ + r_
+                    n += 1
+            fl, rows_per_pair = tot / n, rows_tot / n
         roof = None
         if prof or ctx_prof:
             tot_f = sum(p[0] for p in prof or [])
@@ -301,6 +328,8 @@ def main():
                           "response_layout": ("packed: chosen+rejected share one pass over the image+query prefix (segment-masked attention), "
                                               f"{q_len + d.n_patches - 1}+2x{t_len} positions per pair and pass" if pack else
                                               f"stacked: 2 x {q_len + t_len + d.n_patches - 1} positions per pair and pass (reference layout)"),
+                          "rows": (f"ragged: padding positions (left pad of the query, right pad of each response) are not rows of any kernel; {rows_per_pair:.0f} rows per pair "
+                                   f"and pass on average instead of {q_len + d.n_patches - 1 + 2 * t_len}" if (ragged and pack) else "padded: every position is a row, like the reference computes it"),
                           "reference_adapter": ("frozen adapter merged into a second bf16 copy of the LLM projections at load (no LoRA GEMMs in the no-grad pass)"
                                                 if not args.no_merge_ref else "unmerged (K-concatenated LoRA in the no-grad pass)"),
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
@@ -322,7 +351,7 @@ def main():
         if args.model == "7b" and world == 1 and not (args.no_rollout and args.no_exchange_probe):
             # side records, measured AFTER the timed region on the same GPU; the training state is released first
             numel, layer_numel = pol_ad.numel, pol_ad.layer_numel
-            del opt, policy, ref_policy, pol_ad, ref_ad, batches, loss
+            del opt, policy, ref_policy, pol_ad, ref_ad, pool, loss
             eng.release()
             torch.cuda.empty_cache()
             if not args.no_exchange_probe:

@@ -196,6 +196,7 @@ struct opadpo_ctx {
   std::vector<Block> cache;                       // released arenas kept for reuse (default allocator only)
   void* ws = nullptr; size_t ws_bytes = 0;        // scratch of vision / backward / decode
   size_t bytes_live = 0, bytes_peak = 0;
+  size_t arena_hint[2] = {0, 0};                  // largest activation arena requested so far (no-grad / training pass)
   std::vector<opadpo_saved*> live;
   // dispatch
   int gemm_variant = -1, use_tr = -1;             // -1: process default (opadpo_set_flags)
@@ -721,6 +722,11 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
     sv->ragged = 1; sv->meta_stride = stride; sv->M = row; sv->L = lmax;
   }
   sv->bytes = saved_layout(d, sv, nullptr);
+  // ragged batches differ in size: ask for the largest arena seen so far for this kind of pass, so that the allocator hands the
+  // same block back every time instead of growing (and fragmenting) its pool
+  size_t& hint = c->arena_hint[train ? 1 : 0];
+  hint = std::max(hint, sv->bytes);
+  sv->bytes = hint;
   sv->arena = ctx_alloc(c, sv->bytes, st);
   if (!sv->arena) { delete sv; return cfail(c, hipErrorOutOfMemory, "opadpo_seq_logprobs_fwd (activation arena)"); }
   saved_layout(d, sv, sv->arena);

@@ -4,8 +4,9 @@
     (LoraAdapter.merge_into_base / lib.ACT_SWIGLU_PAIR), the trainable policy adapter K-concatenated;
   * problem sizes at which the default dispatch takes the large-shape kernels of the benchmark
     (gemm_nt_w4_kernel<12>, gemm_tn_w4_kernel, the 128-row attention kernels): LLaVA-1.5-7B WIDTH
-    (H 4096, FFN 11008, V 32000, r 256), 4 decoder layers, 6 pairs x (query 128 + 2 x response 384), packed
-    rows = 5 466 -> 22 row tiles x 16..86 column tiles >= 320 blocks for every base projection;
+    (H 4096, FFN 11008, V 32000, r 256), 4 decoder layers, 7 pairs x (query 128 + 2 x response 384) on packed RAGGED rows
+    (the product default: padding positions are not rows) -> >= 20 row tiles x 16..86 column tiles >= 320 blocks for every base
+    projection;
   * LLaVA-1.5-13B width (H 5120, 40 heads, FFN 13824), 2 layers, same shape rule;
   * the on-policy rollout at batch 64 and 7B width (prefill L = 703, context up to ~750).
 
@@ -53,7 +54,7 @@ def _inputs(d, B, Q, T, seed):
     queries = torch.randint(3, d.vocab, (B, Q), generator=g)
     qmask = torch.ones(B, Q, dtype=torch.bool)
     for b in range(B):
-        n_pad = int(torch.randint(0, Q // 2, (1,), generator=g)) if b else 0
+        n_pad = int(torch.randint(0, Q // 8, (1,), generator=g)) if b else 0
         queries[b, :n_pad] = 0
         qmask[b, :n_pad] = False
         queries[b, int(torch.randint(n_pad, Q, (1,), generator=g))] = -200
@@ -61,7 +62,7 @@ def _inputs(d, B, Q, T, seed):
     for k in ("chosen_response", "rejected_response"):
         ids = torch.randint(3, d.vocab, (B, T), generator=g)
         for b in range(B):
-            ln = int(torch.randint(T // 6, T, (1,), generator=g))
+            ln = int(torch.randint(3 * T // 4, T, (1,), generator=g))       # long responses: enough VALID rows for the 256x256 dispatch at B = 6..7
             if b == 1 and k == "chosen_response":
                 continue                       # one response without any padding
             ids[b, ln] = 2
@@ -100,7 +101,8 @@ def _model(kw, n_seed_w=0, std=0.02):
     d, od = LlavaDims(**kw), LR.LlavaDims(**kw)
     W = {k: v.to(BF).float() for k, v in LR.init_weights(od, seed=n_seed_w, std=std).items()}
     dev = torch.device("cuda:0")
-    eng = LlavaEngine(BaseWeights(d, W, dev, need_backward=True))
+    from opadpo_amd.ctx import CtxEngine
+    eng = CtxEngine(BaseWeights(d, W, dev, need_backward=True))       # product path: opadpo_ctx, ragged rows
     return d, od, W, eng, dev, LR
 
 
@@ -126,8 +128,8 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
     lora_pol = {k: v.to(BF).float() for k, v in LR.init_lora(od, seed=1, b_std=0.01, with_vision=False).items()}
     lora_ref = {k: v.to(BF).float() for k, v in LR.init_lora(od, seed=2, b_std=0.01, with_vision=False).items()}
     images, queries, qmask, resp = _inputs(d, B, Q, T, seed=11)
-    # the dispatch the benchmark takes: default flags, packed rows; every base projection must reach the 256x256 4-wave kernel
-    M = B * (Q + d.n_patches - 1 + 2 * T)
+    # the dispatch the benchmark takes: default flags, packed RAGGED rows; every base projection must reach the 256x256 4-wave kernel
+    M = sum(int((qmask[b]).sum()) + d.n_patches - 1 + sum(int((resp[k][b] != 0).sum()) for k in resp) for b in range(B))
     assert ((M + 255) // 256) * (d.hidden // 256) >= 320, "too few row tiles: the 256x256 kernel would not be dispatched"
     lib.set_flags(True, True)
     ref_ad = LoraAdapter(d, lora_ref, dev, trainable=False)
@@ -217,13 +219,13 @@ def test_bench_config_parity_7b_width_1_layer_1e3():
     """One decoder layer at full 7B width, benchmark kernel shapes: north_star's 1e-3 on mean and p99."""
     kw = dict(hidden=4096, n_layers=1, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
               v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
-    _check_config("7b_w1", kw, B=6, Q=128, T=384, assert_1e3=True)
+    _check_config("7b_w1", kw, B=7, Q=128, T=384, assert_1e3=True)
 
 
 def test_bench_config_parity_7b_width_4_layers():
     kw = dict(hidden=4096, n_layers=4, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
               v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
-    _check_config("7b_w4", kw, B=6, Q=128, T=384)
+    _check_config("7b_w4", kw, B=7, Q=128, T=384)
 
 
 def test_bench_config_parity_13b_width_2_layers():
@@ -233,7 +235,7 @@ def test_bench_config_parity_13b_width_2_layers():
     full = LlavaDims.llava15_13b()
     kw = dict(hidden=full.hidden, n_layers=2, n_heads=full.n_heads, head_dim=full.head_dim, ffn=full.ffn, vocab=full.vocab,
               v_hidden=128, v_layers=2, v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
-    _check_config("13b_w2", kw, B=5, Q=128, T=384)
+    _check_config("13b_w2", kw, B=6, Q=128, T=384)
 
 
 def test_rollout_batch64_7b_width():
@@ -247,8 +249,6 @@ def test_rollout_batch64_7b_width():
     kw = dict(hidden=4096, n_layers=2, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
               v_heads=2, v_ffn=256, image_size=336, patch=14, lora_r=256, lora_alpha=512.0)
     d, od, W, eng, dev, LR = _model(kw, std=0.03)
-    from opadpo_amd.ctx import CtxEngine
-    eng = CtxEngine(eng.base)           # the product path: prefill, KV cache, hipGraph and the 33..64-token decode GEMMs below the C ABI
     B, Q, N = 64, 128, 48
     assert d.n_patches == 576
     g = torch.Generator().manual_seed(8)

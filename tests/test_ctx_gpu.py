@@ -115,9 +115,9 @@ def test_default_allocator_and_per_context_flags(env):
     ad, p = env["ads"]["ref"], env["p"]
     with torch.no_grad():
         want = _policy(env["cx"], ad, 24, True)(**_kw(p, env["cx"]))
-        plain = CtxEngine(env["base"], torch_allocator=False)
+        plain = CtxEngine(env["base"], torch_allocator=False, ragged=False)
         got = _policy(plain, ad, 24, True)(**_kw(p, plain))
-        small = CtxEngine(env["base"])
+        small = CtxEngine(env["base"], ragged=False)
         small.set_flags(gemm_variant=4)
         got4 = _policy(small, ad, 24, True)(**_kw(p, small))
         again = _policy(env["cx"], ad, 24, True)(**_kw(p, env["cx"]))

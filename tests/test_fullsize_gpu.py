@@ -30,7 +30,8 @@ def full():
     dev = torch.device("cuda:0")
     d = LlavaDims.llava15_7b()
     base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
-    eng = LlavaEngine(base)
+    from opadpo_amd.ctx import CtxEngine
+    eng = CtxEngine(base)                   # product path: opadpo_ctx on ragged rows
     ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     p = synth_pairs(d, 3, 128, 384, seed=5, device=dev)
     feats = eng.encode_images(p["images"])

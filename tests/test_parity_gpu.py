@@ -38,7 +38,8 @@ def setup():
         lora_ref[k] = vis[k]
     dev = torch.device("cuda:0")
     base = BaseWeights(d, W, dev, need_backward=True, vision_lora=vis)
-    eng = LlavaEngine(base)
+    from opadpo_amd.ctx import CtxEngine
+    eng = CtxEngine(base)               # the product path: sequence-level C entry points on ragged rows (padding positions are not rows)
     pol = LoraAdapter(d, lora_pol, dev, trainable=True)
     ref = LoraAdapter(d, lora_ref, dev, trainable=False)
     ref_merged = LoraAdapter(d, lora_ref, dev, trainable=False)      # what bench.py runs: frozen adapter folded into its own bf16 copy,
