@@ -267,6 +267,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("OPADPO_BENCH_TRACE") == "1"
     for _ in range(args.warmup):
         step()
     sync()
@@ -275,7 +276,11 @@ def main():
         eng.profile(True)                               # the LLM passes: launched inside opadpo_seq_logprobs_fwd / _bwd
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         loss = step()
+        if trace:      # diagnostics only (synchronises every step)
+            torch.cuda.synchronize()
+            print(f"[trace] step {step_no[0]}: {(time.perf_counter() - ts) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     sync()
     dt = time.perf_counter() - t0
     prof, L.PROFILE = L.PROFILE, None

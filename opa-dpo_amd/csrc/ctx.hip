@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void kv_fill_kernel(const bf16_t* qkv, bf16_t*
 }
 // splice backward (OPA LoRA-SFT stage): d_feats[feat_row[s], p, :] += dX[s*Lp + img_pos(s) + p, :]
 __global__ __launch_bounds__(256) void splice_grad_kernel(const float* dX, const int32_t* ids, const int32_t* feat_row, float* d_feats, int S,
-                                                         int n_txt, int Lp, int P, int H, int image_token) {
+                                                         int n_txt, int Lp, int P, int H, int image_token, const int32_t* meta, int stride, int K) {
   const int s = blockIdx.y, p = blockIdx.x;
   __shared__ int pos;
   if (threadIdx.x == 0) {
@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void splice_grad_kernel(const float* dX, const
     pos = q;
   }
   __syncthreads();
-  const float* src = dX + ((size_t)s * Lp + pos + p) * H;
+  // ragged rows: sequence s starts at row meta[0] and its first `lead` (meta[2 + K]) positions are not rows
+  const size_t row = meta ? (size_t)meta[(size_t)s * stride] + (pos - meta[(size_t)s * stride + 2 + K]) + p : (size_t)s * Lp + pos + p;
+  const float* src = dX + row * H;
   float* dst = d_feats + ((size_t)feat_row[s] * P + p) * H;
   for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dst + c, src[c]);
 }
@@ -725,6 +727,11 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   // ragged batches differ in size: ask for the largest arena seen so far for this kind of pass, so that the allocator hands the
   // same block back every time instead of growing (and fragmenting) its pool
   size_t& hint = c->arena_hint[train ? 1 : 0];
+  if (sv->ragged) {                               // size for the padded row count of this shape: a ragged batch can never need more
+    opadpo_saved worst = *sv;
+    worst.M = S * Lp; worst.L = Lp;
+    hint = std::max(hint, saved_layout(d, &worst, nullptr));
+  }
   hint = std::max(hint, sv->bytes);
   sv->bytes = hint;
   sv->arena = ctx_alloc(c, sv->bytes, st);
@@ -792,7 +799,6 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   if (!sv->train) return cbad(c, __func__, "activations were not saved for backward (train = 0)");
   const opadpo_dims& d = c->d;
   if (layer_hi >= d.n_layers || layer_lo < 0 || layer_lo > layer_hi) return cbad(c, __func__, "bad layer range");
-  if (sv->ragged && d_feats) return cbad(c, __func__, "d_feats (OPA-SFT splice backward) needs the padded layout: pass row_plan = NULL to the forward");
   const opadpo_ctx::Adapter& ad = c->adapters[sv->adapter];
   if (ad.kind != 1 || !ad.grad || !ad.work_t) return cbad(c, __func__, "adapter lost its gradient / transposed buffers");
   hipStream_t st = (hipStream_t)stream;
@@ -878,7 +884,8 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   }
   if (layer_lo == 0 && d_feats) {
     const int side = d.image_size / d.patch, P = side * side;
-    hipLaunchKernelGGL(splice_grad_kernel, dim3(P, S), dim3(256), 0, st, dX, sv->ids, sv->feat_row, d_feats, S, sv->n_txt, Lp, P, H, OPADPO_IMAGE_TOKEN);
+    hipLaunchKernelGGL(splice_grad_kernel, dim3(P, S), dim3(256), 0, st, dX, sv->ids, sv->feat_row, d_feats, S, sv->n_txt, Lp, P, H, OPADPO_IMAGE_TOKEN,
+                       sv->ragged ? sv->meta : nullptr, sv->meta_stride, sv->K);
     CK(hipGetLastError());
   }
   return 0;

@@ -293,6 +293,7 @@ def test_rollout_batch64_7b_width():
         mask = torch.cat([mask, torch.ones(len(rows), 1, dtype=torch.bool)], 1)
     # the LDS-ring decode GEMM (default from 33 sequences) against the 16/32-row streaming kernels (context flag bit 5): two
     # summation orders of the same projections - greedy tokens agree except at near-ties of the top-2 logits
+    from opadpo_amd.ctx import CtxEngine
     old = CtxEngine(eng.base)
     old.set_flags(use_tr=1 | 32)
     greedy_old = Generator(old, None, use_graph=True).generate(queries, qmask, image_feats=feats, max_new_tokens=N, top_k=1, top_p=1.0,
