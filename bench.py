@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--batch-pool", type=int, default=8, help="number of different synthetic micro-batches cycled over the steps")
     ap.add_argument("--padded", action="store_true", help="keep the reference's padded rows (padding positions computed and thrown away) instead of ragged rows")
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
+    ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward as its own launch)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
@@ -218,6 +219,8 @@ def main():
     base = BaseWeights(d, W, dev, need_backward=True)
     del W
     eng = LlavaEngine(base) if args.op_level else CtxEngine(base, ragged=not args.padded)      # default: ONE C call per pass (opadpo_seq_logprobs_fwd / _bwd)
+    if args.ctx_flags >= 0 and not args.op_level:
+        eng.set_flags(use_tr=args.ctx_flags)
     ragged = getattr(eng, "ragged", False)
     pol_ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref_ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)

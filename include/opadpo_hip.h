@@ -35,6 +35,9 @@ extern "C" {
                                     * (the trailing padding of a right-padded response) writes zeros (forward: O, backward: dQ) and is left
                                     * out of the dK / dV accumulation - exact for the LLM, where such rows are padding whose outputs nobody
                                     * reads and whose output gradient is zero; needs key_mask */
+#define OPADPO_ACT_SWIGLU_BWD 4 /* gemm_nt only (N a multiple of 256, bf16 out, alpha 1, no bias): the product is d_act [M,N], R (bf16, ldr) holds the
+                                * stored pre-activations [gate | up] = [M,2N] and C (ldc) receives [d_gate | d_up] = [M,2N]: opadpo_silu_mul_bwd applied
+                                * in the epilogue on the bf16-rounded d_act tile (bit-identical to the two-call form, d_act never written) */
 #define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
                                   * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
 
@@ -270,7 +273,8 @@ void opadpo_ctx_destroy(opadpo_ctx* ctx);
 const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
 int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
 /* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default.  Context-only: use_tr bit 5 = keep the
- * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode) */
+ * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
+ * bit 6 = SwiGLU backward as its own launch (default: OPADPO_ACT_SWIGLU_BWD in the epilogue of the down projection's dgrad) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);

@@ -852,8 +852,14 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
     CK(tn(dXb, H, b.t_d, r, gr + o.b_d, r, H, r, 0, 0));
     CK(tn(dt_r, r, b.act, F, gr + o.a_d, F, r, F, 0, 0));
-    { GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_act, F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r); CK(run_gemm(c, g, st)); }
-    CK(launch_silu_mul_bwd(d_act, b.gu, d_gu, M, F, st));
+    if (F % 256 == 0 && !(c->use_tr >= 0 && (c->use_tr & 64))) {      // SwiGLU backward in the dgrad epilogue: d_act stays in the block's LDS (flag bit 6 = two-kernel form)
+      GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_gu, 2 * F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r);
+      g.act = OPADPO_ACT_SWIGLU_BWD; g.R = b.gu; g.ldr = 2 * F; g.r_f32 = 0;
+      CK(run_gemm(c, g, st));
+    } else {
+      { GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_act, F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r); CK(run_gemm(c, g, st)); }
+      CK(launch_silu_mul_bwd(d_act, b.gu, d_gu, M, F, st));
+    }
     { GemmNTArgs g = gemm(c, d_gu, 2 * F, wt + o.b_gu, F, F, dt_2r, 2 * r, 0, M, 2 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = F; CK(run_gemm(c, g, st)); }
     CK(tn(d_gu, 2 * F, b.t_gu, 2 * r, gr + o.b_gu, r, 2 * F, r, F, r));
     CK(tn(dt_2r, 2 * r, b.n2, H, gr + o.a_gu, H, 2 * r, H, 0, 0));

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       }
       if (hf == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the second half overwrites the staging rows
     };
-    if (!p.out_f32 && !p.R) {
+    if (!p.out_f32 && (!p.R || p.act == OPADPO_ACT_SWIGLU_BWD)) {
       // bf16 result without residual: the whole 128x128 block fits the wave's 32 KiB as bf16 -> one LDS round trip, half the bytes
       // (32-byte groups XOR-swizzled by row & 7; 8-byte writes in fragment layout, 16-byte reads along rows)
       epi_dispatch_plain(p, [&](auto MD_) {
@@ -767,6 +767,33 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = gt[e] / (1.0f + __expf(-gt[e])) * up[e];
           if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ocol) = pack8(o);
+        }
+        return;
+      }
+      if (p.act == OPADPO_ACT_SWIGLU_BWD) {
+        // fused SwiGLU backward (dgrad of the down projection): the staged bf16-ROUNDED block is d_act[:, ncol0..+127]; R holds the
+        // stored pre-activations [gate | up] ([M, 2N]) and C receives [d_gate | d_up] - the arithmetic of silu_mul_bwd_kernel on the
+        // same rounded operands, so the result is bit-identical to the two-kernel path without d_act ever reaching HBM.
+        const int row0 = lane >> 4, g = lane & 15;
+        const bf16_t* gu = (const bf16_t*)p.R;
+#pragma unroll 4
+        for (int ps = 0; ps < 32; ++ps) {
+          const int row = ps * 4 + row0, m = mb + row;
+          if (m >= p.M) continue;
+          const size_t n = (size_t)ncol0 + g * 8;
+          float dd[8], gt[8], up[8], dg[8], du[8];
+          unpack8(*(const uint4*)(stg + row * 256 + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), dd);
+          unpack8(*(const uint4*)(gu + (size_t)m * p.ldr + n), gt);
+          unpack8(*(const uint4*)(gu + (size_t)m * p.ldr + p.N + n), up);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float sg = 1.0f / (1.0f + __expf(-gt[e]));
+            const float silu = gt[e] * sg;
+            du[e] = dd[e] * silu;
+            dg[e] = dd[e] * up[e] * sg * (1.0f + gt[e] * (1.0f - sg));
+          }
+          *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(dg);
+          *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + p.N + n) = pack8(du);
         }
         return;
       }
@@ -1850,6 +1877,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
+  if (a.act == OPADPO_ACT_SWIGLU_BWD) {       // fused SwiGLU backward epilogue (R = stored [gate | up], C = [d_gate | d_up]): the 4-wave 256x256 kernel only
+    const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
+                      (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));
+    if (a.bias || !a.R || a.r_f32 || a.out_f32 || a.alpha != 1.0f || a.N % P_BN || !ok32 || a.ldr % 8 || a.ldc % 8 || a.rope_cos) return hipErrorInvalidValue;
+    const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    return hipGetLastError();
+  }
   if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: the 4-wave 256x256 kernel, or the weight-streaming kernel for decode
     const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9;
     if (a.bias || a.R || a.out_f32 || a.alpha != 1.0f || a.K2 != 0 || a.N % P_BN || !ok32) return hipErrorInvalidValue;
@@ -1912,8 +1947,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // rounds, w4 1.10 vs 0.84; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
   const bool plain = !a.bias && !a.act;                 // the 4-wave kernel is instantiated for alpha-only epilogues
   const int pp_slots = ((pp_tiles + 255) / 256) * 256;
+  // ragged rows (M ~ 24-26 k): N = 512 -> 188-200 blocks in ONE round, w4 0.088 / 0.256 ms (K = 4096 / 11008) vs 0.121 / 0.424 for the
+  // 128x128 kernel; N = 768 -> 282-300 blocks: a tie; N = 256 -> 94-100 blocks: the 128x128 kernel keeps a 5-20 % lead
   const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 ||
-                   (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
+                   (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 150 && pp_tiles <= 256) ||
+                                            (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
     if (plain && g_gemm_variant != 17)      // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
       hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);

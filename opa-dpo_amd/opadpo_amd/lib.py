@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopadpo_hip.so")
 
-ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SWIGLU_PAIR = 0, 1, 2, 3
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SWIGLU_PAIR, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4
 CAUSAL_SKIP_MASKED_Q = 3      # `causal` of opadpo_attn_fwd / _bwd: 1 = causal, | 2 = OPADPO_ATTN_SKIP_MASKED_Q (all-padding q tiles write zeros)
 
 _p = C.c_void_p
@@ -197,12 +197,13 @@ def gemm_nt(a1: torch.Tensor, b1: torch.Tensor, out: torch.Tensor, *, a2: Option
             act: int = ACT_NONE) -> torch.Tensor:
     """out[M,N] = act(alpha*(a1 @ b1^T + a2[:, group] @ b2^T) + bias) + residual.  2-D row-major views
     with arbitrary row stride (leading dimension).  act = ACT_SWIGLU_PAIR: b1 rows per 128 are [64 gate | 64 up], out is [M, N/2] =
-    silu(gate) * up (include/opadpo_hip.h)."""
+    silu(gate) * up; act = ACT_SWIGLU_BWD: the product is d_act [M,N], `residual` holds the stored [gate | up] ([M,2N]) and out is
+    [d_gate | d_up] ([M,2N]) (include/opadpo_hip.h)."""
     _chk(a1, torch.bfloat16, "a1"); _chk(b1, torch.bfloat16, "b1")
     M = a1.shape[0]
     K1 = a1.shape[1] if k1 is None else k1       # k1: per-group K when a1 is the wide [M, G*K1] grouped operand
     N = b1.shape[0]
-    assert b1.shape[1] == K1 and out.shape[0] == M and out.shape[1] == (N // 2 if act == ACT_SWIGLU_PAIR else N)
+    assert b1.shape[1] == K1 and out.shape[0] == M and out.shape[1] == (N // 2 if act == ACT_SWIGLU_PAIR else 2 * N if act == ACT_SWIGLU_BWD else N)
     K2 = 0
     if a2 is not None:
         _chk(a2, torch.bfloat16, "a2"); _chk(b2, torch.bfloat16, "b2")

@@ -916,6 +916,28 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert relerr(got[:M], ref) < 2e-2
 
 
+@pytest.mark.parametrize("M,F,K,r", [(300, 256, 128, 64), (1000, 768, 256, 0), (257, 1536, 512, 256), (3, 256, 64, 64)])
+def test_gemm_nt_swiglu_bwd(L, M, F, K, r):
+    """ACT_SWIGLU_BWD: dgrad of the down projection (+ K-concatenated LoRA tail) with opadpo_silu_mul_bwd in its epilogue ==
+    the projection followed by opadpo_silu_mul_bwd, bit for bit; rows >= M of the output untouched; an unsupported width is refused."""
+    L.set_flags(10, True)
+    dy = rnd(M, K, seed=1)
+    wd_t = rnd(F, K, scale=0.3, seed=2)
+    gu = rnd(M, 2 * F, seed=3)
+    kw = dict(a2=rnd(M, r, seed=4), b2=rnd(F, r, scale=0.3, seed=5)) if r else {}
+    d_act = torch.empty(M, F, dtype=BF, device=dev())
+    L.gemm_nt(dy, wd_t, d_act, **kw)
+    want = torch.empty(M, 2 * F, dtype=BF, device=dev())
+    L.call("opadpo_silu_mul_bwd", L.ptr(d_act), L.ptr(gu), L.ptr(want), M, F, L.stream())
+    got = torch.full((M + 2, 2 * F), 7.0, dtype=BF, device=dev())
+    L.gemm_nt(dy, wd_t, got[:M], residual=gu, act=L.ACT_SWIGLU_BWD, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:M], want)
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    with pytest.raises(L.OpadpoError):         # N = 128 is not a whole 256-column tile: no silent fallback
+        L.gemm_nt(dy, wd_t[:128], got[:M, :256], residual=gu[:, :256], act=L.ACT_SWIGLU_BWD)
+
+
 @pytest.mark.parametrize("M,tr", [(1, 1), (4, 1), (8, 1), (9, 1), (16, 1), (17, 1), (24, 1), (32, 1), (40, 1), (64, 1), (4, 17), (16, 17), (24, 17)])
 @pytest.mark.parametrize("F,K", [(128, 256), (1408, 4096), (384, 11008), (11008, 256)])
 def test_gemm_nt_swiglu_pair_decode(L, M, tr, F, K):

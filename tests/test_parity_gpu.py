@@ -365,6 +365,32 @@ def test_eval_generation_from_checkpoint(setup, tmp_path):
         for row in a.tolist():                     # pad after the first EOS
             if 2 in row:
                 assert all(t == 0 for t in row[row.index(2) + 1:])
+    # ... and against the ORACLE: greedy decoding with the state dict read back from the checkpoint directory, the CPU
+    # model re-run on the whole sequence every step (eval_llava_rlhf_coco/model_vqa.py:213-226, do_sample=False)
+    from opadpo_amd.checkpoint_io import load_adapter
+    from opadpo_amd.eval_generate import adapter_dir_of
+    LR = s["LR"]
+    lora = {k: v for k, v in s["lora_ref"].items() if "vision_tower" in k or "mm_projector" in k}   # merged into the engine's vision weights
+    lora.update({k: v.to(s["lora_ref"][k].dtype).cpu() for k, v in load_adapter(adapter_dir_of(str(ckpt))).items()})
+    N = 8
+    out = generate_from_checkpoint(s["eng"], str(ckpt), queries, qmask, images.to(s["dev"]), max_new_tokens=N, temperature=0.0).cpu()
+    feats = LR.image_features(images, s["W"], lora, s["od"])
+    ids, mask = queries.clone(), qmask.clone()
+    done = torch.zeros(2, dtype=torch.bool)
+    for step in range(N):
+        logits = LR.llava_logits(ids, mask, None, s["W"], lora, s["od"], feats=feats)[:, -1]
+        top2 = logits.topk(2, dim=-1)
+        for b in range(2):
+            if done[b]:
+                assert int(out[b, step]) == 0
+                continue
+            if int(out[b, step]) != int(top2.indices[b, 0]):      # a bf16 near-tie may flip the argmax: only between the top two
+                gap = float(top2.values[b, 0] - top2.values[b, 1])
+                assert int(out[b, step]) == int(top2.indices[b, 1]) and gap < 2e-2, (step, b, gap)
+        nxt = out[:, step].clone()
+        done |= nxt == 2
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        mask = torch.cat([mask, torch.ones(2, 1, dtype=torch.bool)], 1)
 
 
 def test_online_rollout_step_on_the_decode_kernels(setup):

@@ -71,6 +71,21 @@ def main():
             res.append(dict(kernel="attn_bwd_packed", ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
             print(res[-1], flush=True)
         return
+    if only == "tail":     # partial last round of 256x256 tiles: row-tile count sweep at the ragged bench row counts
+        for name, N, K1, K2, grp in shapes[:4]:
+            for R in [int(v) for v in os.environ.get("GB_RT", "96,97,100,104,108,112").split(",")]:
+                M_ = R * 256
+                a1 = torch.randn(M_, K1, device=dev).to(BF)
+                b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
+                out = torch.empty(M_, N, dtype=BF, device=dev)
+                G = N // grp if grp else 1
+                kw = dict(a2=torch.randn(M_, G * K2, device=dev).to(BF), b2=(torch.randn(N, K2, device=dev) * 0.02).to(BF),
+                          a2_group_n=grp, a2_group_stride=K2 if grp else 0)
+                t = timeit(lambda: L.gemm_nt(a1, b1, out, **kw))
+                tiles = R * (N // 256)
+                res.append(dict(name=name, R=R, tiles=tiles, rounds=tiles / 256, ms=t * 1e3, tflops=2.0 * M_ * N * (K1 + K2) / t / 1e12))
+                print(res[-1], flush=True)
+        return
     if only == "cube":     # yardstick shapes of the micro-architecture guide's 256^2 template: 4096^3 and 8192^3, uniform [-1,1)
         for n in (4096, 8192):
             a1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
