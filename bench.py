@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--batch-pool", type=int, default=8, help="number of different synthetic micro-batches cycled over the steps")
     ap.add_argument("--padded", action="store_true", help="keep the reference's padded rows (padding positions computed and thrown away) instead of ragged rows")
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
-    ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward as its own launch)")
+    ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward fused into the dgrad epilogue)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")

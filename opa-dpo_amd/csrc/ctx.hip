@@ -852,7 +852,9 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
     CK(tn(dXb, H, b.t_d, r, gr + o.b_d, r, H, r, 0, 0));
     CK(tn(dt_r, r, b.act, F, gr + o.a_d, F, r, F, 0, 0));
-    if (F % 256 == 0 && !(c->use_tr >= 0 && (c->use_tr & 64))) {      // SwiGLU backward in the dgrad epilogue: d_act stays in the block's LDS (flag bit 6 = two-kernel form)
+    if (F % 256 == 0 && c->use_tr >= 0 && (c->use_tr & 64)) {      // opt-in (flag bit 6): SwiGLU backward in the dgrad epilogue, d_act stays in the block's LDS.
+      // Same-box A/B at the bench shape: 1016.9 vs 1013.3 ms per step for the two-kernel form - the longer epilogue idles the one-block-per-CU
+      // matrix pipe for longer than the 5 TB/s elementwise kernel takes
       GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_gu, 2 * F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r);
       g.act = OPADPO_ACT_SWIGLU_BWD; g.R = b.gu; g.ldr = 2 * F; g.r_f32 = 0;
       CK(run_gemm(c, g, st));

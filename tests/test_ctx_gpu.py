@@ -175,6 +175,15 @@ def test_wide_7b_forward_is_bit_identical():
         res.append((out["chosen_response_logprobs"].detach().clone(), out["rejected_response_entropies"].clone(), ad.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float((res[0][2] - res[1][2]).norm() / res[0][2].norm()) < 1e-5
+    # opt-in flag bit 6: SwiGLU backward inside the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD) - same bits
+    # into the wgrads, so the gradient differs from the two-kernel form only by the order of the fp32 atomics
+    cx.set_flags(use_tr=1 | 64)
+    ad.grad.zero_()
+    out = _policy(cx, ad, 384, True)(**_kw(p, cx))
+    sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out["chosen_response_logprobs"].detach(), res[1][0])
+    assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-5
     cx.close()
     op.release()
 
