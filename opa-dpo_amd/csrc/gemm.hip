@@ -237,48 +237,26 @@ constexpr int P_STAGE = 2 * P_TILE;              // A + B
 // gemm_nt "w4" kernel: 256x256 tile, BK = 64, FOUR waves (2x2), each owning a 128x128 block of C in 64 accumulator
 // fragments (256 accumulator registers -> one wave per SIMD, 512-register budget), two 64-KiB LDS stages filled by
 // buffer_load ... lds.  One wave per SIMD means nothing else can feed the matrix pipe, so every non-MFMA instruction of
-// the K-loop is placed INSIDE the MFMA stream (one issue slot per 2-4 MFMAs, pinned with sched_barrier), the pipe never
-// waits for a phase change of a sibling wave, and a wave reads each LDS fragment for 8 MFMAs (128 KiB of LDS reads per
-// K-tile and block instead of 192 KiB in the 8-wave kernel):
-//   sub-step (t,0): 64 MFMAs on fragment set 0 | 16 ds_read_b128 of set 1 (k 32..63 of tile t) | DMA pieces 8..15 of tile t+1
-//   sub-step (t,1): 32 MFMAs on set 1 | s_waitcnt vmcnt(0) + ONE barrier (tile t+1 landed, tile t's stage is free)
-//                 | 32 MFMAs | 16 ds_read_b128 of set 0 of tile t+1 | DMA pieces 0..7 of tile t+2
-// so a DMA piece is issued >= 64 MFMAs (~1100 cycles) before the barrier that waits for it.
-// Measured on 8192^3 (uniform random operands): this schedule 1.26-1.32 PF/s; without the in-loop DMA 1.56-1.68, with every
-// K-tile re-reading k = 0 (all L2 hits) 1.40-1.46: about half of the DMA cost is HBM / Infinity-Cache miss latency that a
-// <= 1-tile lead cannot hide.  Releasing the stage per operand behind extra barriers (the schedule of the vendor library's
-// hand-written 256x256x64 kernel, which waits with vmcnt(13) three quarters into the NEXT tile: 1.55-1.6 PF/s) was tried in
-// two forms and measured 0.88-1.13 PF/s here (the extra barriers + lgkmcnt(0) drains cost more than the longer lead wins in
-// compiler-scheduled code); a cooperative L2 prefetch of tile t+3 (each block touches its share of the XCD's unique lines)
-// gave +6 % on 8192^3 and -6 % on 4096^3.  What was wrong with the long-lead forms was the COMPILER, not the schedule: across
-// their pinned scheduling regions it rotated the 64 accumulators through other AGPRs / VGPRs (152 v_accvgpr_* + 34 s_nop per
-// K-tile).  With the MFMA as inline asm and the accumulator tied in place ("+a") the long-lead schedule (EXP = 6, variant 23:
-// stage released after the 16 set-1 reads, DMA of tile t+2 waited with vmcnt(13) three quarters into tile t+1) is the fastest
-// kernel here: 1.33-1.38 PF/s on 8192^3, 1.25-1.30 on the training shapes -> DEFAULT for large GEMMs.  SQ counters on the
-// cubes (quad-cycles per launch set): single-barrier w4 244 M (24 % parked in s_waitcnt / s_barrier), long lead 228 M (21 %),
-// p8 2 x 245 M, vendor asm kernel 165 M (5 %); removing any ONE of its waits (racy diagnostics, since deleted) gave +4.5 % each, and
-// timing-only variants (no in-loop DMA / no fragment reads / every K-tile re-reading k = 0) gave the 1.56-1.68 and 1.40-1.46 figures above.
-// Variant 16 = single-barrier schedule, 23 / 24 = long lead with the builtin DMA (with / without the MFMA between wait and barrier).
+// the K-loop is placed INSIDE the MFMA stream (one issue slot per 1-5 MFMAs, pinned with sched_barrier) and a wave reads
+// each LDS fragment for 8 MFMAs (128 KiB of LDS reads per K-tile and block instead of 192 KiB in the 8-wave kernel).
+// Long-lead schedule per K-tile t (128 MFMAs):
+//   P1: 40 MFMAs(kk=0) | 16 reads set1(t)                  | lgkmcnt(0), barrier  -> the stage of tile t is dead
+//   P2: 24 MFMAs(kk=0) | 6 DMA (t+2)
+//   P3: 36 MFMAs(kk=1) | 7 DMA (t+2)                       | vmcnt(13), barrier   -> tile t+1 has landed
+//   P4: 28 MFMAs(kk=1) | 16 reads set0(t+1), 3 DMA (t+2)
+// so a DMA piece is waited for 104-184 MFMAs (1.8-3.1 k cycles) after its issue (a single-barrier schedule with <= 1 tile of
+// lead stalled on the ~19 % of pieces that miss the XCD's L2).  The MFMA is inline asm with the accumulator tied in place in
+// an AGPR tuple ("+a"): with the builtin, the register allocator rotated the 64 accumulators through other AGPRs / VGPRs
+// across the pinned scheduling regions (152 v_accvgpr_* + 34 s_nop per K-tile).  The DMA is two inline-asm halves: M0 (the
+// LDS destination) is written one MFMA AHEAD of the buffer_load, which costs the MFMA stream 6.5 instead of 10.5 cycles per
+// piece (tools/micro/mfma_dma.hip).  1.40-1.48 PF/s on the training shapes; DESIGN.md section 8.1 keeps the numbers of the
+// schedules this one replaced (single barrier, 8-wave 4-phase, register-staged operands, in-kernel s_memtime stamps).
 // ------------------------------------------------------------------------------------------
-// EXP == 10 (variant 27, diagnostic): the default schedule with s_memtime stamps around its two wait points; per wave
-// {cycles in the K-loop, cycles parked at wait 1 (lgkmcnt + barrier), at wait 2 (vmcnt + barrier), 100-MHz ticks, K-tiles}
-constexpr int W4_PROF_MAX_WG = 4096;
-constexpr int W4_PROF_N = 13;
-__device__ unsigned long long g_w4_prof[W4_PROF_MAX_WG * 4 * W4_PROF_N];
-
-template <int EXP>   // 0: single-barrier schedule, 6: long lead (builtin DMA), 7: 6 without the MFMA between wait and barrier, 10: stamped 6 (variant 27),
-                     // 11: register-staged operands (variant 28), 12: long lead with the DMA as two asm halves (variant 31, DEFAULT)
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  unsigned long long prof_e0 = 0, prof_r0 = 0;
-  int diag = 0;
-  if constexpr (EXP == 10) {
-    diag = p.act >> 9; p.act &= 0xff;      // diagnostics: bit 0 = skip the stores of the staged epilogue, bit 1 = direct (fragment-layout) epilogue
-    prof_e0 = __builtin_readcyclecounter(); prof_r0 = __builtin_amdgcn_s_memrealtime();
-  }
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
@@ -332,8 +310,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
   };
-  // EXP == 12: the DMA as two inline-asm halves - M0 (the LDS destination) is written one MFMA AHEAD of the buffer_load, which
-  // costs the MFMA stream 6.5 instead of 10.5 cycles per piece (tools/micro/mfma_dma.hip); nothing between the halves uses M0.
+  // the in-loop DMA as two inline-asm halves (M0 first, the load one MFMA later); nothing between the halves uses M0
   typedef __attribute__((ext_vector_type(4))) int i32x4_t;
   auto mk_rsrc = [&](const void* base) {
     const unsigned long long v = (unsigned long long)base;
@@ -353,28 +330,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? (t - nt1) : t) * P_BK * 2);
     const i32x4_t r = q < 8 ? (second ? qA2 : qA1) : (second ? qB2 : qB1);
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff) : "memory");
-  };
-
-  // EXP == 11: operands staged through registers (buffer_load -> VGPR, ds_write_b128 later) instead of LDS-DMA
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4r_t;
-  u32x4r_t G[16];
-  auto load_piece = [&](int t, int q) {
-    const bool second = t >= nt1;
-    const int k0 = (second ? (t - nt1) : t) * P_BK;
-    const int pi = q & 7;
-    if (q < 8) {
-      const unsigned ld2 = (unsigned)(second ? p.lda2 : p.lda1) * 2u;
-      const unsigned row = min((unsigned)m0 + lrow + pi * 8u, m_last);
-      G[q] = __builtin_amdgcn_raw_buffer_load_b128(second ? rA2 : rA1, row * ld2 + csw[pi & 1], k0 * 2, 0);
-    } else {
-      const unsigned ld2 = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)n0 + pi * 8u) * ld2 + k0 * 2));
-      G[q] = __builtin_amdgcn_raw_buffer_load_b128(second ? rB2 : rB1, lrow * ld2 + csw[pi & 1], soff, 0);
-    }
-  };
-  const int g_lds = wave * 8192 + lane * 16;
-  auto store_piece = [&](int t, int q) {
-    *(u32x4r_t*)(smem + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + g_lds + (q & 7) * 1024) = G[q];
   };
 
   f32x4_t acc[8][8];
@@ -405,54 +360,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[kk][j]), "v"(fa[kk][i]));
     }
   };
-  auto tile_body = [&](int t, auto ISSUE_B, auto HAS_NEXT, auto HAS_NEXT2) {
-    constexpr bool issue_b = decltype(ISSUE_B)::value, has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    // ---- sub-step 0: set 0 in registers; stream set 1 of this tile out of LDS, finish the DMA of tile t+1
-    if constexpr (issue_b) { if (t + 1 == nt1) { set_voff(true, 2); W4_PIN(); } }
-#pragma unroll
-    for (int g4 = 0; g4 < 16; ++g4) {
-      mfma_run(0, g4 * 4, 4);
-      W4_PIN();
-      read_frag(t, 1, g4);
-      if constexpr (issue_b) { if (g4 < 8) issue_piece(t + 1, 8 + g4); }
-      W4_PIN();
-    }
-    // ---- sub-step 1, first half
-    mfma_run(1, 0, 32);
-    W4_PIN();
-    if constexpr (has_next) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    W4_PIN();
-    // ---- second half: set 0 of the next tile, first DMA pieces of tile t+2 (its stage is the one just retired)
-    if constexpr (has_next2) { if (t + 2 == nt1) { set_voff(true, 1); W4_PIN(); } }
-#pragma unroll
-    for (int g4 = 0; g4 < 8; ++g4) {
-      mfma_run(1, 32 + g4 * 4, 4);
-      W4_PIN();
-      if constexpr (has_next) { read_frag(t + 1, 0, 2 * g4); read_frag(t + 1, 0, 2 * g4 + 1); }
-      if constexpr (has_next2) issue_piece(t + 2, g4);
-      W4_PIN();
-    }
-  };
-  // EXP == 6: long-lead schedule (stage released per operand, DMA of tile t+2 waited three quarters into tile t+1)
-  //   P1: 40 MFMAs(kk=0) | 16 reads set1(t)                  | lgkmcnt(0), barrier  -> the stage of tile t is dead
-  //   P2: 24 MFMAs(kk=0) | 6 DMA (t+2)
-  //   P3: 36 MFMAs(kk=1) | 7 DMA (t+2)                       | vmcnt(13), barrier   -> tile t+1 has landed
-  //   P4: 28 MFMAs(kk=1) | 16 reads set0(t+1), 3 DMA (t+2)
-  unsigned long long prof_w1 = 0, prof_w2 = 0, prof_p1 = 0, prof_p23 = 0, prof_p4 = 0, prof_tb = 0;
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
     constexpr bool dma = has_next2;
-    // schedule knobs (EXP 6 = default; 7, 8, 9 = variants measured against it)
-    //   R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
-    //   DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after)
-    unsigned long long ts = 0;
-    if constexpr (EXP == 10) { ts = __builtin_readcyclecounter(); W4_PIN(); }
+    // schedule knobs.  R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
+    // DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after); one MFMA sits
+    // between each s_waitcnt and its s_barrier
     constexpr int R1 = 32, B1 = 40, DSTEP = 4;
-    constexpr bool WM = EXP != 7;
-    constexpr bool SPLIT = EXP == 12;        // M0 one MFMA ahead of each DMA            // one MFMA between each s_waitcnt and its s_barrier (EXP 7 = without, for A/B)
     // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -461,18 +375,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       read_frag(t, 1, g);
       W4_PIN();
     }
-    mfma_run(0, R1, B1 - R1 - (WM ? 1 : 0));
+    mfma_run(0, R1, B1 - R1 - 1);
     W4_PIN();
     if constexpr (has_next2) {
-      unsigned long long ta = 0;
-      if constexpr (EXP == 10) { ta = __builtin_readcyclecounter(); W4_PIN(); prof_p1 += ta - ts; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (WM) { W4_PIN(); mfma_run(0, B1 - 1, 1); W4_PIN(); }
+      W4_PIN(); mfma_run(0, B1 - 1, 1); W4_PIN();
       __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
-      if constexpr (EXP == 10) { prof_tb = __builtin_readcyclecounter(); prof_w1 += prof_tb - ta; W4_PIN(); }
       if (t + 2 == nt1) { set_voff(true); W4_PIN(); }
-    } else if constexpr (WM) {
+    } else {
       mfma_run(0, B1 - 1, 1);
       W4_PIN();
     }
@@ -480,29 +391,26 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     {
       constexpr int NM = 100 - B1;             // MFMAs in this span
 #pragma unroll
-      for (int m = 0; m < NM - (WM ? 1 : 0); ++m) {
+      for (int m = 0; m < NM - 1; ++m) {
         const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
         mfma_run(gi >> 6, gi & 63, 1);
-        if constexpr (SPLIT && dma) {
+        if constexpr (dma) {
           if ((m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(t + 2, (m + 2) / DSTEP - 1); W4_PIN(); }
         }
         if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
           W4_PIN();
-          if constexpr (dma) { if constexpr (SPLIT) dma_go(t + 2, (m + 1) / DSTEP - 1); else issue_piece(t + 2, (m + 1) / DSTEP - 1); }
+          if constexpr (dma) dma_go(t + 2, (m + 1) / DSTEP - 1);
           W4_PIN();
         }
       }
     }
     W4_PIN();
     if constexpr (has_next) {
-      unsigned long long tc = 0;
-      if constexpr (EXP == 10) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) prof_p23 += tc - prof_tb; }
       if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if constexpr (WM) { W4_PIN(); mfma_run(1, 35, 1); W4_PIN(); }
+      W4_PIN(); mfma_run(1, 35, 1); W4_PIN();
       __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
-      if constexpr (EXP == 10) { W4_PIN(); prof_tb = __builtin_readcyclecounter(); prof_w2 += prof_tb - tc; }
-    } else if constexpr (WM) {
+    } else {
       mfma_run(1, 35, 1);
     }
     W4_PIN();
@@ -512,72 +420,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       mfma_run(1, 36 + g * 3, 2);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
-      if constexpr (SPLIT && dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, 13 + (g - 1) / 3); }
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, 13 + (g - 1) / 3); }
       W4_PIN();
       mfma_run(1, 36 + g * 3 + 2, 1);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) { if constexpr (SPLIT) dma_go(t + 2, 13 + (g - 1) / 3); else issue_piece(t + 2, 13 + (g - 1) / 3); } }
-      W4_PIN();
-    }
-    mfma_run(1, 60, 4);
-    W4_PIN();
-    if constexpr (EXP == 10 && has_next) { prof_p4 += __builtin_readcyclecounter() - prof_tb; W4_PIN(); }
-  };
-  // EXP == 11 (variant 28): register-staged operands, ONE barrier per K-tile.  A buffer_load into VGPRs costs the MFMA
-  // stream ~3 cycles and a ds_write_b128 ~2, an LDS-DMA instruction ~35 (tools/micro/mfma_dma.hip), so the 16 pieces per wave
-  // and tile cost ~80 instead of ~560 cycles; the price is 64 VGPRs of in-flight data and a lead of exactly one tile:
-  //   P1: 40 MFMAs(kk=0) | 16 reads set1(t)          | lgkmcnt(0), barrier: stage t&1 is dead AND every wave's ds_writes of
-  //                                                     tile t+1 (issued during tile t-1) are complete
-  //   P2-P4: 88 MFMAs | 16 x { ds_write piece q of tile t+2 (loaded during tile t-1) ; buffer_load piece q of tile t+3 }
-  //   P4 also: 16 reads set0(t+1)
-  auto tile_body_rs = [&](int t, auto HAS_NEXT, auto HAS_NEXT2, auto HAS_NEXT3) {
-    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value, has_next3 = decltype(HAS_NEXT3)::value;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      mfma_run(0, g * 2, 2);
-      W4_PIN();
-      read_frag(t, 1, g);
-      W4_PIN();
-    }
-    mfma_run(0, 32, 8);
-    W4_PIN();
-    if constexpr (has_next) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      W4_PIN();
-    }
-    // MFMAs 40..99: 13 pieces, one per 4 MFMAs from MFMA 44 on
-#pragma unroll
-    for (int m = 0; m < 60; ++m) {
-      const int gi = 40 + m;
-      mfma_run(gi >> 6, gi & 63, 1);
-      if ((m + 1) % 4 == 0 && (m + 1) / 4 <= 13) {
-        const int q = (m + 1) / 4 - 1;
-        W4_PIN();
-        if constexpr (has_next2) store_piece(t + 2, q);
-        W4_PIN();
-        if constexpr (has_next3) load_piece(t + 3, q);
-        W4_PIN();
-      }
-    }
-    W4_PIN();
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      mfma_run(1, 36 + g * 3, 2);
-      W4_PIN();
-      if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
-      W4_PIN();
-      mfma_run(1, 36 + g * 3 + 2, 1);
-      W4_PIN();
-      if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
-      if (g == 1 || g == 4 || g == 7) {
-        const int q = 13 + (g - 1) / 3;
-        W4_PIN();
-        if constexpr (has_next2) store_piece(t + 2, q);
-        W4_PIN();
-        if constexpr (has_next3) load_piece(t + 3, q);
-      }
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_go(t + 2, 13 + (g - 1) / 3); }
       W4_PIN();
     }
     mfma_run(1, 60, 4);
@@ -585,76 +433,27 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   };
   using T_ = std::true_type; using F_ = std::false_type;
 
-  if constexpr (EXP == 11) {
+  set_voff(false);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) load_piece(0, q);
+  for (int q = 0; q < 16; ++q) issue_piece(0, q);
+  if (nt > 1) {
+    if (nt1 == 1) set_voff(true);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) store_piece(0, q);
-    if (nt > 1) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) load_piece(1, q);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) store_piece(1, q);
-    }
-    if (nt > 2) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) load_piece(2, q);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int q = 0; q < 16; ++q) issue_piece(1, q);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   } else {
-    set_voff(false);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) issue_piece(0, q);
-    if (nt > 1) {
-      if (nt1 == 1) set_voff(true);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) issue_piece(1, q);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
   W4_PIN();
 #pragma unroll
   for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   W4_PIN();
-  unsigned long long prof_l1 = 0;
-  if constexpr (EXP == 11) {
-    int t = 0;
-    for (; t + 3 < nt; ++t) tile_body_rs(t, T_{}, T_{}, T_{});
-    if (t + 2 < nt) { tile_body_rs(t, T_{}, T_{}, F_{}); ++t; }
-    if (t + 1 < nt) { tile_body_rs(t, T_{}, F_{}, F_{}); ++t; }
-    tile_body_rs(t, F_{}, F_{}, F_{});
-  } else if constexpr (EXP >= 6) {
-    unsigned long long pt0 = 0, pr0 = 0;
-    if constexpr (EXP == 10) { pt0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+  {
     int t = 0;
     for (; t + 2 < nt; ++t) tile_body_ll(t, T_{}, T_{});
     if (t + 1 < nt) { tile_body_ll(t, T_{}, F_{}); ++t; }
     tile_body_ll(t, F_{}, F_{});
-    if constexpr (EXP == 10) {
-      const unsigned long long pt1 = __builtin_readcyclecounter(), pr1 = __builtin_amdgcn_s_memrealtime();
-      if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
-        unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
-        o[0] = pt1 - pt0; o[1] = prof_w1; o[2] = prof_w2; o[3] = pr1 - pr0; o[4] = (unsigned long long)nt;
-        o[10] = prof_p1; o[11] = prof_p23; o[12] = prof_p4;
-        o[5] = pt0 - prof_e0;                                  // entry -> K-loop (index math, 32 DMA pieces, first landing)
-        o[7] = prof_r0;
-        o[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) | (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff00u);
-      }
-      prof_l1 = pt1;
-    }
-  } else if (nt == 1) {
-    tile_body(0, F_{}, F_{}, F_{});
-  } else if (nt == 2) {
-    tile_body(0, F_{}, T_{}, F_{});
-    tile_body(1, F_{}, F_{}, F_{});
-  } else {
-    tile_body(0, F_{}, T_{}, T_{});
-    for (int t = 1; t < nt - 2; ++t) tile_body(t, T_{}, T_{}, T_{});
-    tile_body(nt - 2, T_{}, T_{}, F_{});
-    tile_body(nt - 1, F_{}, F_{}, F_{});
   }
 #undef W4_PIN
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
@@ -687,7 +486,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
         for (int ps = 0; ps < 32; ++ps) {
           const int row = ps * 2 + (lane >> 5), c = lane & 31, m = mbase + row, n = ncol0 + c * 4;
           float4 v = *(const float4*)(stg + row * 512 + ((c ^ (row & 15)) << 4));
-          if (m < p.M && !(diag & 1)) {
+          if (m < p.M) {
             if (p.R) {
               if (p.r_f32) {
                 const float4 r = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
@@ -708,7 +507,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           const float4 lo = *(const float4*)(stg + row * 512 + (((2 * g) ^ (row & 15)) << 4));
           const float4 hi = *(const float4*)(stg + row * 512 + (((2 * g + 1) ^ (row & 15)) << 4));
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          if (m < p.M && !(diag & 1)) {
+          if (m < p.M) {
             if (p.R) {
               if (p.r_f32) {
                 const float4 r0 = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n);
@@ -846,7 +645,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            if (!(diag & 1)) __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 0);
             vo += step;
           }
         }
@@ -855,7 +654,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
         for (int ps = 0; ps < 32; ++ps) {
           const int row = ps * 4 + (lane >> 4), g = lane & 15, m = mb + row;
           const uint4 o = *(const uint4*)(stg + row * 256 + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16);
-          if (m < p.M && !(diag & 1)) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = o;
+          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = o;
         }
       }
       return;
@@ -865,30 +664,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       half(std::integral_constant<int, 1>{}, MD_);
     });
   };
-  auto direct_epi = [&]() {
-    epi_dispatch_plain(p, [&](auto MD_) {
-      constexpr int md = decltype(MD_)::value;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          epilogue4<md>(p, m, n0 + wc * 128 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    });
-  };
-  if constexpr (EXP == 10) { if (diag & 2) direct_epi(); else staged_epi(); }
-  else if constexpr (EXP >= 6) staged_epi();
-  else direct_epi();
-  if constexpr (EXP == 10) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long pe = __builtin_readcyclecounter(), re = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
-      unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
-      o[6] = pe - prof_l1; o[8] = re;
-    }
-  }
+  staged_epi();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1620,9 +1396,8 @@ __device__ __forceinline__ int tn3_off(int row, int col) {
 //       m 48..78 : DMA pieces 0..7 of K-step t+2, one per 4 MFMAs          | vmcnt(8), barrier at 80: K-step t+1 has landed
 //       m 80..127: 16 fragments of set 0 of K-step t+1 (one per 3 MFMAs), DMA pieces 8..15
 //   Measured (M = 32362, one decoder layer's 8 LoRA wgrads): 1.63 ms vs 2.35 ms with the 128x128 kernel; 1.1 PF/s on a 4096^2
-//   output.  PROF = s_memtime stamps (OPADPO_TN_PROF=1), summary on stderr.
+//   output.
 // ------------------------------------------------------------------------------------------
-template <bool PROF>
 __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1654,7 +1429,6 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     }
   const int c = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
-  unsigned long long pf_loop = 0, pf_w1 = 0, pf_w2 = 0, pf_p1 = 0, pf_p23 = 0, pf_p4 = 0, pf_rt = 0, pf_nt = 0, pf_epi = 0, pf_tb = 0;
 
   while (run_s < run_e) {
     const long long cidx = run_s / chunk_len;
@@ -1726,8 +1500,6 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     };
     auto tile_body = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
       constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-      unsigned long long ts = 0, ta = 0, tc = 0;
-      if constexpr (PROF) { ts = __builtin_readcyclecounter(); W4_PIN(); }
       // m 0..39: the 16 fragments of set 1, one per 2 / 3 MFMAs
 #pragma unroll
       for (int g2 = 0; g2 < 16; ++g2) {
@@ -1739,12 +1511,10 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
       mfma_run(0, 40, 7);
       W4_PIN();
       if constexpr (has_next2) {
-        if constexpr (PROF) { ta = __builtin_readcyclecounter(); W4_PIN(); pf_p1 += ta - ts; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_PIN(); mfma_run(0, 47, 1); W4_PIN();
         __builtin_amdgcn_s_barrier();            // the stage of K-step t is dead: it takes K-step t+2
         W4_PIN();
-        if constexpr (PROF) { pf_tb = __builtin_readcyclecounter(); pf_w1 += pf_tb - ta; W4_PIN(); }
       } else {
         mfma_run(0, 47, 1);
         W4_PIN();
@@ -1761,12 +1531,10 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
       }
       W4_PIN();
       if constexpr (has_next) {
-        if constexpr (PROF) { tc = __builtin_readcyclecounter(); W4_PIN(); if constexpr (has_next2) pf_p23 += tc - pf_tb; }
         if constexpr (has_next2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces above stay in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W4_PIN(); mfma_run(1, 15, 1); W4_PIN();
         __builtin_amdgcn_s_barrier();            // K-step t+1 has landed for everyone
-        if constexpr (PROF) { W4_PIN(); pf_tb = __builtin_readcyclecounter(); pf_w2 += pf_tb - tc; }
       } else {
         mfma_run(1, 15, 1);
       }
@@ -1780,7 +1548,6 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
         if constexpr (has_next2) { if (g2 & 1) { W4_PIN(); issue_piece(t + 2, 8 + (g2 >> 1)); } }
         W4_PIN();
       }
-      if constexpr (PROF && has_next) { pf_p4 += __builtin_readcyclecounter() - pf_tb; W4_PIN(); }
     };
     using T_ = std::true_type; using F_ = std::false_type;
 
@@ -1799,13 +1566,10 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
     W4_PIN();
     {
-      unsigned long long l0 = 0, r0 = 0;
-      if constexpr (PROF) { l0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
       int t = 0;
       for (; t + 2 < nt; ++t) tile_body(t, T_{}, T_{});
       if (t + 1 < nt) { tile_body(t, T_{}, F_{}); ++t; }
       tile_body(t, F_{}, F_{});
-      if constexpr (PROF) { pf_tb = __builtin_readcyclecounter(); pf_loop += pf_tb - l0; pf_rt += __builtin_amdgcn_s_memrealtime() - r0; pf_nt += nt; }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     W4_PIN();
@@ -1824,14 +1588,6 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_barrier();      // the next run segment re-uses the stages
-    if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_epi += __builtin_readcyclecounter() - pf_tb; }
-  }
-  if constexpr (PROF) {
-    if (lane == 0 && blockIdx.x < W4_PROF_MAX_WG) {
-      unsigned long long* o = g_w4_prof + ((size_t)blockIdx.x * 4 + wave) * W4_PROF_N;
-      o[0] = pf_loop; o[1] = pf_w1; o[2] = pf_w2; o[3] = pf_rt; o[4] = pf_nt; o[5] = 0; o[6] = pf_epi; o[7] = 0; o[8] = 0; o[9] = blockIdx.x;
-      o[10] = pf_p1; o[11] = pf_p23; o[12] = pf_p4;
-    }
   }
 }
 }  // namespace
@@ -1864,7 +1620,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
@@ -1874,7 +1630,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     if (a.bias || a.act || a.R || a.out_f32 || a.N % P_BN || !ok32 || a.rope_L < 4 || a.rope_cols % 128 ||
         (a.rope_seg_len > 0 && a.rope_seg_len < 4)) return hipErrorInvalidValue;
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   if (a.act == OPADPO_ACT_SWIGLU_BWD) {       // fused SwiGLU backward epilogue (R = stored [gate | up], C = [d_gate | d_up]): the 4-wave 256x256 kernel only
@@ -1882,7 +1638,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                       (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));
     if (a.bias || !a.R || a.r_f32 || a.out_f32 || a.alpha != 1.0f || a.N % P_BN || !ok32 || a.ldr % 8 || a.ldc % 8 || a.rope_cos) return hipErrorInvalidValue;
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: the 4-wave 256x256 kernel, or the weight-streaming kernel for decode
@@ -1905,7 +1661,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       return hipGetLastError();
     }
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();
   }
   // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
@@ -1954,7 +1710,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
     if (plain && g_gemm_variant != 17)      // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
-      hipLaunchKernelGGL(gemm_nt_w4_kernel<12>, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+      hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
     else                                    // bias / activation epilogues (vision tower, projector): 8 waves x 128x64, 4 phases per K-tile
       hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);
     return hipGetLastError();
@@ -1973,7 +1729,7 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (tn_w4 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
       attr = true;
     }
     GemmTNGroup G;
@@ -1984,7 +1740,7 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
     if (G.splits > ksteps) G.splits = ksteps;
     const long long total = (long long)G.splits * tiles4 * ((ksteps + G.splits - 1) / G.splits);
     const dim3 gr((unsigned)(total < 256 ? total : 256));
-    hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, G);
+    hipLaunchKernelGGL(gemm_tn_w4_kernel, gr, dim3(256), 2 * P_STAGE, st, G);
     return hipGetLastError();
   }
   const int tiles = (a.N1 / 128) * (a.N2 / 128);
@@ -2075,7 +1831,7 @@ hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st) {
   }
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr = true;
   }
   GemmTNGroup G;
@@ -2091,6 +1847,6 @@ hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st) {
   if (G.splits > ksteps) G.splits = ksteps;
   const long long total = (long long)G.splits * tiles * ((ksteps + G.splits - 1) / G.splits);
   const dim3 gr((unsigned)(total < 256 ? total : 256));
-  hipLaunchKernelGGL(gemm_tn_w4_kernel<false>, gr, dim3(256), 2 * P_STAGE, st, G);
+  hipLaunchKernelGGL(gemm_tn_w4_kernel, gr, dim3(256), 2 * P_STAGE, st, G);
   return hipGetLastError();
 }
