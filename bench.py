@@ -89,12 +89,12 @@ def cpu_baseline(dims_kw, q_len, t_len):
 def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
     """BASELINE.json configs[4] (on-policy rollout, opadpo/generator_models/online_generator.py:292-309) in the driver's line:
     LLaVA-1.5-7B KV-cache sampling decode (top-k 30 / top-p 0.95, no LoRA = the shipped rollout config), prefill L = 703, `steps`
-    graph-replayed decode steps per batch size.  HBM-bound: bytes per step = bf16 weights of every linear + lm_head (read once per
+    decode steps per batch size.  HBM-bound: bytes per step = bf16 weights of every linear + lm_head (read once per
     step) + the KV cache read of every sequence at the mean context of the timed steps; frac = bytes / time / 8 TB/s."""
     from opadpo_amd.generate import Generator
     from opadpo_amd.synth import synth_pairs
     out = {}
-    gen = Generator(eng, None, use_graph=True, fuse_swiglu=True)
+    gen = Generator(eng, None, fuse_swiglu=True)
     wbytes = 2 * (d.n_layers * (4 * d.hidden ** 2 + 3 * d.hidden * d.ffn) + d.vocab * d.hidden)
     for B in batches:
         p = synth_pairs(d, B, 128, 8, seed=77, device=dev)
@@ -102,7 +102,7 @@ def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
         t = {}
         for n in (2, steps + 2):
             kw = dict(image_feats=feats, max_new_tokens=n, top_k=30, top_p=0.95, suppress_eos=True)
-            gen.generate(p["queries"], p["queries_attn_masks"], seed=1, **kw)            # warm (kernels, graph capture path)
+            gen.generate(p["queries"], p["queries_attn_masks"], seed=1, **kw)            # warm (kernel attribute calls, allocator)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             gen.generate(p["queries"], p["queries_attn_masks"], seed=2, **kw)
@@ -117,7 +117,7 @@ def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
         del feats, p
         torch.cuda.empty_cache()
     return {"workload": "LLaVA-1.5-7B rollout decode, query 128 -> prefill L=703, top-k 30 / top-p 0.95, no LoRA (shipped rollout config), "
-                        "one HIP-graph replay per token", "bound": "hbm", "peak_GBps": 8000.0, **out}
+                        "one C++ launch loop per token inside the context (opadpo_decode_run)", "bound": "hbm", "peak_GBps": 8000.0, **out}
 
 
 def exchange_probe(numel, dev, layer_numel, n_layers):

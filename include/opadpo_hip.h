@@ -331,7 +331,9 @@ int opadpo_decode_begin(opadpo_ctx* ctx, int adapter_id, const int32_t* ids, con
                         int32_t* history, void* stream);
 /* one more token for every row: all launches of a step, asynchronous */
 int opadpo_decode_step(opadpo_ctx* ctx, void* stream);
-/* n_steps more tokens; use_graph: one step is captured into a hipGraph once and replayed per token */
+/* n_steps more tokens.  use_graph = 0: the launches of every step are issued from the library's own loop (no host work between
+ * them; measured faster than graph replay on MI355X: 3.45 vs 3.72 ms per step at 7B / 4 sequences); use_graph = 1: one step is
+ * captured into a hipGraph once and replayed per token (same tokens, bit for bit) */
 int opadpo_decode_run(opadpo_ctx* ctx, int n_steps, int use_graph, void* stream);
 /* synchronous: *all_finished = every row has emitted EOS */
 int opadpo_decode_all_finished(opadpo_ctx* ctx, int* all_finished, void* stream);

@@ -16,6 +16,7 @@ tests/test_ctx_gpu.py checks that both give bit-identical log-probs.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -262,7 +263,7 @@ class CtxEngine(LlavaEngine):
     def generate(self, adapter, queries: torch.Tensor, query_attn_masks: torch.Tensor, image_feats: torch.Tensor, *, max_new_tokens: int,
                  temperature: float, top_k: int, top_p: float, seed: int, eos_token_id: int, pad_token_id: int, suppress_eos: bool,
                  use_graph: bool) -> torch.Tensor:
-        """-> responses [B, max_new_tokens] int64 (pad after a row finished); prefill, KV cache and the per-token hipGraph live in
+        """-> responses [B, max_new_tokens] int64 (pad after a row finished); prefill, KV cache and the per-token launch loop (or hipGraph) live in
         the context (opadpo_decode_begin / opadpo_decode_run)."""
         dev, d = self.dev, self.d
         B, Q = queries.shape

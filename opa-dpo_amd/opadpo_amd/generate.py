@@ -45,11 +45,17 @@ class _WeightsOnlyAdapter:
 
 
 class Generator:
-    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: bool = True, merge_adapter: bool = False,
+    def __init__(self, engine: LlavaEngine, adapter: Optional[LoraAdapter] = None, use_graph: Optional[bool] = None, merge_adapter: bool = False,
                  fuse_swiglu: bool = False):
-        """merge_adapter: fold a FROZEN adapter into its own bf16 copy of the projections (LoraAdapter.merge_into_base) - the
+        """use_graph: replay one captured decode step per token (hipGraph) or launch the step's ~230 kernels one by one.  None = the
+        faster form of the engine: the op-level engine launches from Python (20 us per launch > the step's GPU time) and needs the graph;
+        the context launches from a C++ loop that keeps the queue full, where plain launches measured FASTER than graph replay (7B,
+        B = 4: 3.45 vs 3.72 ms per step, B = 64: see DESIGN.md section 6 - graph nodes pay ~1 us more per kernel boundary).
+        merge_adapter: fold a FROZEN adapter into its own bf16 copy of the projections (LoraAdapter.merge_into_base) - the
         rollout / evaluation policy does not change while it generates, so the 4 LoRA down-projections and the K-concatenated
         tails of every layer and step disappear (13 -> 8 launches per layer; the gate|up projection fuses SwiGLU)."""
+        if use_graph is None:
+            use_graph = not hasattr(engine, "ctx")
         self.engine, self.adapter, self.use_graph = engine, adapter, use_graph
         if merge_adapter and adapter is not None and not adapter.trainable and adapter.merged is None:
             adapter.merge_into_base(engine.base)

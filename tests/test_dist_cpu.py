@@ -55,6 +55,17 @@ def _grads(step):
     return [torch.randn(N, generator=g) * (3.0 if step == 0 else 0.01) for _ in range(2)]   # one per rank
 
 
+def _by_value(items):
+    """Tensors cross the queue as numpy arrays (pickled by value): a torch tensor travels as a file descriptor that the SENDER must
+    keep alive until the parent has received it - a 1-rank worker exits first (ConnectionResetError in the parent)."""
+    return tuple(t.numpy() if isinstance(t, torch.Tensor) else t for t in items)
+
+
+def _from_queue(items):
+    import numpy as np
+    return tuple(torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in items)
+
+
 def _spawn(fn, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -62,7 +73,7 @@ def _spawn(fn, world, *args):
     procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    res = sorted([_from_queue(q.get(timeout=180)) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -92,7 +103,7 @@ def _worker(rank, world, port, q, mode, wire, bucketed):
         norms.append(opt.grad_norm_post_clip())
         opt.zero_grad()
     full_master = opt.state_dict()["master"]
-    q.put((rank, work.float().clone(), full_master.clone(), opt.shard_ranges(), norms))
+    q.put(_by_value((rank, work.float().clone(), full_master.clone(), opt.shard_ranges(), norms)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,7 +170,7 @@ def _ckpt_worker(rank, world, port, q, path, phase):
     sd = opt.state_dict()                      # collective: every rank calls it
     if phase == "save" and rank == 0:
         torch.save(sd, path)
-    q.put((rank, work.float().clone(), sd["master"].clone(), sd["m"].clone(), sd["v"].clone()))
+    q.put(_by_value((rank, work.float().clone(), sd["master"].clone(), sd["m"].clone(), sd["v"].clone())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -232,7 +243,7 @@ def _model_worker(rank, world, port, q):
                     align=8, **CPU_KW)
     opt.launch_bucket(1)
     opt.step()
-    q.put((rank, opt.state_dict()["master"].clone(), opt.grad_norm_post_clip()))
+    q.put(_by_value((rank, opt.state_dict()["master"].clone(), opt.grad_norm_post_clip())))
     dist.barrier()
     dist.destroy_process_group()
 

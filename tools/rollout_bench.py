@@ -37,7 +37,7 @@ def main():
         from opadpo_amd.model import LoraAdapter
         from opadpo_amd.synth import init_lora
         ad = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
-    gen = Generator(eng, ad, merge_adapter=lora == 2, fuse_swiglu=os.environ.get("RB_FUSE", "1") == "1")
+    gen = Generator(eng, ad, merge_adapter=lora == 2, fuse_swiglu=os.environ.get("RB_FUSE", "1") == "1", use_graph={"0": False, "1": True}.get(os.environ.get("RB_GRAPH", ""), None))
     feats = eng.encode_images(p["images"])
     res = {}
     for n in (1, steps):

@@ -15,6 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "opa-dpo_amd"))
 from opadpo_amd import lib as L  # noqa: E402
 from opadpo_amd.dims import LlavaDims  # noqa: E402
+from opadpo_amd.ctx import CtxEngine
 from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter  # noqa: E402
 from opadpo_amd.policy import AutoregressivePolicy  # noqa: E402
 from opadpo_amd.synth import init_lora, init_weights, synth_rollout_batches  # noqa: E402
@@ -29,7 +30,8 @@ def main():
     pack = os.environ.get("SB_PACK", "1") == "1"
     Q, T = 128, 384
     d = LlavaDims.llava15_7b()
-    eng = LlavaEngine(BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True))
+    base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
+    eng = LlavaEngine(base) if os.environ.get("OPADPO_OP_LEVEL") == "1" else CtxEngine(base)      # default: the product path (opadpo_ctx, ragged rows)
     pol = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref = LoraAdapter(d, init_lora(d, seed=2, device=dev), dev, trainable=False)
     if os.environ.get("SB_MERGE_REF", "1") == "1":

@@ -12,6 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "opa-dpo_amd"))
 from opadpo_amd import lib as L  # noqa: E402
 from opadpo_amd.dims import LlavaDims  # noqa: E402
+from opadpo_amd.ctx import CtxEngine
 from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter  # noqa: E402
 from opadpo_amd.sft import SFTTrainer  # noqa: E402
 from opadpo_amd.synth import init_lora, init_weights, synth_pairs  # noqa: E402
@@ -24,7 +25,8 @@ def main():
     B = int(os.environ.get("SB_BATCH", 24))
     steps = int(os.environ.get("SB_STEPS", 3))
     d = LlavaDims.llava15_7b()
-    eng = LlavaEngine(BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True))
+    base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
+    eng = LlavaEngine(base) if os.environ.get("OPADPO_OP_LEVEL") == "1" else CtxEngine(base)      # default: the product path (opadpo_ctx, ragged rows)
     lora = init_lora(d, seed=1, device=dev, with_vision=True)
     tr = SFTTrainer(eng, LoraAdapter(d, lora, dev, trainable=True), VisionLoraAdapter(d, lora, dev), response_len=384, lr=1e-6)
     p = synth_pairs(d, B, 128, 384, seed=3, device=dev)

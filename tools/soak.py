@@ -6,6 +6,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "opa-dpo_amd"))
 from opadpo_amd.dims import LlavaDims
 from opadpo_amd.losses import DPOArgs, pair_loss
+from opadpo_amd.ctx import CtxEngine
 from opadpo_amd.model import BaseWeights, LlavaEngine, LoraAdapter
 from opadpo_amd.optim import FlatAdamW
 from opadpo_amd.policy import AutoregressivePolicy
@@ -17,7 +18,7 @@ def main():
     steps, pairs, lr = int(os.environ.get("SOAK_STEPS", 10)), int(os.environ.get("SOAK_PAIRS", 22)), float(os.environ.get("SOAK_LR", 2e-5))
     d = LlavaDims.llava15_7b()
     base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
-    eng = LlavaEngine(base)
+    eng = LlavaEngine(base) if os.environ.get("OPADPO_OP_LEVEL") == "1" else CtxEngine(base)
     pol = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=True)
     ref = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, trainable=False)          # same start as the policy: loss = log 2 at step 0
     ref.merge_into_base(base)
