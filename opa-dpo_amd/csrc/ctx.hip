@@ -361,7 +361,13 @@ hipError_t ensure_rope(opadpo_ctx* c, int len, hipStream_t st) {
 // ---- one Llama decoder layer over M = S*Lp rows (model.py layer_fwd / mlp_fwd) ------------------------------------------------
 struct LayerBufs { bf16_t *n1, *qkv, *t_qkv, *attn, *t_o, *n2, *t_gu, *gu, *act, *t_d; float *rstd1, *rstd2, *lse, *h; };
 
-hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* h, float* xo, const LayerBufs& b, int M, int stream_hint, hipStream_t st) {
+// ydef != nullptr ("deferred residual", the full-sequence passes): the down projection writes its fp32 product to ydef WITHOUT the
+// residual - the RMSNorm that follows adds it (rmsnorm_sum_fwd: x = h + y in the same fp32 arithmetic, so h / x keep their bits).
+// A residual operand in the epilogue of a 256x256 tile makes every CU read 256 KiB at the same moment at the end of each round of
+// tiles: +0.21-0.28 ms on a 0.6-1.6 ms GEMM (tools/resid_probe.py), while the norm kernel takes the same bytes at 6 TB/s (+0.13 ms).
+// ydef == nullptr (decode steps: a few rows): residual in the epilogue, result in xo.
+hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* h, float* xo, const LayerBufs& b, int M, int stream_hint, hipStream_t st,
+                   float* ydef = nullptr, bool norm_done = false) {
   const opadpo_dims& d = c->d;
   const int H = d.hidden, F = d.ffn, r = d.lora_r;
   const float s = d.lora_alpha / d.lora_r;
@@ -371,7 +377,7 @@ hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const fl
   const LoraOff o = lora_off(d);
   const bf16_t* lw = ad.kind == 1 ? ad.work + (size_t)i * o.layer : nullptr;
   hipError_t e;
-  if ((e = launch_rmsnorm_fwd(h, 1, w0.ln2, b.n2, b.rstd2, M, H, d.rms_eps, st)) != hipSuccess) return e;
+  if (!norm_done && (e = launch_rmsnorm_fwd(h, 1, w0.ln2, b.n2, b.rstd2, M, H, d.rms_eps, st)) != hipSuccess) return e;
   bool have_gu = true;
   if (lw) {
     GemmNTArgs g1_ = gemm(c, b.n2, H, lw + o.a_gu, H, H, b.t_gu, 2 * r, 0, M, 2 * r); g1_.alpha = s; g1_.act |= stream_hint;
@@ -390,16 +396,21 @@ hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const fl
   if (lw) {
     GemmNTArgs g3 = gemm(c, b.act, F, lw + o.a_d, F, F, b.t_d, r, 0, M, r); g3.alpha = s; g3.act |= stream_hint;
     if ((e = run_gemm(c, g3, st)) != hipSuccess) return e;
-    GemmNTArgs g4 = gemm(c, b.act, F, w.wd, F, F, xo, H, 1, M, H); tail(g4, b.t_d, r, lw + o.b_d, r, r); resid(g4, h, H, 1); g4.act |= stream_hint;
+    GemmNTArgs g4 = gemm(c, b.act, F, w.wd, F, F, ydef ? ydef : xo, H, 1, M, H); tail(g4, b.t_d, r, lw + o.b_d, r, r); g4.act |= stream_hint;
+    if (!ydef) resid(g4, h, H, 1);
     return run_gemm(c, g4, st);
   }
-  GemmNTArgs g4 = gemm(c, b.act, F, w.wd, F, F, xo, H, 1, M, H); resid(g4, h, H, 1); g4.act |= stream_hint;
+  GemmNTArgs g4 = gemm(c, b.act, F, w.wd, F, F, ydef ? ydef : xo, H, 1, M, H); g4.act |= stream_hint;
+  if (!ydef) resid(g4, h, H, 1);
   return run_gemm(c, g4, st);
 }
 
 struct Rag { const int32_t* meta; int stride, n_seg, rows; const int32_t* row_pos; };      // ragged rows of a pass (nullptr = padded)
 
-hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* x, float* xo, const LayerBufs& b, int S, int Lp,
+// Input of the layer: x = res (+ yin when yin != nullptr: the previous layer's down-projection product, residual deferred).  x is written
+// to `x` (may alias res when yin is null), the layer leaves h = x + attention branch in b.h and its own down-projection product in Y:
+// the caller hands (b.h, Y) to the next layer / the final norm.
+hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* res, const float* yin, float* x, float* Y, const LayerBufs& b, int S, int Lp,
                      const uint8_t* key_mask, int seg0, int seg1, bf16_t* kc, bf16_t* vc, int max_ctx, hipStream_t st, const Rag* rg = nullptr) {
   const opadpo_dims& d = c->d;
   const int H = d.hidden, r = d.lora_r, nh = d.n_heads, hd = d.head_dim;
@@ -410,7 +421,10 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   const LoraOff o = lora_off(d);
   const bf16_t* lw = ad.kind == 1 ? ad.work + (size_t)i * o.layer : nullptr;
   hipError_t e;
-  if ((e = launch_rmsnorm_fwd(x, 1, w0.ln1, b.n1, b.rstd1, M, H, d.rms_eps, st)) != hipSuccess) return e;
+  const size_t MH = (size_t)M * H;
+  if (yin) e = launch_rmsnorm_sum_fwd(res, 1, yin, 1, MH, w0.ln1, x, b.n1, b.rstd1, M, H, d.rms_eps, st);
+  else e = (res == x) ? launch_rmsnorm_fwd(x, 1, w0.ln1, b.n1, b.rstd1, M, H, d.rms_eps, st) : hipErrorInvalidValue;
+  if (e != hipSuccess) return e;
   if (lw) {
     GemmNTArgs g1_ = gemm(c, b.n1, H, lw + o.a_qkv, H, H, b.t_qkv, 3 * r, 0, M, 3 * r); g1_.alpha = s;
     if ((e = run_gemm(c, g1_, st)) != hipSuccess) return e;
@@ -435,19 +449,20 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   if (lw) {
     GemmNTArgs g3 = gemm(c, b.attn, H, lw + o.a_o, H, H, b.t_o, r, 0, M, r); g3.alpha = s;
     if ((e = run_gemm(c, g3, st)) != hipSuccess) return e;
-    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, b.h, H, 1, M, H); tail(g4, b.t_o, r, lw + o.b_o, r, r); resid(g4, x, H, 1);
+    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, Y, H, 1, M, H); tail(g4, b.t_o, r, lw + o.b_o, r, r);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
   } else {
-    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, b.h, H, 1, M, H); resid(g4, x, H, 1);
+    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, Y, H, 1, M, H);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
   }
-  return mlp_fwd(c, i, ad, b.h, xo, b, M, 0, st);
+  if ((e = launch_rmsnorm_sum_fwd(x, 1, Y, 1, MH, w0.ln2, b.h, b.n2, b.rstd2, M, H, d.rms_eps, st)) != hipSuccess) return e;      // h = x + attn . Wo, n2 = norm(h)
+  return mlp_fwd(c, i, ad, b.h, nullptr, b, M, 0, st, Y, true);
 }
 
 size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   const size_t M = sv->M, H = d.hidden, F = d.ffn, r = d.lora_r, nl = d.n_layers, nb = sv->nb, R = sv->R;
   Carve cv(base);
-  sv->x = cv.take<float>((sv->train ? nl + 1 : 2) * M * H);
+  sv->x = cv.take<float>((sv->train ? nl + 1 : 3) * M * H);      // x_0 .. x_{nl-1} (train) or two alternating slots, + ONE slot for the branch product Y
   sv->n1 = cv.take<bf16_t>(nb * M * H);
   sv->rstd1 = cv.take<float>(nb * M);
   sv->qkv = cv.take<bf16_t>(nb * M * 3 * H);
@@ -755,19 +770,23 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   } else {
     CKS(launch_embed_splice(ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x, 1, sv->key_mask, S, n_txt, P, H, OPADPO_IMAGE_TOKEN, st));
   }
+  float* const Y = sv->x + (size_t)(train ? d.n_layers : 2) * MH;          // branch product of the o / down projections (residual deferred)
+  const float* res = sv->x;
+  const float* yin = nullptr;
   for (int i = 0; i < d.n_layers; ++i) {
-    const int k = train ? i : 0;
-    const float* x = sv->x + (size_t)(train ? i : (i & 1)) * MH;
-    float* xo = sv->x + (size_t)(train ? i + 1 : ((i + 1) & 1)) * MH;
-    CKS(layer_fwd(c, i, ad, x, xo, slot(d, sv, k), S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg));
+    const LayerBufs lb = slot(d, sv, train ? i : 0);
+    float* x = sv->x + (size_t)(train ? i : (i & 1)) * MH;
+    CKS(layer_fwd(c, i, ad, res, yin, x, Y, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg));
+    res = lb.h; yin = Y;
   }
-  const float* xf = sv->x + (size_t)(train ? d.n_layers : (d.n_layers & 1)) * MH;
   const int R = sv->R;
   if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(R), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels);
   else hipLaunchKernelGGL(head_index_kernel, g1(R), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
   CKS(hipGetLastError());
-  CKS(launch_gather_rows((const bf16_t*)xf, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));       // fp32 rows = 2H bf16 units
-  CKS(launch_rmsnorm_fwd(sv->hs, 1, c->norm, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
+  // final hidden state x = h + y of the HEAD rows only (fp32 rows = 2H bf16 units; the y rows park in the logits buffer, written later)
+  CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
+  CKS(launch_gather_rows((const bf16_t*)Y, 2 * H, sv->rows, (bf16_t*)sv->logits, R, 2 * H, st));
+  CKS(launch_rmsnorm_sum_fwd(sv->hs, 1, sv->logits, 1, (size_t)R * H, c->norm, sv->hs, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
   { GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head, H, H, sv->logits, d.vocab, 1, R, d.vocab); CKS(run_gemm(c, g, st)); }
   CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, logp, sv->ent, sv->lse_head, R, d.vocab, st));
   CKS(hipMemcpyAsync(ent, sv->ent, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1052,7 +1071,7 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   size_t pbytes = 0;
   auto playout = [&](void* base) {
     Carve cv(base);
-    pf.x = cv.take<float>(2 * (size_t)M * H); pf.n1 = cv.take<bf16_t>((size_t)M * H); pf.rstd1 = cv.take<float>(M); pf.qkv = cv.take<bf16_t>((size_t)M * 3 * H);
+    pf.x = cv.take<float>(3 * (size_t)M * H); pf.n1 = cv.take<bf16_t>((size_t)M * H); pf.rstd1 = cv.take<float>(M); pf.qkv = cv.take<bf16_t>((size_t)M * 3 * H);
     pf.t_qkv = cv.take<bf16_t>((size_t)M * 3 * r); pf.attn = cv.take<bf16_t>((size_t)M * H); pf.lse = cv.take<float>((size_t)B * nh * Lp);
     pf.t_o = cv.take<bf16_t>((size_t)M * r); pf.h = cv.take<float>((size_t)M * H); pf.n2 = cv.take<bf16_t>((size_t)M * H); pf.rstd2 = cv.take<float>(M);
     pf.t_gu = cv.take<bf16_t>((size_t)M * 2 * r); pf.gu = cv.take<bf16_t>((size_t)M * 2 * F); pf.act = cv.take<bf16_t>((size_t)M * F); pf.t_d = cv.take<bf16_t>((size_t)M * r);
@@ -1076,13 +1095,17 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   CKD(hipGetLastError());
   const size_t MH = (size_t)M * H, per_layer = (size_t)B * nh * max_ctx * hd;
   const LayerBufs pb = slot(d, &pf, 0);
-  for (int i = 0; i < d.n_layers; ++i)
-    CKD(layer_fwd(c, i, ad, pf.x + (size_t)(i & 1) * MH, pf.x + (size_t)((i + 1) & 1) * MH, pb, B, Lp, pf.key_mask, 0, 0, D.kc + i * per_layer,
+  float* const Yp = pf.x + 2 * MH;
+  const float* yin = nullptr;
+  for (int i = 0; i < d.n_layers; ++i) {
+    CKD(layer_fwd(c, i, ad, i == 0 ? pf.x : pb.h, yin, pf.x + (size_t)(i & 1) * MH, Yp, pb, B, Lp, pf.key_mask, 0, 0, D.kc + i * per_layer,
                   D.vc + i * per_layer, max_ctx, st));
-  const float* xf = pf.x + (size_t)(d.n_layers & 1) * MH;
+    yin = Yp;
+  }
   hipLaunchKernelGGL(affine_index_kernel, g1(B), dim3(256), 0, st, pf.rows, B, Lp, Lp - 1);
   CKD(hipGetLastError());
-  CKD(launch_gather_rows((const bf16_t*)xf, 2 * H, pf.rows, (bf16_t*)D.hs, B, 2 * H, st));
+  CKD(launch_gather_rows((const bf16_t*)pb.h, 2 * H, pf.rows, (bf16_t*)D.hs, B, 2 * H, st));          // last position: x = h + y, added by the head's norm
+  CKD(launch_gather_rows((const bf16_t*)Yp, 2 * H, pf.rows, (bf16_t*)D.x, B, 2 * H, st));
   CKD(hipMemsetAsync(D.finished, 0, B, st));
   CKD(hipMemsetAsync(D.step_d, 0, sizeof(int32_t), st));
   { const int32_t p0 = Lp - 1; CKD(hipMemcpyAsync(D.pos_d, &p0, sizeof(int32_t), hipMemcpyHostToDevice, st)); CKD(hipStreamSynchronize(st)); }
@@ -1092,7 +1115,7 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
     CKD(hipMemcpyAsync(history, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     CKD(hipStreamSynchronize(st));
   }
-  CKD(decode_head(c, D.hs, nullptr, 0, st));      // token 0 from the prefill logits
+  CKD(decode_head(c, D.hs, D.x, 1, st));          // token 0 from the prefill logits
 #undef CKD
   ctx_free(c, parena, pbytes);
   return 0;

@@ -98,7 +98,7 @@ class Generator:
         # ---- prefill: full-sequence kernels, K/V of every layer copied into the cache -----------------------
         sv = Saved()
         M = B * Lp
-        sv.x = e((2, M, H), torch.float32)
+        sv.x = e((3, M, H), torch.float32)
         sv.n1, sv.qkv, sv.t_qkv, sv.attn = e((1, M, H)), e((1, M, 3 * H)), e((1, M, 3 * r)), e((1, M, H))
         sv.lse, sv.t_o, sv.h, sv.n2 = e((1, B, nh, Lp), torch.float32), e((1, M, r)), e((1, M, H), torch.float32), e((1, M, H))
         sv.t_gu, sv.gu, sv.act, sv.t_d = e((1, M, 2 * r)), e((1, M, 2 * F)), e((1, M, F)), e((1, M, r))
@@ -117,9 +117,10 @@ class Generator:
             vc[i, :, :, :Lp].copy_(q5[:, :, 2].transpose(1, 2))
 
         cos, sin = b.rope_tables(max_ctx)
+        Yp, yin = sv.x[2], None
         for i in range(d.n_layers):
-            eng.layer_fwd(i, self.adapter, sv.x[i & 1], sv.x[(i + 1) & 1], sv, 0, B, Lp, km_prefill, cos, sin, kv_hook)
-        xf = sv.x[d.n_layers & 1]
+            eng.layer_fwd(i, self.adapter, sv.x[0] if i == 0 else sv.h[0], yin, sv.x[i & 1], Yp, sv, 0, B, Lp, km_prefill, cos, sin, kv_hook)
+            yin = Yp
         last = (torch.arange(B, device=dev, dtype=torch.int32) * Lp + (Lp - 1)).contiguous()
         # ---- decode: ONE step captured in a HIP graph and replayed per token -----------------------------------
         # Everything that changes from step to step lives in device memory (position / step counter,
@@ -145,8 +146,11 @@ class Generator:
         ad = self.adapter
         eos_arg = -1 if suppress_eos else eos_token_id
 
-        def head(src_f32):
-            L.call("opadpo_rmsnorm_fwd", L.ptr(src_f32), 1, L.ptr(b.norm), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, L.stream())
+        def head(src_f32, add_f32=None):
+            if add_f32 is not None:      # prefill: last position x = h + y (down-projection product, residual deferred)
+                L.call("opadpo_rmsnorm_sum_fwd", L.ptr(src_f32), 1, L.ptr(add_f32), 1, B * H, L.ptr(b.norm), L.ptr(x2), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, L.stream())
+            else:
+                L.call("opadpo_rmsnorm_fwd", L.ptr(src_f32), 1, L.ptr(b.norm), L.ptr(hn), L.ptr(rstd), B, H, d.rms_eps, L.stream())
             L.gemm_nt(hn, b.lm_head, logits)
             if suppress_eos:
                 logits[:, eos_token_id] = float("-inf")
@@ -182,9 +186,10 @@ class Generator:
                 cur, nx = nx, (x2 if nx is x else x)
             head(cur)
 
-        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
+        L.call("opadpo_gather_rows", L.ptr(sv.h[0]), 2 * H, L.ptr(last), L.ptr(hs), B, 2 * H, st)
+        L.call("opadpo_gather_rows", L.ptr(Yp), 2 * H, L.ptr(last), L.ptr(x), B, 2 * H, st)
         with L.decode_schedule():                  # M = B <= 64 GEMMs: weight-streaming kernel
-            head(hs)                               # token 0 from the prefill logits
+            head(hs, x)                            # token 0 from the prefill logits
             graph = None
             for step in range(1, max_new_tokens):
                 if step == 2 and self.use_graph and max_new_tokens > 3:

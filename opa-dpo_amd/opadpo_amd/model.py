@@ -373,7 +373,7 @@ class LlavaEngine:
         sv.S, sv.L, sv.T, sv.M, sv.train = S, Lp, T, M, train
         nb = nl if train else 1
         e = lambda shape, dtype=BF: torch.empty(*shape, dtype=dtype, device=self.dev)
-        sv.x = e((nl + 1 if train else 2, M, H), torch.float32)     # fp32 residual stream
+        sv.x = e((nl + 1 if train else 3, M, H), torch.float32)     # fp32 residual stream x_0..x_{nl-1} (train) / two alternating slots, + the branch product Y
         sv.n1 = e((nb, M, H))
         sv.rstd1 = e((nb, M), torch.float32)
         sv.qkv = e((nb, M, 3 * H))
@@ -397,11 +397,14 @@ class LlavaEngine:
         sv.lse_head = e((R,), torch.float32)
         return sv
 
-    def layer_fwd(self, i: int, adapter: Optional[LoraAdapter], x, xo, sv, k: int, S: int, Lp: int, key_mask, cos, sin,
+    def layer_fwd(self, i: int, adapter: Optional[LoraAdapter], res, yin, x, Y, sv, k: int, S: int, Lp: int, key_mask, cos, sin,
                   kv_hook=None, seg=(0, 0)) -> None:
-        """One Llama decoder layer over M = S*Lp rows: x (fp32 residual stream) -> xo.  `adapter=None` runs the
-        bare base model (the shipped rollout config has no LoRA: run/online_generate.sh POLICY_LORA_DIR=none).
-        sv.<buf>[k] are the activation buffers; kv_hook(i, qkv) sees the post-RoPE q|k|v (KV-cache fill)."""
+        """One Llama decoder layer over M = S*Lp rows (csrc/ctx.hip layer_fwd).  Input x = res (+ yin: the previous layer's
+        down-projection product, its residual add deferred to this layer's norm; yin None: x is res).  Leaves h = x + attention
+        branch in sv.h[k] and the layer's own down-projection product in Y (fp32, no residual in the GEMM epilogue: a residual read
+        at the end of a round of 256x256 tiles costs +0.21-0.28 ms per projection, the norm kernel adds it at 6 TB/s).
+        `adapter=None` runs the bare base model (the shipped rollout config has no LoRA: run/online_generate.sh
+        POLICY_LORA_DIR=none).  sv.<buf>[k] are the activation buffers; kv_hook(i, qkv) sees the post-RoPE q|k|v (KV-cache fill)."""
         d, w = self.d, self.base.layers[i]
         mlp_adapter = adapter
         if adapter is not None and adapter.merged is not None:      # frozen adapter folded into its own weight copy
@@ -413,7 +416,11 @@ class LlavaEngine:
         s = d.lora_scale
         n1, qkv, t_qkv, attn, t_o, h, n2, t_gu, gu, act, t_d = (sv.n1[k], sv.qkv[k], sv.t_qkv[k], sv.attn[k], sv.t_o[k],
                                                                  sv.h[k], sv.n2[k], sv.t_gu[k], sv.gu[k], sv.act[k], sv.t_d[k])
-        L.call("opadpo_rmsnorm_fwd", L.ptr(x), int(x.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
+        if yin is not None:
+            L.call("opadpo_rmsnorm_sum_fwd", L.ptr(res), 1, L.ptr(yin), 1, M * H, L.ptr(w["ln1"]), L.ptr(x), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
+        else:
+            assert res.data_ptr() == x.data_ptr()
+            L.call("opadpo_rmsnorm_fwd", L.ptr(x), int(x.dtype == torch.float32), L.ptr(w["ln1"]), L.ptr(n1), L.ptr(sv.rstd1[k]), M, H, d.rms_eps, st)
         # rotary embedding fused into the projection's epilogue (each 128-column block of q and k is one head): OPT-IN
         # (OPADPO_FUSE_ROPE=1).  Measured neutral at the bench shape: the epilogue pays 7.7 us per block for the fp32 cos / sin rows
         # (8 B of table per 2 B of output, latency-bound inside a one-block-per-CU kernel) - as much as the in-place kernel it saves.
@@ -436,19 +443,23 @@ class LlavaEngine:
                L.ptr(sv.lse[k]), L.ptr(key_mask), S, Lp, nh, hd, L.CAUSAL_SKIP_MASKED_Q, hd ** -0.5, seg[0], seg[1], st)
         if adapter is not None:
             L.gemm_nt(attn, adapter.w(i, "a_o"), t_o, alpha=s)
-            L.gemm_nt(attn, w["wo"], h, a2=t_o, b2=adapter.w(i, "b_o"), residual=x)
+            L.gemm_nt(attn, w["wo"], Y, a2=t_o, b2=adapter.w(i, "b_o"))
         else:
-            L.gemm_nt(attn, w["wo"], h, residual=x)
-        self.mlp_fwd(i, mlp_adapter, h, xo, n2, t_gu, gu, act, t_d, sv.rstd2[k], M)
+            L.gemm_nt(attn, w["wo"], Y)
+        L.call("opadpo_rmsnorm_sum_fwd", L.ptr(x), 1, L.ptr(Y), 1, M * H, L.ptr(w["ln2"]), L.ptr(h), L.ptr(n2), L.ptr(sv.rstd2[k]), M, H, d.rms_eps, st)
+        self.mlp_fwd(i, mlp_adapter, h, None, n2, t_gu, gu, act, t_d, sv.rstd2[k], M, ydef=Y, norm_done=True)
 
-    def mlp_fwd(self, i: int, adapter: Optional[LoraAdapter], h, xo, n2, t_gu, gu, act, t_d, rstd2, M: int) -> None:
+    def mlp_fwd(self, i: int, adapter: Optional[LoraAdapter], h, xo, n2, t_gu, gu, act, t_d, rstd2, M: int, ydef=None, norm_done: bool = False) -> None:
+        """ydef: the down projection writes its product there WITHOUT the residual (full-sequence passes, see layer_fwd); None
+        (decode steps): residual in the epilogue, result in xo."""
         d, w = self.d, self.base.layers[i]
         if adapter is not None and adapter.merged is not None:
             w = dict(w, **adapter.merged[i])
             adapter = None
         st = L.stream()
         H, F, r, s = d.hidden, d.ffn, d.lora_r, d.lora_scale
-        L.call("opadpo_rmsnorm_fwd", L.ptr(h), int(h.dtype == torch.float32), L.ptr(w["ln2"]), L.ptr(n2), L.ptr(rstd2), M, H, d.rms_eps, st)
+        if not norm_done:
+            L.call("opadpo_rmsnorm_fwd", L.ptr(h), int(h.dtype == torch.float32), L.ptr(w["ln2"]), L.ptr(n2), L.ptr(rstd2), M, H, d.rms_eps, st)
         if adapter is not None:
             L.gemm_nt(n2, adapter.w(i, "a_gu"), t_gu, alpha=s)
             L.gemm_nt(n2, w["wgu"], gu, a2=t_gu, b2=adapter.w(i, "b_gu"), a2_group_n=F, a2_group_stride=r)
@@ -460,9 +471,9 @@ class LlavaEngine:
             L.call("opadpo_silu_mul_fwd", L.ptr(gu), L.ptr(act), M, F, st)
         if adapter is not None:
             L.gemm_nt(act, adapter.w(i, "a_d"), t_d, alpha=s)
-            L.gemm_nt(act, w["wd"], xo, a2=t_d, b2=adapter.w(i, "b_d"), residual=h)
+            L.gemm_nt(act, w["wd"], xo if ydef is None else ydef, a2=t_d, b2=adapter.w(i, "b_d"), residual=h if ydef is None else None)
         else:
-            L.gemm_nt(act, w["wd"], xo, residual=h)
+            L.gemm_nt(act, w["wd"], xo if ydef is None else ydef, residual=h if ydef is None else None)
 
     def seq_logprobs_fwd(self, adapter: LoraAdapter, batch: SeqBatch, feats: torch.Tensor, temperature: float,
                          train: bool):
@@ -488,12 +499,12 @@ class LlavaEngine:
                L.ptr(batch.feat_row), L.ptr(batch.image_mask), L.ptr(x0), 1, L.ptr(sv.key_mask), S, n_txt, P, H,
                IMAGE_TOKEN_INDEX, st)
         cos, sin = b.rope_tables(Lp)
+        Y = sv.x[d.n_layers if train else 2]          # branch product of the o / down projections (residual deferred to the next norm)
+        res, yin = x0, None
         for i in range(d.n_layers):
             k = i if train else 0
-            x = sv.x[i if train else (i & 1)]
-            xo = sv.x[i + 1 if train else ((i + 1) & 1)]
-            self.layer_fwd(i, adapter, x, xo, sv, k, S, Lp, sv.key_mask, cos, sin, seg=seg)
-        xf = sv.x[d.n_layers if train else (d.n_layers & 1)]
+            self.layer_fwd(i, adapter, res, yin, sv.x[i if train else (i & 1)], Y, sv, k, S, Lp, sv.key_mask, cos, sin, seg=seg)
+            res, yin = sv.h[k], Y
         # response rows: the position before each response token predicts it (rl_models.py:121-123: logits[:, -T-1:-1]).
         # Packed rows: token 0 of EVERY response is predicted from the last prefix position, token t >= 1 of response k
         # from position pfx + k*T + t - 1.  Output order is [k][s][t] = the reference's stacking of the response keys.
@@ -504,8 +515,10 @@ class LlavaEngine:
         rows = (ar(S)[None, :, None] * Lp + off).reshape(-1).contiguous()            # [K,S,T]
         labels = batch.ids[:, n_txt - K * T:].reshape(S, K, T).transpose(0, 1).contiguous().view(-1)
         sv.rows, sv.labels = rows, labels
-        L.call("opadpo_gather_rows", L.ptr(xf), 2 * H, L.ptr(rows), L.ptr(sv.hs), R, 2 * H, st)   # fp32 rows = 2H bf16 units
-        L.call("opadpo_rmsnorm_fwd", L.ptr(sv.hs), 1, L.ptr(b.norm), L.ptr(sv.hn), L.ptr(sv.rstd_f), R, H, d.rms_eps, st)
+        # final hidden state x = h + y of the HEAD rows only (fp32 rows = 2H bf16 units; the y rows park in the logits buffer)
+        L.call("opadpo_gather_rows", L.ptr(res), 2 * H, L.ptr(rows), L.ptr(sv.hs), R, 2 * H, st)
+        L.call("opadpo_gather_rows", L.ptr(Y), 2 * H, L.ptr(rows), L.ptr(sv.logits), R, 2 * H, st)
+        L.call("opadpo_rmsnorm_sum_fwd", L.ptr(sv.hs), 1, L.ptr(sv.logits), 1, R * H, L.ptr(b.norm), L.ptr(sv.hs), L.ptr(sv.hn), L.ptr(sv.rstd_f), R, H, d.rms_eps, st)
         L.gemm_nt(sv.hn, b.lm_head, sv.logits)
         logp = torch.empty(R, dtype=torch.float32, device=self.dev)
         ent = torch.empty(R, dtype=torch.float32, device=self.dev)
