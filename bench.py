@@ -343,7 +343,7 @@ def main():
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
                           "global_pairs_per_step": pairs_per_step, "seq_len": q_len + t_len,
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
-                          "loss": float(loss)},
+                          "loss": float(loss.detach()) if hasattr(loss, "detach") else float(loss)},
                "executed_flops_per_pair_TF": fl / 1e12, "reference_layout_flops_per_pair_TF": fl_ref / 1e12,
                # hardware utilisation = FLOPs this run EXECUTES per second / peak.  The packed layout executes 0.66x the FLOPs of the
                # reference's stacked layout per pair (reference_layout_flops_per_pair_TF); that saving is credited in pairs/s only.
