@@ -140,17 +140,36 @@ __global__ __launch_bounds__(256) void embed_splice_ragged_kernel(const int32_t*
   }
   if (threadIdx.x == 0) { key_mask[row] = mk; row_pos[row] = rpos; }
 }
-// rows[k,s,t]: the compact row that predicts token t of response k (token 0: the last prefix row; token t: row t-1 of the response,
-// clamped into its valid rows - a label behind the valid tokens is pad and its log-prob is -0.0 whatever row is read)
+// Head rows of a ragged pass are COMPACT as well: only the cells (k, s, t) with t < valid length of response k get a head row (the
+// others are padding: their log-prob is -0.0 / entropy 0 by definition, so no lm_head row, no softmax, no gradient is spent on them -
+// 44 % of the [K,S,T] cells of a synthetic seq512 pair).  Cell (k,s,t) -> compact index j = off[s][k] + t (off = exclusive prefix sum of
+// the valid lengths in [k][s] order, meta[3 + K + k]); rows[j] = the compact activation row that predicts the token (token 0: the last
+// prefix row; token t: row t-1 of the response), labels[j] = the token, cell[j] = the flat [K,S,T] index the result is scattered to.
 __global__ void head_index_ragged_kernel(const int32_t* ids, const int32_t* meta, int stride, int S, int n_txt, int K, int T, int32_t* rows,
-                                         int32_t* labels) {
+                                         int32_t* labels, int32_t* cell) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K * S * T) return;
   const int t = i % T, s = (i / T) % S, k = i / (T * S);
   const int32_t* m = meta + (size_t)s * stride;
   const int b0 = m[1], bk = m[1 + k], vk = m[2 + k] - bk;
-  rows[i] = m[0] + ((t == 0 || vk == 0) ? b0 - 1 : bk + min(t, vk) - 1);
-  labels[i] = ids[(size_t)s * n_txt + (n_txt - K * T) + k * T + t];
+  if (t >= vk) return;
+  const int j = m[3 + K + k] + t;
+  rows[j] = m[0] + (t == 0 ? b0 - 1 : bk + t - 1);
+  labels[j] = ids[(size_t)s * n_txt + (n_txt - K * T) + k * T + t];
+  cell[j] = i;
+}
+// out[i] = fill for every cell, then out[cell[j]] = src[j] (two launches: the fill must be complete first)
+__global__ void fill_f32_kernel(float* a, float va, float* b, float vb, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { a[i] = va; b[i] = vb; }
+}
+__global__ void scatter_cells_kernel(const float* a_c, const float* b_c, const int32_t* cell, float* a, float* b, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) { a[cell[j]] = a_c[j]; b[cell[j]] = b_c[j]; }
+}
+__global__ void gather_cells_kernel(const float* a, const float* b, const int32_t* cell, float* a_c, float* b_c, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) { a_c[j] = a[cell[j]]; if (b) b_c[j] = b[cell[j]]; }
 }
 
 inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -169,6 +188,8 @@ struct opadpo_saved {
   float *rstd1, *rstd2, *lse, *h;
   uint8_t* key_mask; float* hs; bf16_t* hn; float* rstd_f; float* logits; float* lse_head; float* ent;
   int32_t *rows, *labels;
+  int Rc = 0;                       // head rows actually computed: R (padded layout) or the number of valid response cells (ragged)
+  int32_t* cell = nullptr; float* logp_c = nullptr;      // ragged: flat [K,S,T] index of every compact head row; compact log-probs
   const int32_t* ids = nullptr; const int32_t* feat_row = nullptr;   // borrowed (SFT splice backward only)
   // ragged rows (padding removed): M = valid rows of the batch, L = longest sequence; meta / row_pos live in the arena
   int ragged = 0, meta_stride = 0, S_pad_rows = 0;
@@ -486,6 +507,8 @@ size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   sv->ent = cv.take<float>(R);
   sv->rows = cv.take<int32_t>(R);
   sv->labels = cv.take<int32_t>(R);
+  sv->cell = cv.take<int32_t>(sv->ragged ? R : 1);
+  sv->logp_c = cv.take<float>(sv->ragged ? R : 1);
   sv->meta = cv.take<int32_t>(sv->ragged ? (size_t)sv->S * sv->meta_stride : 1);
   sv->row_pos = cv.take<int32_t>(sv->ragged ? M : 1);
   return cv.off;
@@ -721,7 +744,7 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   // response (trailing pad dropped); the valid rows of the batch become the M of every row-wise kernel of the pass
   MetaBlob blob;
   if (row_plan) {
-    const int stride = K + 3;
+    const int stride = 2 * K + 3;
     if (S * stride > (int)(sizeof(blob.v) / sizeof(int32_t)) || K > 8) { delete sv; return cbad(c, __func__, "row_plan: too many sequences / responses for the ragged layout"); }
     int row = 0, lmax = 0;
     for (int q = 0; q < S; ++q) {
@@ -736,7 +759,12 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
       row += m[1 + K];
       lmax = std::max(lmax, (int)m[1 + K]);
     }
-    sv->ragged = 1; sv->meta_stride = stride; sv->M = row; sv->L = lmax;
+    int cells = 0;                                  // compact head rows, in the [k][s] order of the outputs
+    for (int k = 0; k < K; ++k)
+      for (int q = 0; q < S; ++q) { blob.v[q * stride + 3 + K + k] = cells; cells += row_plan[(size_t)q * (K + 1) + 1 + k]; }
+    sv->ragged = 1; sv->meta_stride = stride; sv->M = row; sv->L = lmax; sv->Rc = cells;
+  } else {
+    sv->Rc = sv->R;
   }
   sv->bytes = saved_layout(d, sv, nullptr);
   // ragged batches differ in size: ask for the largest arena seen so far for this kind of pass, so that the allocator hands the
@@ -779,17 +807,27 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
     CKS(layer_fwd(c, i, ad, res, yin, x, Y, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg));
     res = lb.h; yin = Y;
   }
-  const int R = sv->R;
-  if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(R), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels);
-  else hipLaunchKernelGGL(head_index_kernel, g1(R), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
+  const int Rall = sv->R, R = sv->Rc;                // cells of the [K,S,T] outputs; head rows computed
+  if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(Rall), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels, sv->cell);
+  else hipLaunchKernelGGL(head_index_kernel, g1(Rall), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
   CKS(hipGetLastError());
   // final hidden state x = h + y of the HEAD rows only (fp32 rows = 2H bf16 units; the y rows park in the logits buffer, written later)
   CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
   CKS(launch_gather_rows((const bf16_t*)Y, 2 * H, sv->rows, (bf16_t*)sv->logits, R, 2 * H, st));
   CKS(launch_rmsnorm_sum_fwd(sv->hs, 1, sv->logits, 1, (size_t)R * H, c->norm, sv->hs, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
   { GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head, H, H, sv->logits, d.vocab, 1, R, d.vocab); CKS(run_gemm(c, g, st)); }
-  CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, logp, sv->ent, sv->lse_head, R, d.vocab, st));
-  CKS(hipMemcpyAsync(ent, sv->ent, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (rg) {       // compact head rows -> the rectangular outputs (padding cells: -0.0 / 0, Quirk Q4)
+    CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, sv->logp_c, sv->ent, sv->lse_head, R, d.vocab, st));
+    hipLaunchKernelGGL(fill_f32_kernel, g1(Rall), dim3(256), 0, st, logp, -0.0f, ent, 0.0f, Rall);
+    CKS(hipGetLastError());
+    if (R > 0) {
+      hipLaunchKernelGGL(scatter_cells_kernel, g1(R), dim3(256), 0, st, sv->logp_c, sv->ent, sv->cell, logp, ent, R);
+      CKS(hipGetLastError());
+    }
+  } else {
+    CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, logp, sv->ent, sv->lse_head, R, d.vocab, st));
+    CKS(hipMemcpyAsync(ent, sv->ent, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
 #undef CKS
   if (train) {
     *saved_out = sv;
@@ -821,7 +859,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   const opadpo_ctx::Adapter& ad = c->adapters[sv->adapter];
   if (ad.kind != 1 || !ad.grad || !ad.work_t) return cbad(c, __func__, "adapter lost its gradient / transposed buffers");
   hipStream_t st = (hipStream_t)stream;
-  const int S = sv->S, Lp = sv->L, M = sv->M, R = sv->R, H = d.hidden, F = d.ffn, r = d.lora_r, nh = d.n_heads, hd = d.head_dim, V = d.vocab;
+  const int S = sv->S, Lp = sv->L, M = sv->M, R = sv->Rc, H = d.hidden, F = d.ffn, r = d.lora_r, nh = d.n_heads, hd = d.head_dim, V = d.vocab;
   const float s = d.lora_alpha / d.lora_r;
   const size_t MH = (size_t)M * H;
   // workspace (persists between the ranged calls of one backward)
@@ -844,6 +882,12 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");
+    if (sv->ragged && R > 0) {      // gradients of the compact head rows: gathered from the rectangular [K,S,T] gradients (into d_hs, free until the norm backward)
+      float* dl_c = d_hs; float* de_c = d_hs + R;
+      hipLaunchKernelGGL(gather_cells_kernel, g1(R), dim3(256), 0, st, dlogp, dent, sv->cell, dl_c, de_c, R);
+      CK(hipGetLastError());
+      dlogp = dl_c; if (dent) dent = de_c;
+    }
     CK(launch_head_bwd(sv->logits, V, sv->labels, sv->lse_head, dlogp, dent ? sv->ent : nullptr, dent, 1.0f / sv->temperature, dz, V, R, V, st));
     { GemmNTArgs g = gemm(c, dz, V, c->lm_head_t, V, V, d_hn, H, 0, R, H); CK(run_gemm(c, g, st)); }
     CK(launch_rmsnorm_bwd(d_hn, sv->hs, 1, c->norm, sv->rstd_f, nullptr, 0, d_hs, nullptr, R, H, st));

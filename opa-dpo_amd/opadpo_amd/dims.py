@@ -143,13 +143,13 @@ def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2, ref_merg
 def pair_flops_ragged(d: LlavaDims, prefix_rows, resp_rows, ref_merged: bool = False) -> float:
     """FLOPs EXECUTED for one preference pair on ragged rows (ctx.CtxEngine default: padding positions are not rows of any kernel):
     `prefix_rows` valid image + query positions, `resp_rows` = valid lengths of the K responses packed behind it.  Same conventions
-    as pair_flops_packed; the head runs on all K*T label rows (pad labels included, their rows are clamped)."""
+    as pair_flops_packed; the head (lm_head + log-softmax) runs on the valid response tokens only (compact head rows)."""
     H, V, nl = d.hidden, d.vocab, d.n_layers
     rows = prefix_rows + sum(resp_rows)
     p_lin = nl * (4 * H * H + 3 * H * d.ffn)
     p_lora = lora_param_count(d)
     pairs = prefix_rows * prefix_rows / 2 + sum(v * prefix_rows + v * v / 2 for v in resp_rows)
-    f_row = 2 * (p_lin + p_lora) * rows + nl * 4 * H * pairs
+    f_row = 2 * (p_lin + p_lora) * rows + nl * 4 * H * pairs + 2 * V * H * sum(resp_rows)
     vh, vf, P1 = d.v_hidden, d.v_ffn, d.n_patches + 1
     f_img = d.v_used_layers * (2 * (4 * vh * vh + 2 * vh * vf) * P1 + 4 * P1 * P1 * vh) \
         + 2 * d.n_patches * (d.patch_k * vh + vh * H + H * H)

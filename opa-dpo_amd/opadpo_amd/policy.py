@@ -67,11 +67,27 @@ class AutoregressivePolicy(torch.nn.Module):
         self.layer_done_hook = None       # callable(layer) set by the trainer on the gradient-sync micro-batch (optim.launch_bucket)
 
     def build_batch(self, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
-        dev = self.engine.dev
-        d = self.engine.d
+        """-> (response keys, SeqBatch).  The reference policy and the trained policy of a step see the SAME collated tensors
+        (dpo_trainer.py rollout() / compute_policy_loss): the device-side concatenations and - for ragged rows - the one host read of
+        the row plan are done once per distinct input (cache on the engine, keyed by storage, version counter and shape)."""
         keys = response_keys(responses)
         if not keys:
             raise ValueError("no *response* tensors passed to the policy")
+        ck = (self.pack_responses, self.response_len) + tuple(
+            (t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in [queries, queries_attn_masks] + [responses[k] for k in keys])
+        cache = self.engine.__dict__.setdefault("_batch_cache", {})
+        hit = cache.get(ck)
+        if hit is not None:
+            return hit[0], hit[1]
+        out = self._build_batch(keys, queries, queries_attn_masks, responses)
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        cache[ck] = (out[0], out[1], queries, queries_attn_masks, [responses[k] for k in keys])      # the inputs stay alive with their entry: a recycled address cannot alias it
+        return out
+
+    def _build_batch(self, keys, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
+        dev = self.engine.dev
+        d = self.engine.d
         B, Q = queries.shape
         queries = queries.to(dev)
         qm = queries_attn_masks.to(dev).bool()
