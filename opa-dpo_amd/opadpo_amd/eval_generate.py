@@ -4,7 +4,7 @@ Tensor-level counterpart of eval_llava_rlhf_coco/model_vqa.py:77-120,213-226 (`m
 do_sample = temperature > 0, temperature, max_new_tokens, use_cache=True)` on base + `PeftModel.from_pretrained(model,
 <ckpt>/adapter_model/lora_policy)`): the prompt templating / tokenizer / keyword stopping of that script are host-side text
 processing outside the kernel path; this module consumes token ids and returns token ids, re-using the rollout kernels
-(prefill + graph-replayed KV-cache decode, LoRA tail fused into the decode GEMMs).
+(prefill + KV-cache decode launched from the context's own loop, LoRA tail fused into the decode GEMMs).
 """
 from __future__ import annotations
 

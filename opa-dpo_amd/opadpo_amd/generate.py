@@ -77,7 +77,7 @@ class Generator:
         """-> responses [B, max_new_tokens] int64 (pad after a row finished)."""
         eng, d, b = self.engine, self.engine.d, self.engine.base
         dev = eng.dev
-        if hasattr(eng, "ctx"):      # CtxEngine: prefill, KV cache, the per-token hipGraph and the sampler loop live below the C ABI
+        if hasattr(eng, "ctx"):      # CtxEngine: prefill, KV cache, the per-token launch loop (optionally a hipGraph) and the sampler live below the C ABI
             if image_feats is None:
                 image_feats = eng.encode_images(images)
             return eng.generate(self.adapter, queries, query_attn_masks, image_feats, max_new_tokens=max_new_tokens, temperature=temperature,
