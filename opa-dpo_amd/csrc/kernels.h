@@ -27,6 +27,10 @@ struct GemmNTArgs {
   int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
   int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
   int variant = -1;                     // kernel-variant override of this call (opadpo_ctx_set_flags); -1 = process default (opadpo_set_flags)
+  // split-K tail launch of the 256x256 kernel (set by launch_gemm_nt only): block = (tile tile0 + blockIdx / ksplit, K-slice blockIdx % ksplit),
+  // fp32 partial tile to partial[(slot * ksplit + slice) * 65536]
+  int ksplit = 0, tile0 = 0;
+  float* partial = nullptr;
 };
 
 struct GemmTNArgs {

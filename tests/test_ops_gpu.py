@@ -916,6 +916,45 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert relerr(got[:M], ref) < 2e-2
 
 
+@pytest.mark.parametrize("R,K,r,mode", [(17, 4096, 0, "bf16"), (17, 4096, 256, "f32"), (18, 4096, 256, "bf16_res"), (19, 2048, 0, "f32_res"),
+                                         (22, 1024, 256, "bf16"), (22, 4096, 0, "alpha"), (33, 4096, 256, "bf16")])
+def test_gemm_nt_split_k_tail(L, R, K, r, mode):
+    """A partly filled last round of 256x256 tiles (R row tiles x 16 column tiles: 272 / 288 / 304 / 352 / 528 tiles) runs as a split-K
+    tail (8 / 8 / 4 / 2 / 8 slices per tile) + gemm_nt_tail_reduce_kernel: every epilogue of the plain kernel (bf16 / fp32 out, bf16 /
+    fp32 residual, alpha, K-concatenated LoRA tail, ragged last row tile) against fp32 torch and against the 128x128 kernel (no split);
+    rows >= M untouched; repeated runs identical (slice order is fixed)."""
+    L.set_flags(10, True)
+    N, M = 4096, R * 256 - 100
+    x, w = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+    kw = dict(a2=rnd(M, r, seed=3), b2=rnd(N, r, scale=0.05, seed=4)) if r else {}
+    want = x.float() @ w.float().t()
+    if r:
+        want = want + kw["a2"].float() @ kw["b2"].float().t()
+    out_dtype = torch.float32 if mode.startswith("f32") else BF
+    if mode == "alpha":
+        kw["alpha"] = 0.37
+        want = want * 0.37
+    if mode.endswith("_res"):
+        res = rnd(M, N, seed=5) if mode == "bf16_res" else rnd(M, N, seed=5).float() * 1.001
+        kw["residual"] = res
+        want = want + res.float()
+    got = torch.full((M + 3, N), 7.0, dtype=out_dtype, device=dev())
+    L.gemm_nt(x, w, got[:M], **kw)
+    again = torch.empty(M, N, dtype=out_dtype, device=dev())
+    L.gemm_nt(x, w, again, **kw)
+    L.set_flags(4, True)
+    small = torch.empty(M, N, dtype=out_dtype, device=dev())
+    L.gemm_nt(x, w, small, **kw)
+    L.set_flags(10, True)
+    torch.cuda.synchronize()
+    assert relerr(got[:M], want) < (3e-3 if out_dtype == BF else 2e-5 * (K ** 0.5))
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(got[:M], again)
+    # same products, another summation order in the tail tiles: fp32 noise (then at most a bf16 rounding flip)
+    tol = 2e-2 if out_dtype == BF else 1e-3
+    assert float((got[:M].float() - small.float()).abs().max()) <= tol * float(want.abs().max())
+
+
 @pytest.mark.parametrize("M,F,K,r", [(300, 256, 128, 64), (1000, 768, 256, 0), (257, 1536, 512, 256), (3, 256, 64, 64)])
 def test_gemm_nt_swiglu_bwd(L, M, F, K, r):
     """ACT_SWIGLU_BWD: dgrad of the down projection (+ K-concatenated LoRA tail) with opadpo_silu_mul_bwd in its epilogue ==
