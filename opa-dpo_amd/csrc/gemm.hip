@@ -1804,19 +1804,23 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   const int pp_slots = ((pp_tiles + 255) / 256) * 256;
   // ragged rows (M ~ 24-26 k): N = 512 -> 188-200 blocks in ONE round, w4 0.088 / 0.256 ms (K = 4096 / 11008) vs 0.121 / 0.424 for the
   // 128x128 kernel; N = 768 -> 282-300 blocks: a tie; N = 256 -> 94-100 blocks: the 128x128 kernel keeps a 5-20 % lead
+  // with the split-K tail (below) a second, short round costs its share only: N = 768 (282-300 blocks) moves to the 256x256 kernel as well,
+  // and a deep-K one-round problem of <= 128 tiles (x . A_d^T: N = 256, K = 11008) runs as two K-slices per tile on twice the CUs
+  const int pp_rem = pp_tiles % 256, pp_nt = (a.K1 + a.K2) / P_BK;
+  const bool deep_small = plain && pp_tiles >= 64 && pp_tiles <= 128 && pp_nt >= 128;
   const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 ||
-                   (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 150 && pp_tiles <= 256) ||
+                   (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 150 && (pp_tiles <= 256 || pp_rem <= 128)) || deep_small ||
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
     if (plain && g_gemm_variant != 17) {    // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
       // a partly filled last round (<= 128 tiles) runs as 2 / 4 / 8 K-slices per tile + a reduce / epilogue launch (gemm_nt_tail_reduce_kernel)
       const int full = pp_tiles / 256 * 256, rem = pp_tiles - full, ntt = (a.K1 + a.K2) / P_BK;
-      int S = (full == 0 || rem == 0 || rem > 128 || a.ldc % 8 || (a.R && a.ldr % 8)) ? 1 : rem <= 32 ? 8 : rem <= 64 ? 4 : 2;
+      int S = ((full == 0 && !deep_small) || rem == 0 || rem > 128 || a.ldc % 8 || (a.R && a.ldr % 8)) ? 1 : rem <= 32 ? 8 : rem <= 64 ? 4 : 2;
       while (S > 1 && ntt / S < 8) S >>= 1;
       if (S == 2 && ntt < 128) S = 1;        // two slices only pay on deep K (down, dgrads: 1.730 vs 1.772 ms); at K = 4352 the reduce pass eats the gain
       float* ws = S > 1 ? tail_workspace(st) : nullptr;
       if (ws) {
-        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
+        if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
         GemmNTArgs t = a;
         t.ksplit = S; t.tile0 = full; t.partial = ws;
         hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(rem * S), dim3(256), 2 * P_STAGE, st, t);
