@@ -1807,7 +1807,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // with the split-K tail (below) a second, short round costs its share only: N = 768 (282-300 blocks) moves to the 256x256 kernel as well,
   // and a deep-K one-round problem of <= 128 tiles (x . A_d^T: N = 256, K = 11008) runs as two K-slices per tile on twice the CUs
   const int pp_rem = pp_tiles % 256, pp_nt = (a.K1 + a.K2) / P_BK;
-  const bool deep_small = plain && pp_tiles >= 64 && pp_tiles <= 128 && pp_nt >= 128;
+  const bool deep_small = plain && pp_tiles >= 64 && pp_tiles <= 128 && pp_nt >= 128;      // K = 4096 one-round problems measured no gain (0.085 vs 0.081 ms)
   const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 ||
                    (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 150 && (pp_tiles <= 256 || pp_rem <= 128)) || deep_small ||
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
@@ -1817,7 +1817,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       const int full = pp_tiles / 256 * 256, rem = pp_tiles - full, ntt = (a.K1 + a.K2) / P_BK;
       int S = ((full == 0 && !deep_small) || rem == 0 || rem > 128 || a.ldc % 8 || (a.R && a.ldr % 8)) ? 1 : rem <= 32 ? 8 : rem <= 64 ? 4 : 2;
       while (S > 1 && ntt / S < 8) S >>= 1;
-      if (S == 2 && ntt < 128) S = 1;        // two slices only pay on deep K (down, dgrads: 1.730 vs 1.772 ms); at K = 4352 the reduce pass eats the gain
+      if (S == 2 && ntt < 128 && full > 0) S = 1;        // two slices only pay on deep K (down, dgrads: 1.730 vs 1.772 ms); at K = 4352 the reduce pass eats the gain
       float* ws = S > 1 ? tail_workspace(st) : nullptr;
       if (ws) {
         if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
