@@ -149,8 +149,10 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
     with torch.no_grad():
         Wm, rest = LR.merge_llm_lora(W, lora_ref, od, emulate_bf16=True)
         ref_emu_merged = LR.policy_forward(images, queries, qmask, resp, Wm, rest, od, 1.0, emulate_bf16=True)
-        ref_emu = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0, emulate_bf16=True)
-        ref_f32 = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0)
+        # reported drift only (merged vs unmerged rounding of the frozen adapter, bf16 pipeline vs fp32 arithmetic): run in the one-layer
+        # test; the deeper tests skip these two oracle passes (each costs 20-30 s of host time at full width)
+        ref_emu = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0, emulate_bf16=True) if assert_1e3 else None
+        ref_f32 = LR.policy_forward(images, queries, qmask, resp, W, lora_ref, od, 1.0) if assert_1e3 else None
         pol_emu = LR.policy_forward(images, queries, qmask, resp, W, lora_pol, od, 1.0, emulate_bf16=True)
         ref_emu_b = _floor(LR, lambda: LR.policy_forward(images, queries, qmask, resp, Wm, rest, od, 1.0, emulate_bf16=True))
         pol_emu_b = _floor(LR, lambda: LR.policy_forward(images, queries, qmask, resp, W, lora_pol, od, 1.0, emulate_bf16=True))
@@ -167,15 +169,17 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
                                     ("ref_merged_vs_emu_merged_B", r_out, ref_emu_b), ("policy_vs_emu_B", p_out, pol_emu_b),
                                     ("floor_ref_emuA_vs_emuB", ref_emu_merged, ref_emu_b), ("floor_policy_emuA_vs_emuB", pol_emu, pol_emu_b),
                                     ("oracle_emu_vs_fp32_policy", pol_emu, pol_f32)):
+            if want_d is None:
+                continue
             got, want = got_d[k + "_logprobs"].detach().cpu(), want_d[k + "_logprobs"].detach()
             assert bool((got[~valid] == 0).all()) and bool((want[~valid] == 0).all())        # mask placement is exact (Quirk Q4)
             mean, p99, mx = _relstats(got, want, valid)
             REPORT[f"{tag}_{name}_{k}"] = {"mean": mean, "p99": p99, "max": mx}
             w = worst.setdefault(name, [0.0, 0.0, 0.0])
             worst[name] = [max(w[0], mean), max(w[1], p99), max(w[2], mx)]
-        ent = r_out[k + "_entropies"].cpu()
-        REPORT[f"{tag}_ref_entropy_maxabs_{k}"] = float((ent - ref_f32[k + "_entropies"]).abs().max())
-        assert float((ent - ref_f32[k + "_entropies"]).abs().max()) < 5e-2
+        ent, ent_want = r_out[k + "_entropies"].cpu(), (ref_f32 if ref_f32 is not None else ref_emu_merged)[k + "_entropies"]
+        REPORT[f"{tag}_ref_entropy_maxabs_{k}"] = float((ent - ent_want).abs().max())
+        assert float((ent - ent_want).abs().max()) < 5e-2
     REPORT[f"{tag}_worst"] = worst
     if check_grads:
         blocks = _grad_blocks(d, pol_ad, ol)
@@ -198,8 +202,10 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False):
             f"{tag} {name}: mean {mean:.2e} / p99 {p99:.2e} vs oracle self-noise mean {fm:.2e} / p99 {fp:.2e}"
         assert mean < 2e-3 and mx < 1.2e-2, f"{tag} {name}: mean {mean:.2e} max {mx:.2e}"
     # reported drift: merged-vs-unmerged rounding of the reference adapter, and bf16 pipeline vs fp32 arithmetic
-    assert worst["ref_merged_vs_emu_unmerged"][0] < 3e-3, worst
-    assert worst["ref_merged_vs_fp32"][0] < 3e-3 and worst["policy_vs_fp32"][0] < 3e-3, worst
+    if assert_1e3:
+        assert worst["ref_merged_vs_emu_unmerged"][0] < 3e-3, worst
+        assert worst["ref_merged_vs_fp32"][0] < 3e-3, worst
+    assert worst["policy_vs_fp32"][0] < 3e-3, worst
     assert worst["policy_vs_fp32"][0] <= 1.35 * worst["oracle_emu_vs_fp32_policy"][0] + 5e-5, "HIP drifts further from fp32 than the bf16-emulating oracle does"
     if check_grads:
         # bf16 backward against fp32 autograd.  One layer: every block within 3e-2.  Deeper: the activations the wgrads contract

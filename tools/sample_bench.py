@@ -59,6 +59,8 @@ def main():
            "loss": next((float(v) for k, v in stats.items() if k.startswith("dpo/loss") and "grad" not in k), None),
            "grad_norm_post_clip": stats.get("dpo/loss-grad_norm"),
            "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated() / 1e9}
+    ms = torch.cuda.memory_stats()
+    out["allocator"] = {k: int(ms.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
     print(json.dumps(out))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(REPO, "gpurun_out", f"sample_bench_{'packed' if pack else 'stacked'}.json"), "w"), indent=1)
