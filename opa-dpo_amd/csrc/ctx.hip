@@ -502,7 +502,7 @@ size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   sv->hs = cv.take<float>(R * H);
   sv->hn = cv.take<bf16_t>(R * H);
   sv->rstd_f = cv.take<float>(R);
-  sv->logits = cv.take<float>(R * (size_t)d.vocab);
+  sv->logits = cv.take<float>(R * (size_t)std::max(d.vocab, d.hidden));      // also parks the head rows of the deferred branch product ([R,H]) before the lm_head GEMM writes it
   sv->lse_head = cv.take<float>(R);
   sv->ent = cv.take<float>(R);
   sv->rows = cv.take<int32_t>(R);

@@ -393,7 +393,8 @@ class LlavaEngine:
         sv.hs = e((R, H), torch.float32)
         sv.hn = e((R, H))
         sv.rstd_f = e((R,), torch.float32)
-        sv.logits = e((R, d.vocab), torch.float32)
+        sv.logits_buf = e((R * max(d.vocab, d.hidden),), torch.float32)      # also parks the [R,H] head rows of the deferred branch product
+        sv.logits = sv.logits_buf[:R * d.vocab].view(R, d.vocab)
         sv.lse_head = e((R,), torch.float32)
         return sv
 
