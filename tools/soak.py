@@ -1,5 +1,6 @@
 """Full-size sanity run (diagnostic): LLaVA-1.5-7B LoRA DPO on ONE synthetic micro-batch for a few optimizer steps at a learning rate
-large enough to see the loss move; prints loss / pre-clip gradient norm per step.  SOAK_STEPS, SOAK_PAIRS, SOAK_LR."""
+large enough to see the loss move; prints loss / pre-clip gradient norm per step.  SOAK_STEPS, SOAK_PAIRS, SOAK_LR; SOAK_POOL > 1
+cycles over that many different synthetic batches (different ragged row counts from step to step)."""
 import os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,10 +25,11 @@ def main():
     ref.merge_into_base(base)
     policy, ref_policy = AutoregressivePolicy(eng, pol, 384), AutoregressivePolicy(eng, ref, 384)
     opt = FlatAdamW(pol.master, pol.grad, pol.work, lr=lr, max_grad_norm=1.0, mode="allreduce")
-    b = synth_pairs(d, pairs, 128, 384, seed=7, device=dev)
+    pool = [synth_pairs(d, pairs, 128, 384, seed=7 + i, device=dev) for i in range(int(os.environ.get("SOAK_POOL", 1)))]
     largs = DPOArgs()
     for it in range(steps):
         t0 = time.time()
+        b = pool[it % len(pool)]
         feats = eng.encode_images(b["images"])
         kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
                   chosen_response=b["chosen"], rejected_response=b["rejected"])
@@ -37,12 +39,13 @@ def main():
         loss, _, _ = pair_loss(largs, o["chosen_response_logprobs"], o["rejected_response_logprobs"],
                                r["chosen_response_logprobs"], r["rejected_response_logprobs"])
         loss.backward()
+        assert bool(torch.isfinite(pol.grad).all()), "non-finite LoRA gradient"
         opt.step()
         gn = opt.grad_norm_post_clip()
         opt.zero_grad()
         pol.refresh_transposed()
         torch.cuda.synchronize()
-        print(f"step {it}: loss {float(loss):.6f}  post-clip grad_norm {gn:.4f}  {time.time() - t0:.2f} s", flush=True)
+        print(f"step {it}: loss {float(loss.detach()):.6f}  post-clip grad_norm {gn:.4f}  {time.time() - t0:.2f} s", flush=True)
         assert torch.isfinite(loss)
 
 
