@@ -263,7 +263,7 @@ class FlatAdamW:
                 pad[:b.s_len].copy_(mine)
                 mine = pad
             if gloo:
-                parts = [torch.empty(b.per, dtype=mine.dtype) for _ in range(self.world)]
+                parts = [torch.empty(b.per, dtype=mine.dtype, device=mine.device) for _ in range(self.world)]
                 dist.all_gather(parts, mine.contiguous(), group=self.group)
                 self.work[b.lo:b.hi].copy_(torch.cat(parts)[:n])
             elif b.direct_gather:
