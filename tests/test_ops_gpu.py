@@ -240,6 +240,29 @@ def test_gemm_nt_grouped_a1(L, variant):
     assert relerr(out, want) < 6e-3
 
 
+def test_gemm_nt_grouped_a1_split_k_tail(L):
+    """The benchmark's dT_qkv shape on ragged rows: N = 3r = 768 with one A1 column group per 256 outputs, 96 row tiles -> 288 tiles of
+    256x256 = one full round + 32 tiles run as 8 K-slices each (the group offset and the K-slice offset of A1 must compose); also the
+    deep-K one-round case (N = 256, K = 11008: 96 tiles as two slices each).  Against fp32 torch and the 128x128 kernel."""
+    M, G, r, K = 96 * 256 - 77, 3, 256, 4096
+    a = rnd(M, G * K, seed=1)
+    b = rnd(G * r, K, scale=0.05, seed=2)
+    out = torch.empty(M, G * r, dtype=BF, device=dev())
+    small = torch.empty_like(out)
+    L.set_flags(10, True)
+    L.gemm_nt(a, b, out, alpha=2.0, k1=K, a1_group_n=r, a1_group_stride=K)
+    L.set_flags(4, True)
+    L.gemm_nt(a, b, small, alpha=2.0, k1=K, a1_group_n=r, a1_group_stride=K)
+    L.set_flags(10, True)
+    want = torch.cat([2.0 * a[:, g * K:(g + 1) * K].float() @ b[g * r:(g + 1) * r].float().t() for g in range(G)], 1)
+    assert relerr(out, want) < 3e-3 and relerr(small, want) < 3e-3
+    assert float((out.float() - small.float()).abs().max()) <= 2e-2 * float(want.abs().max())
+    x, w = rnd(M, 11008, seed=3), rnd(256, 11008, scale=0.05, seed=4)
+    t = torch.empty(M, 256, dtype=BF, device=dev())
+    L.gemm_nt(x, w, t, alpha=0.5)
+    assert relerr(t, 0.5 * (x.float() @ w.float().t())) < 3e-3
+
+
 @pytest.mark.parametrize("tr", [1, 9, 0, 13])      # 1 = default (256x256 stream-K kernel where both dims allow), 9 = 128x128 kernel, 13 = wide tiles
 @pytest.mark.parametrize("M,N1,N2,groups", [(777, 256, 128, 0), (64, 128, 128, 0), (1500, 384, 128, 3), (130, 128, 256, 0),
                                             (1100, 512, 256, 0), (1100, 256, 1024, 0), (1300, 768, 256, 3), (2100, 1024, 256, 2),
