@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--batch-pool", type=int, default=8, help="number of different synthetic micro-batches cycled over the steps")
     ap.add_argument("--padded", action="store_true", help="keep the reference's padded rows (padding positions computed and thrown away) instead of ragged rows")
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
-    ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward fused into the dgrad epilogue)")
+    ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward fused into the dgrad epilogue, bit 7: top decoder layer on every row)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
@@ -311,7 +311,7 @@ def main():
                 vr = (t_len - ((b["rejected"] != 0).flip(1).int().cumsum(1) == 0).sum(1)).tolist()
                 for l_, c_, r_ in zip(lead, vc, vr):
                     pr = q_len + d.n_patches - 1 - l_
-                    tot += pair_flops_ragged(d, pr, [c_, r_], ref_merged=merged)
+                    tot += pair_flops_ragged(d, pr, [c_, r_], ref_merged=merged, compact_top=not (args.ctx_flags >= 0 and args.ctx_flags & 128))
                     rows_tot += pr + c_ + r_
                     n += 1
             fl, rows_per_pair = tot / n, rows_tot / n
@@ -337,7 +337,7 @@ def main():
                                               f"{q_len + d.n_patches - 1}+2x{t_len} positions per pair and pass" if pack else
                                               f"stacked: 2 x {q_len + t_len + d.n_patches - 1} positions per pair and pass (reference layout)"),
                           "rows": (f"ragged: padding positions (left pad of the query, right pad of each response) are not rows of any kernel; {rows_per_pair:.0f} rows per pair "
-                                   f"and pass on average instead of {q_len + d.n_patches - 1 + 2 * t_len}" if (ragged and pack) else "padded: every position is a row, like the reference computes it"),
+                                   f"and pass on average instead of {q_len + d.n_patches - 1 + 2 * t_len}; the top decoder layer's o-projection / MLP only on the rows the head reads" if (ragged and pack) else "padded: every position is a row, like the reference computes it"),
                           "reference_adapter": ("frozen adapter merged into a second bf16 copy of the LLM projections at load (no LoRA GEMMs in the no-grad pass)"
                                                 if not args.no_merge_ref else "unmerged (K-concatenated LoRA in the no-grad pass)"),
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,

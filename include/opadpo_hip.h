@@ -275,7 +275,8 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
 /* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default.  Context-only: use_tr bit 5 = keep the
  * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
  * bit 6 = SwiGLU backward in the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD; default: its own launch, which
- * measured 0.35 % faster per step) */
+ * measured 0.35 % faster per step); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only
+ * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);

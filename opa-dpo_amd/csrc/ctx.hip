@@ -145,8 +145,12 @@ __global__ __launch_bounds__(256) void embed_splice_ragged_kernel(const int32_t*
 // 44 % of the [K,S,T] cells of a synthetic seq512 pair).  Cell (k,s,t) -> compact index j = off[s][k] + t (off = exclusive prefix sum of
 // the valid lengths in [k][s] order, meta[3 + K + k]); rows[j] = the compact activation row that predicts the token (token 0: the last
 // prefix row; token t: row t-1 of the response), labels[j] = the token, cell[j] = the flat [K,S,T] index the result is scattered to.
+// urow != nullptr ("compact last layer"): the rows the head reads - per sequence the last prefix row and rows 0 .. v_k - 2 of every
+// response - are the ONLY rows of the top decoder layer whose o-projection / MLP output anything reads (their K / V still need every
+// row's q|k|v).  They form the list U (ascending; sequence s starts at meta[3 + 2K]); urow[u] = activation row of entry u, and rows[j]
+// then holds the U index instead of the activation row: the top layer's o-projection and MLP run on the gathered U rows only.
 __global__ void head_index_ragged_kernel(const int32_t* ids, const int32_t* meta, int stride, int S, int n_txt, int K, int T, int32_t* rows,
-                                         int32_t* labels, int32_t* cell) {
+                                         int32_t* labels, int32_t* cell, int32_t* urow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K * S * T) return;
   const int t = i % T, s = (i / T) % S, k = i / (T * S);
@@ -154,7 +158,18 @@ __global__ void head_index_ragged_kernel(const int32_t* ids, const int32_t* meta
   const int b0 = m[1], bk = m[1 + k], vk = m[2 + k] - bk;
   if (t >= vk) return;
   const int j = m[3 + K + k] + t;
-  rows[j] = m[0] + (t == 0 ? b0 - 1 : bk + t - 1);
+  const int row = m[0] + (t == 0 ? b0 - 1 : bk + t - 1);
+  if (urow) {
+    int u = m[3 + 2 * K];
+    if (t > 0) {
+      u += t;                                            // 1 (the last prefix row) + (t - 1)
+      for (int a = 0; a < k; ++a) u += max(m[2 + a] - m[1 + a] - 1, 0);
+    }
+    urow[u] = row;                                       // token 0 of every response writes the same value
+    rows[j] = u;
+  } else {
+    rows[j] = row;
+  }
   labels[j] = ids[(size_t)s * n_txt + (n_txt - K * T) + k * T + t];
   cell[j] = i;
 }
@@ -190,6 +205,8 @@ struct opadpo_saved {
   int32_t *rows, *labels;
   int Rc = 0;                       // head rows actually computed: R (padded layout) or the number of valid response cells (ragged)
   int32_t* cell = nullptr; float* logp_c = nullptr;      // ragged: flat [K,S,T] index of every compact head row; compact log-probs
+  int Uc = 0;                       // > 0: compact last layer - rows of the top layer's o-projection / MLP (head_index_ragged_kernel)
+  int32_t* urow = nullptr; bf16_t* attn_u = nullptr;     // U list; attention output gathered on U (saved for the o-projection wgrads)
   const int32_t* ids = nullptr; const int32_t* feat_row = nullptr;   // borrowed (SFT splice backward only)
   // ragged rows (padding removed): M = valid rows of the batch, L = longest sequence; meta / row_pos live in the arena
   int ragged = 0, meta_stride = 0, S_pad_rows = 0;
@@ -427,12 +444,15 @@ hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const fl
 }
 
 struct Rag { const int32_t* meta; int stride, n_seg, rows; const int32_t* row_pos; };      // ragged rows of a pass (nullptr = padded)
+// top decoder layer on the rows the head reads only (opadpo_saved::Uc): U list, gathered attention output (kept), gathered input (scratch)
+struct TopRows { const int32_t* urow; int n; bf16_t* attn_u; float* x_u; };
 
 // Input of the layer: x = res (+ yin when yin != nullptr: the previous layer's down-projection product, residual deferred).  x is written
 // to `x` (may alias res when yin is null), the layer leaves h = x + attention branch in b.h and its own down-projection product in Y:
 // the caller hands (b.h, Y) to the next layer / the final norm.
 hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* res, const float* yin, float* x, float* Y, const LayerBufs& b, int S, int Lp,
-                     const uint8_t* key_mask, int seg0, int seg1, bf16_t* kc, bf16_t* vc, int max_ctx, hipStream_t st, const Rag* rg = nullptr) {
+                     const uint8_t* key_mask, int seg0, int seg1, bf16_t* kc, bf16_t* vc, int max_ctx, hipStream_t st, const Rag* rg = nullptr,
+                     const TopRows* top = nullptr) {
   const opadpo_dims& d = c->d;
   const int H = d.hidden, r = d.lora_r, nh = d.n_heads, hd = d.head_dim;
   const int M = rg ? rg->rows : S * Lp;
@@ -467,17 +487,27 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   a.seg_prefix = seg0; a.seg_len = seg1; a.use_tr = c->use_tr;
   if (rg) { a.seq_meta = rg->meta; a.meta_stride = rg->stride; a.n_seg = rg->n_seg; a.rows_total = rg->rows; a.seg_prefix = 0; a.seg_len = 0; }
   if ((e = launch_attn_fwd(a, st)) != hipSuccess) return e;
+  // top layer with `top`: from here on only the rows the head reads exist (attention needed every row's k, v; nothing reads the
+  // o-projection / MLP output of the other rows).  b.t_o / b.h / b.n2 / ... and Y then hold top->n COMPACT rows.
+  int Mo = M;
+  const bf16_t* attn = b.attn;
+  const float* xr = x;
+  if (top) {
+    if ((e = launch_gather_rows(b.attn, H, top->urow, top->attn_u, top->n, H, st)) != hipSuccess) return e;
+    if ((e = launch_gather_rows((const bf16_t*)x, 2 * H, top->urow, (bf16_t*)top->x_u, top->n, 2 * H, st)) != hipSuccess) return e;      // fp32 rows = 2H bf16 units
+    Mo = top->n; attn = top->attn_u; xr = top->x_u;
+  }
   if (lw) {
-    GemmNTArgs g3 = gemm(c, b.attn, H, lw + o.a_o, H, H, b.t_o, r, 0, M, r); g3.alpha = s;
+    GemmNTArgs g3 = gemm(c, attn, H, lw + o.a_o, H, H, b.t_o, r, 0, Mo, r); g3.alpha = s;
     if ((e = run_gemm(c, g3, st)) != hipSuccess) return e;
-    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, Y, H, 1, M, H); tail(g4, b.t_o, r, lw + o.b_o, r, r);
+    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, Y, H, 1, Mo, H); tail(g4, b.t_o, r, lw + o.b_o, r, r);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
   } else {
-    GemmNTArgs g4 = gemm(c, b.attn, H, w.wo, H, H, Y, H, 1, M, H);
+    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, Y, H, 1, Mo, H);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
   }
-  if ((e = launch_rmsnorm_sum_fwd(x, 1, Y, 1, MH, w0.ln2, b.h, b.n2, b.rstd2, M, H, d.rms_eps, st)) != hipSuccess) return e;      // h = x + attn . Wo, n2 = norm(h)
-  return mlp_fwd(c, i, ad, b.h, nullptr, b, M, 0, st, Y, true);
+  if ((e = launch_rmsnorm_sum_fwd(xr, 1, Y, 1, (size_t)Mo * H, w0.ln2, b.h, b.n2, b.rstd2, Mo, H, d.rms_eps, st)) != hipSuccess) return e;      // h = x + attn . Wo, n2 = norm(h)
+  return mlp_fwd(c, i, ad, b.h, nullptr, b, Mo, 0, st, Y, true);
 }
 
 size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
@@ -509,6 +539,8 @@ size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   sv->labels = cv.take<int32_t>(R);
   sv->cell = cv.take<int32_t>(sv->ragged ? R : 1);
   sv->logp_c = cv.take<float>(sv->ragged ? R : 1);
+  sv->urow = cv.take<int32_t>(sv->ragged ? R : 1);                  // |U| <= valid tokens <= R
+  sv->attn_u = cv.take<bf16_t>(sv->ragged ? std::min(R, M) * H : 1);
   sv->meta = cv.take<int32_t>(sv->ragged ? (size_t)sv->S * sv->meta_stride : 1);
   sv->row_pos = cv.take<int32_t>(sv->ragged ? M : 1);
   return cv.off;
@@ -744,7 +776,7 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   // response (trailing pad dropped); the valid rows of the batch become the M of every row-wise kernel of the pass
   MetaBlob blob;
   if (row_plan) {
-    const int stride = 2 * K + 3;
+    const int stride = 2 * K + 4;
     if (S * stride > (int)(sizeof(blob.v) / sizeof(int32_t)) || K > 8) { delete sv; return cbad(c, __func__, "row_plan: too many sequences / responses for the ragged layout"); }
     int row = 0, lmax = 0;
     for (int q = 0; q < S; ++q) {
@@ -762,7 +794,16 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
     int cells = 0;                                  // compact head rows, in the [k][s] order of the outputs
     for (int k = 0; k < K; ++k)
       for (int q = 0; q < S; ++q) { blob.v[q * stride + 3 + K + k] = cells; cells += row_plan[(size_t)q * (K + 1) + 1 + k]; }
+    int nu = 0;                                     // rows of the compact top layer (U), sequence by sequence
+    for (int q = 0; q < S; ++q) {
+      const int32_t* rp = row_plan + (size_t)q * (K + 1);
+      blob.v[q * stride + 3 + 2 * K] = nu;
+      int any = 0;
+      for (int k = 0; k < K; ++k) { any |= rp[1 + k] > 0; nu += std::max(rp[1 + k] - 1, 0); }
+      nu += any;
+    }
     sv->ragged = 1; sv->meta_stride = stride; sv->M = row; sv->L = lmax; sv->Rc = cells;
+    sv->Uc = (c->use_tr >= 0 && (c->use_tr & 128)) ? 0 : nu;      // context flag bit 7: top layer on every row
   } else {
     sv->Rc = sv->R;
   }
@@ -798,19 +839,22 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   } else {
     CKS(launch_embed_splice(ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x, 1, sv->key_mask, S, n_txt, P, H, OPADPO_IMAGE_TOKEN, st));
   }
+  const int Rall = sv->R, R = sv->Rc;                // cells of the [K,S,T] outputs; head rows computed
+  if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(Rall), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels, sv->cell,
+                             sv->Uc > 0 ? sv->urow : nullptr);
+  else hipLaunchKernelGGL(head_index_kernel, g1(Rall), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
+  CKS(hipGetLastError());
   float* const Y = sv->x + (size_t)(train ? d.n_layers : 2) * MH;          // branch product of the o / down projections (residual deferred)
   const float* res = sv->x;
   const float* yin = nullptr;
+  const TopRows top{sv->urow, sv->Uc, sv->attn_u, sv->hs};                 // hs is free until the head (and |U| <= R rows fit)
   for (int i = 0; i < d.n_layers; ++i) {
     const LayerBufs lb = slot(d, sv, train ? i : 0);
     float* x = sv->x + (size_t)(train ? i : (i & 1)) * MH;
-    CKS(layer_fwd(c, i, ad, res, yin, x, Y, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg));
+    CKS(layer_fwd(c, i, ad, res, yin, x, Y, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg,
+                  (sv->Uc > 0 && i == d.n_layers - 1) ? &top : nullptr));
     res = lb.h; yin = Y;
   }
-  const int Rall = sv->R, R = sv->Rc;                // cells of the [K,S,T] outputs; head rows computed
-  if (rg) hipLaunchKernelGGL(head_index_ragged_kernel, g1(Rall), dim3(256), 0, st, ids, sv->meta, sv->meta_stride, S, n_txt, K, T, sv->rows, sv->labels, sv->cell);
-  else hipLaunchKernelGGL(head_index_kernel, g1(Rall), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
-  CKS(hipGetLastError());
   // final hidden state x = h + y of the HEAD rows only (fp32 rows = 2H bf16 units; the y rows park in the logits buffer, written later)
   CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
   CKS(launch_gather_rows((const bf16_t*)Y, 2 * H, sv->rows, (bf16_t*)sv->logits, R, 2 * H, st));
@@ -867,7 +911,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   { Carve cv(nullptr); cv.take<bf16_t>((size_t)R * V); cv.take<bf16_t>((size_t)R * H); cv.take<float>((size_t)R * H); cv.take<float>(MH); cv.take<bf16_t>(MH);
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
-    cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); need = cv.off; }
+    cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); need = cv.off; }
   const bool first = layer_hi == d.n_layers - 1;
   if (!first && (c->ws_bytes < need || !c->ws)) return cbad(c, __func__, "ranged backward must start at the top layer");
   void* base = ctx_ws(c, need, st);
@@ -879,6 +923,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   bf16_t* d_attn = cv.take<bf16_t>(MH); bf16_t* dqkv = cv.take<bf16_t>((size_t)M * 3 * H); float* delta = cv.take<float>((size_t)S * nh * Lp);
   bf16_t* dt_r = cv.take<bf16_t>((size_t)M * r); bf16_t* dt_2r = cv.take<bf16_t>((size_t)M * 2 * r); bf16_t* dt_3r = cv.take<bf16_t>((size_t)M * 3 * r);
   bf16_t* dt_ra = cv.take<bf16_t>((size_t)M * r);        // dT of the o projection (dt_r keeps the down projection's until the grouped wgrad)
+  float* d_full = cv.take<float>(sv->Uc > 0 ? MH : 1);   // compact top layer: its residual gradient scattered back to every row
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");
@@ -906,35 +951,45 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     // operands exists: every operand stays untouched until then (dt_ra is the second dT buffer that makes that true)
     GemmTNArgs wg[8];
     int nwg = 0;
-    auto tn = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, float* Cg, int ldc, int N1, int N2, int qgn, int qgs) {
-      GemmTNArgs& t = wg[nwg++]; t.P = Pm; t.Q = Q; t.C = Cg; t.M = M; t.N1 = N1; t.N2 = N2; t.ldp = ldp; t.ldq = ldq; t.ldc = ldc;
+    // compact top layer (opadpo_saved::Uc): its MLP / o-projection activations and the incoming gradient are rows of U, not of the batch
+    const bool top = sv->Uc > 0 && i == d.n_layers - 1;
+    const int Mm = top ? sv->Uc : M;
+    auto tn = [&](const bf16_t* Pm, int ldp, const bf16_t* Q, int ldq, float* Cg, int ldc, int N1, int N2, int qgn, int qgs, int rows) {
+      GemmTNArgs& t = wg[nwg++]; t.P = Pm; t.Q = Q; t.C = Cg; t.M = rows; t.N1 = N1; t.N2 = N2; t.ldp = ldp; t.ldq = ldq; t.ldc = ldc;
       t.q_group_n1 = qgn; t.q_group_stride = qgs; t.alpha = 1.f; t.splits = 0; t.use_tr = c->use_tr;
       return hipSuccess;
     };
     // ---- MLP ----
-    { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
-    CK(tn(dXb, H, b.t_d, r, gr + o.b_d, r, H, r, 0, 0));
-    CK(tn(dt_r, r, b.act, F, gr + o.a_d, F, r, F, 0, 0));
+    { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, Mm, r); g.alpha = s; CK(run_gemm(c, g, st)); }
+    CK(tn(dXb, H, b.t_d, r, gr + o.b_d, r, H, r, 0, 0, Mm));
+    CK(tn(dt_r, r, b.act, F, gr + o.a_d, F, r, F, 0, 0, Mm));
     if (F % 256 == 0 && c->use_tr >= 0 && (c->use_tr & 64)) {      // opt-in (flag bit 6): SwiGLU backward in the dgrad epilogue, d_act stays in the block's LDS.
       // Same-box A/B at the bench shape: 1016.9 vs 1013.3 ms per step for the two-kernel form - the longer epilogue idles the one-block-per-CU
       // matrix pipe for longer than the 5 TB/s elementwise kernel takes
-      GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_gu, 2 * F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r);
+      GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_gu, 2 * F, 0, Mm, F); tail(g, dt_r, r, wt + o.a_d, r, r);
       g.act = OPADPO_ACT_SWIGLU_BWD; g.R = b.gu; g.ldr = 2 * F; g.r_f32 = 0;
       CK(run_gemm(c, g, st));
     } else {
-      { GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_act, F, 0, M, F); tail(g, dt_r, r, wt + o.a_d, r, r); CK(run_gemm(c, g, st)); }
-      CK(launch_silu_mul_bwd(d_act, b.gu, d_gu, M, F, st));
+      { GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_act, F, 0, Mm, F); tail(g, dt_r, r, wt + o.a_d, r, r); CK(run_gemm(c, g, st)); }
+      CK(launch_silu_mul_bwd(d_act, b.gu, d_gu, Mm, F, st));
     }
-    { GemmNTArgs g = gemm(c, d_gu, 2 * F, wt + o.b_gu, F, F, dt_2r, 2 * r, 0, M, 2 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = F; CK(run_gemm(c, g, st)); }
-    CK(tn(d_gu, 2 * F, b.t_gu, 2 * r, gr + o.b_gu, r, 2 * F, r, F, r));
-    CK(tn(dt_2r, 2 * r, b.n2, H, gr + o.a_gu, H, 2 * r, H, 0, 0));
-    { GemmNTArgs g = gemm(c, d_gu, 2 * F, w.wgu_t, 2 * F, 2 * F, d_n, H, 0, M, H); tail(g, dt_2r, 2 * r, wt + o.a_gu, 2 * r, 2 * r); CK(run_gemm(c, g, st)); }
-    CK(launch_rmsnorm_bwd(d_n, b.h, 1, w.ln2, b.rstd2, dX, 1, d_h, d_hb, M, H, st));
+    { GemmNTArgs g = gemm(c, d_gu, 2 * F, wt + o.b_gu, F, F, dt_2r, 2 * r, 0, Mm, 2 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = F; CK(run_gemm(c, g, st)); }
+    CK(tn(d_gu, 2 * F, b.t_gu, 2 * r, gr + o.b_gu, r, 2 * F, r, F, r, Mm));
+    CK(tn(dt_2r, 2 * r, b.n2, H, gr + o.a_gu, H, 2 * r, H, 0, 0, Mm));
+    { GemmNTArgs g = gemm(c, d_gu, 2 * F, w.wgu_t, 2 * F, 2 * F, d_n, H, 0, Mm, H); tail(g, dt_2r, 2 * r, wt + o.a_gu, 2 * r, 2 * r); CK(run_gemm(c, g, st)); }
+    CK(launch_rmsnorm_bwd(d_n, b.h, 1, w.ln2, b.rstd2, dX, 1, d_h, d_hb, Mm, H, st));
     // ---- attention ----
-    { GemmNTArgs g = gemm(c, d_hb, H, wt + o.b_o, H, H, dt_ra, r, 0, M, r); g.alpha = s; CK(run_gemm(c, g, st)); }
-    CK(tn(d_hb, H, b.t_o, r, gr + o.b_o, r, H, r, 0, 0));
-    CK(tn(dt_ra, r, b.attn, H, gr + o.a_o, H, r, H, 0, 0));
-    { GemmNTArgs g = gemm(c, d_hb, H, w.wo_t, H, H, d_attn, H, 0, M, H); tail(g, dt_ra, r, wt + o.a_o, r, r); CK(run_gemm(c, g, st)); }
+    { GemmNTArgs g = gemm(c, d_hb, H, wt + o.b_o, H, H, dt_ra, r, 0, Mm, r); g.alpha = s; CK(run_gemm(c, g, st)); }
+    CK(tn(d_hb, H, b.t_o, r, gr + o.b_o, r, H, r, 0, 0, Mm));
+    CK(tn(dt_ra, r, top ? sv->attn_u : b.attn, H, gr + o.a_o, H, r, H, 0, 0, Mm));
+    {
+      bf16_t* dst = top ? d_n : d_attn;            // d_n is free again: the norm backward above has consumed it
+      GemmNTArgs g = gemm(c, d_hb, H, w.wo_t, H, H, dst, H, 0, Mm, H); tail(g, dt_ra, r, wt + o.a_o, r, r); CK(run_gemm(c, g, st));
+      if (top) {                                   // gradient of the attention output: U rows carry one, every other row zero
+        CK(hipMemsetAsync(d_attn, 0, MH * sizeof(bf16_t), st));
+        CK(launch_scatter_rows(d_n, sv->urow, d_attn, H, Mm, H, st));
+      }
+    }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = b.qkv; a.k = b.qkv + H; a.v = b.qkv + 2 * H; a.o = b.attn; a.lse = b.lse; a.key_mask = sv->key_mask;
@@ -945,12 +1000,18 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     CK(launch_attn_bwd(a, st));
     CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr));
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
-    CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r));
-    CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0));
+    CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r, M));
+    CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0, M));
     CK(launch_gemm_tn_group(wg, nwg, st));
     if (i > 0 || d_feats) {          // layer-0 input is the frozen embedding / image features: no further dgrad in the DPO stage
       { GemmNTArgs g = gemm(c, dqkv, 3 * H, w.wqkv_t, 3 * H, 3 * H, d_n, H, 0, M, H); tail(g, dt_3r, 3 * r, wt + o.a_qkv, 3 * r, 3 * r); CK(run_gemm(c, g, st)); }
-      CK(launch_rmsnorm_bwd(d_n, sv->x + (size_t)i * MH, 1, w.ln1, b.rstd1, d_h, 1, dX, dXb, M, H, st));
+      const float* dres = d_h;
+      if (top) {                                   // residual gradient of the block: d_h holds it for the U rows only
+        CK(hipMemsetAsync(d_full, 0, MH * sizeof(float), st));
+        CK(launch_scatter_rows((const bf16_t*)d_h, sv->urow, (bf16_t*)d_full, 2 * H, Mm, 2 * H, st));      // fp32 rows = 2H bf16 units
+        dres = d_full;
+      }
+      CK(launch_rmsnorm_bwd(d_n, sv->x + (size_t)i * MH, 1, w.ln1, b.rstd1, dres, 1, dX, dXb, M, H, st));
     }
   }
   if (layer_lo == 0 && d_feats) {

@@ -140,7 +140,7 @@ def pair_flops_packed(d: LlavaDims, q_len: int, t_len: int, K: int = 2, ref_merg
     return 2 * f_row + dgrad + wgrad + f_img - (2 * p_lora * Lp if ref_merged else 0)
 
 
-def pair_flops_ragged(d: LlavaDims, prefix_rows, resp_rows, ref_merged: bool = False) -> float:
+def pair_flops_ragged(d: LlavaDims, prefix_rows, resp_rows, ref_merged: bool = False, compact_top: bool = True) -> float:
     """FLOPs EXECUTED for one preference pair on ragged rows (ctx.CtxEngine default: padding positions are not rows of any kernel):
     `prefix_rows` valid image + query positions, `resp_rows` = valid lengths of the K responses packed behind it.  Same conventions
     as pair_flops_packed; the head (lm_head + log-softmax) runs on the valid response tokens only (compact head rows)."""
@@ -155,4 +155,11 @@ def pair_flops_ragged(d: LlavaDims, prefix_rows, resp_rows, ref_merged: bool = F
         + 2 * d.n_patches * (d.patch_k * vh + vh * H + H * H)
     dgrad = 2 * (p_lin + p_lora) * rows + 2 * nl * 4 * H * pairs
     wgrad = 4 * p_lora * rows
-    return 2 * f_row + dgrad + wgrad + f_img - (2 * p_lora * rows if ref_merged else 0)
+    total = 2 * f_row + dgrad + wgrad + f_img - (2 * p_lora * rows if ref_merged else 0)
+    if compact_top:
+        # top decoder layer: o-projection and MLP (and their LoRA) only on the rows the head reads (last prefix row + response rows)
+        skipped = rows - (1 + sum(max(v - 1, 0) for v in resp_rows)) if any(v > 0 for v in resp_rows) else rows
+        p_om = H * H + 3 * H * d.ffn
+        l_om = sum(d.lora_r * sum(llm_linear_shape(d, lin)) for lin in ("self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"))
+        total -= skipped * (2 * (p_om + l_om) + 2 * (p_om + (0 if ref_merged else l_om)) + 2 * (p_om + l_om) + 4 * l_om)
+    return total

@@ -211,6 +211,42 @@ def test_ragged_rows_equal_padded_rows(env, which, pack):
 
 
 @pytest.mark.parametrize("pack", [True, False])
+def test_compact_top_layer_equals_full_top_layer(env, pack):
+    """Ragged default: the TOP decoder layer's o-projection and MLP run only on the rows the head reads (last prefix row + response
+    rows), forward and backward.  Against the same context with flag bit 7 (top layer on every row): log-probs and LoRA gradients
+    agree to the tile-order noise of GEMMs with another row count - the rows left out are read by nothing."""
+    from opadpo_amd.ctx import CtxEngine
+    ad, p = env["ads"]["pol"], env["p"]
+    full = CtxEngine(env["base"])
+    full.set_flags(use_tr=1 | 128)
+    g = torch.Generator().manual_seed(5)
+    w = {k: torch.randn(3, 24, generator=g).to(env["dev"]) for k in ("chosen_response", "rejected_response")}
+    res = []
+    for eng in (full, env["cxr"]):
+        ad.grad.zero_()
+        out = _policy(eng, ad, 24, pack)(**_kw(p, eng), temperature=0.9)
+        sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+        torch.cuda.synchronize()
+        res.append(({k: v.detach().clone() for k, v in out.items()}, ad.grad.clone()))
+    for key, ids in (("chosen_response", p["chosen"]), ("rejected_response", p["rejected"])):
+        valid = ids != 0
+        a, b = res[0][0][key + "_logprobs"], res[1][0][key + "_logprobs"]
+        assert bool((b[~valid] == 0).all())
+        rel = ((a - b).abs()[valid] / a.abs()[valid].clamp_min(1e-3))
+        assert float(rel.mean()) < 5e-4 and float(rel.max()) < 1e-2, (float(rel.mean()), float(rel.max()))
+        assert float((res[0][0][key + "_entropies"] - res[1][0][key + "_entropies"]).abs().max()) < 2e-2
+    rel = float((res[0][1] - res[1][1]).norm() / res[0][1].norm())
+    assert rel < 1e-2, rel
+    # block by block: the top layer's own blocks (computed on compact rows) and the layer below it (fed through the scattered gradients)
+    d = env["d"]
+    n = ad.layer_numel
+    for i in range(d.n_layers):
+        a, b = res[0][1][i * n:(i + 1) * n], res[1][1][i * n:(i + 1) * n]
+        assert float((a - b).norm() / a.norm()) < 1.5e-2, i
+    full.close()
+
+
+@pytest.mark.parametrize("pack", [True, False])
 def test_ragged_rows_backward(env, pack):
     ad, p = env["ads"]["pol"], env["p"]
     g = torch.Generator().manual_seed(3)
