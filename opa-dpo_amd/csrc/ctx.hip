@@ -937,7 +937,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dz, V, c->lm_head_t, V, V, d_hn, H, 0, R, H); CK(run_gemm(c, g, st)); }
     CK(launch_rmsnorm_bwd(d_hn, sv->hs, 1, c->norm, sv->rstd_f, nullptr, 0, d_hs, nullptr, R, H, st));
     CK(hipMemsetAsync(dX, 0, MH * sizeof(float), st));
-    if (sv->K > 1 || sv->ragged) CK(launch_scatter_add_rows_f32(d_hs, sv->rows, dX, H, R, H, st));     // rows repeat: the last prefix row feeds token 0 of every response (ragged: pad labels share a clamped row)
+    if (sv->K > 1 || sv->ragged) CK(launch_scatter_add_rows_f32(d_hs, sv->rows, dX, H, R, H, st));     // rows repeat: the last prefix row feeds token 0 of every response (ragged: compact head rows; with the compact top layer `rows` index the U rows that dX holds for that layer)
     else CK(launch_scatter_rows((const bf16_t*)d_hs, sv->rows, (bf16_t*)dX, 2 * H, R, 2 * H, st));
     CK(launch_f32_to_bf16(dX, dXb, MH, st));
   }
