@@ -47,6 +47,66 @@ def _pmc_traffic():
     return None, None
 
 
+def _parity_record():
+    """HIP-vs-oracle parity of the benchmarked path at the benchmarked DEPTH (tests/test_fulldepth_parity_gpu.py: full LLaVA-1.5-7B,
+    32 layers, 2 pairs at seq512, product path = context API, packed ragged rows, merged reference adapter; per-token log-prob error
+    against oracle/llava_ref.py in fp32): the newest committed profiles/r*_parity_fulldepth.json (the test writes it under
+    gpurun_out/; a CPU-hours oracle cannot run inside the timed process)."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_parity_fulldepth.json")))):
+        try:
+            r = json.load(open(f))
+            out = dict(r["bench_line"])
+            out["source"] = os.path.basename(f)
+            return out
+        except Exception:
+            continue
+    return None
+
+
+def cpu_baseline_config_p(dims_kw, n_layers=1):
+    """SURVEY.md §8(d) config (1) timed DIRECTLY on the host cores: 8 pairs, query 32 + response 96 (L = 703), fp32, world 1, the whole
+    path of a pair - CLIP tower + projector once per image, frozen-reference forward (no grad) and policy forward on chosen + rejected,
+    token-level DPO loss, backward into the LoRA tensors - on the oracle (the parity-checked CPU restatement of the reference's
+    forward), with the decoder truncated to `n_layers` of the 32 (stated; §8d allows the truncation for this config)."""
+    from oracle import dpo_ref as DR
+    from oracle import llava_ref as LR
+    torch.set_num_threads(min(os.cpu_count(), 64))
+    d = LR.LlavaDims(**{**dims_kw, "n_layers": n_layers})
+    W = LR.init_weights(d, seed=0)
+    lora_p = {k: v.requires_grad_(True) for k, v in LR.init_lora(d, seed=1, with_vision=False).items()}
+    lora_r = LR.init_lora(d, seed=2, with_vision=False)
+    g = torch.Generator().manual_seed(0)
+    B, Q, T = 8, 32, 96
+    images = torch.randn(B, 3, d.image_size, d.image_size, generator=g)
+    queries = torch.randint(3, d.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    resp = {}
+    for b in range(B):
+        n_pad = int(torch.randint(0, Q // 2 + 1, (1,), generator=g))
+        queries[b, :n_pad] = 0
+        qmask[b, :n_pad] = False
+        queries[b, int(torch.randint(n_pad, Q, (1,), generator=g))] = -200
+    for k in ("chosen_response", "rejected_response"):
+        ids = torch.randint(3, d.vocab, (B, T), generator=g)
+        for b in range(B):
+            ln = int(torch.randint(T // 6, T, (1,), generator=g))
+            ids[b, ln] = 2
+            ids[b, ln + 1:] = 0
+        resp[k] = ids
+    t0 = time.time()
+    with torch.no_grad():
+        r = LR.policy_forward(images, queries, qmask, resp, W, lora_r, d, 1.0)
+    o = LR.policy_forward(images, queries, qmask, resp, W, lora_p, d, 1.0)
+    loss, _, _ = DR.plain_pair_loss(DR.DPOConfig(), o["chosen_response_logprobs"], o["rejected_response_logprobs"],
+                                    r["chosen_response_logprobs"], r["rejected_response_logprobs"])
+    loss.backward()
+    dt = time.time() - t0
+    return {"pairs": B, "query_len": Q, "response_len": T, "L": Q + T + d.n_patches - 1, "n_layers_run": n_layers, "n_layers_model": dims_kw["n_layers"],
+            "seconds": dt, "pairs_per_s_truncated_model": B / dt,
+            "note": "directly timed, nothing extrapolated: vision tower (both passes), decoder truncated to n_layers_run, head, DPO loss, LoRA backward"}
+
+
 def cpu_baseline(dims_kw, q_len, t_len):
     """Reported CPU baseline: the oracle (the parity-checked CPU restatement of the reference's forward, kind
     'port') on the host cores, on a bounded sample: ONE of the 32 decoder layers at 7B width, one pair =
@@ -183,6 +243,7 @@ def main():
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
     ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward fused into the dgrad epilogue, bit 7: top decoder layer on every row)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the dense-batch and exchange-overlap sub-records (measured after the timed region)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
     args = ap.parse_args()
@@ -232,32 +293,41 @@ def main():
     opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode,
                     bucket_bounds=layer_buckets(pol_ad.layer_numel, d.n_layers, 4))
 
-    def bucket_hook(layer):          # the exchange of a bucket of layers starts when the backward has left its lowest layer
-        pos = layer * pol_ad.layer_numel
-        for bi, b in enumerate(opt.buckets):
-            if b.lo == pos:
-                opt.launch_bucket(bi)
+    def make_hook(o):                # the exchange of a bucket of layers starts when the backward has left its lowest layer
+        def hook(layer):
+            pos = layer * pol_ad.layer_numel
+            for bi, b in enumerate(o.buckets):
+                if b.lo == pos:
+                    o.launch_bucket(bi)
+        return hook
+    bucket_hook = make_hook(opt)
     largs = DPOArgs()
     # a POOL of different synthetic micro-batches, cycled over the steps: with ragged rows the cost of a step depends on the valid
     # lengths of its batch (SURVEY.md §8d draws them per pair), so one fixed batch would be a biased sample
     n_pool = max(1, args.batch_pool) * args.accum
     pool = [synth_pairs(d, args.pairs, q_len, t_len, seed=1000 * rank + i, device=dev) for i in range(n_pool)]
+    main_pool, main_opt = pool, opt
     step_no = [0]
 
-    def step():
-        k0 = (step_no[0] * args.accum) % n_pool
+    def step(pool=None, opt=None, hook=None):
+        pool = pool if pool is not None else main_pool
+        opt = opt if opt is not None else main_opt
+        hook = hook if hook is not None else bucket_hook
+        k0 = (step_no[0] * args.accum) % len(pool)
         step_no[0] += 1
         batches = pool[k0:k0 + args.accum]
         for mi, b in enumerate(batches):
             feats = eng.encode_images(b["images"])
+            # row_lead / row_lens: the batch's ragged-row plan as the (synthetic) collator produced it on the host - no pass reads
+            # anything back from the device
             kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
-                      chosen_response=b["chosen"], rejected_response=b["rejected"])
+                      chosen_response=b["chosen"], rejected_response=b["rejected"], row_lead=b["row_lead"], row_lens=b["row_lens"])
             with torch.no_grad():
                 r = ref_policy(**kw)
             o = policy(**kw)
             loss, _, _ = pair_loss(largs, o["chosen_response_logprobs"], o["rejected_response_logprobs"],
                                    r["chosen_response_logprobs"], r["rejected_response_logprobs"])
-            policy.layer_done_hook = bucket_hook if mi == len(batches) - 1 else None
+            policy.layer_done_hook = hook if mi == len(batches) - 1 else None
             loss.backward()
             policy.layer_done_hook = None
         opt.step(grad_accum_div=args.accum)
@@ -350,16 +420,77 @@ def main():
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
                "roofline": roof}
+        par = _parity_record()
+        if par is not None and args.model == "7b":
+            out["parity"] = par
+        if world == 1 and not args.no_side_legs and not args.op_level:
+            def timed(n_warm, n, **kw):
+                for _ in range(n_warm):
+                    step(**kw)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(n):
+                    step(**kw)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n
+            # (a) the seq512 shape with NOTHING to drop: every query 128 and every response 384 tokens long (no padding), same code path
+            try:
+                dense_pool = [synth_pairs(d, args.pairs, q_len, t_len, seed=4242 + i, device=dev, dense=True) for i in range(args.accum)]
+                dt_d = timed(1, 3, pool=dense_pool)
+                fl_d = pair_flops_packed(d, q_len, t_len, 2, ref_merged=not args.no_merge_ref) if pack else fl_ref
+                out["dense"] = {"value": args.pairs * args.accum / dt_d, "unit": "pairs/s", "ms_per_step": dt_d * 1e3, "steps": 3,
+                                "rows_per_pair": (q_len + d.n_patches - 1 + 2 * t_len) if pack else 2 * (q_len + t_len + d.n_patches - 1),
+                                "executed_flops_per_pair_TF": fl_d / 1e12,
+                                "mfma_roofline_frac_end_to_end": args.pairs * args.accum / dt_d * fl_d / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                                "note": "all queries / responses at full length (no padding for the ragged layout to drop): the seq512-dense rate of the same kernels"}
+                del dense_pool
+            except Exception as e:
+                out["dense"] = {"error": repr(e)}
+            # (b) does the data-parallel exchange hide behind the backward?  Same step with a 1-rank RCCL group: every bucket's bf16 staging
+            # cast + reduce_scatter is launched from the layer hook INSIDE the backward, all-gathers after AdamW (optim.FlatAdamW zero1),
+            # A/B against the collective-free step measured back to back on the same pool
+            if args.model == "7b" and not dist.is_initialized():
+                try:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29547")
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                    os.environ["OPADPO_FORCE_COLLECTIVES"] = "1"
+                    opt2 = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode="zero1",
+                                     bucket_bounds=layer_buckets(pol_ad.layer_numel, d.n_layers, 4))
+                    os.environ.pop("OPADPO_FORCE_COLLECTIVES", None)
+                    n_ab = max(4, min(8, len(main_pool)))
+                    step_no[0] = 0
+                    t_with = timed(2, n_ab, opt=opt2, hook=make_hook(opt2))
+                    step_no[0] = 0
+                    t_without = timed(2, n_ab)
+                    out["exchange_overlap"] = {"world": 1, "buckets": len(opt2.buckets), "steps": n_ab,
+                                               "ms_per_step_with_inline_collectives": t_with * 1e3, "ms_per_step_without": t_without * 1e3,
+                                               "overlapped_step_delta_ms": (t_with - t_without) * 1e3,
+                                               "delta_frac_of_step": (t_with - t_without) / t_without,
+                                               "note": "1-rank RCCL group on one MI355X: per bucket fp32->bf16 staging + reduce_scatter launched from the "
+                                                       "backward's layer hook, sharded AdamW, per-bucket all_gather; same batches both ways"}
+                    del opt2
+                    dist.destroy_process_group()
+                except Exception as e:
+                    out["exchange_overlap"] = {"error": repr(e)}
+                    os.environ.pop("OPADPO_FORCE_COLLECTIVES", None)
         if args.model == "7b" and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(dict(hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim,
                                                         ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
+                try:
+                    out["cpu_baseline"]["config_p_direct"] = cpu_baseline_config_p(dict(
+                        hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim, ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r,
+                        lora_alpha=d.lora_alpha, v_hidden=d.v_hidden, v_layers=d.v_layers, v_heads=d.v_heads, v_ffn=d.v_ffn,
+                        image_size=d.image_size, patch=d.patch))
+                except Exception as e:
+                    out["cpu_baseline"]["config_p_direct"] = {"error": repr(e)}
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"error": repr(e)}
         if args.model == "7b" and world == 1 and not (args.no_rollout and args.no_exchange_probe):
             # side records, measured AFTER the timed region on the same GPU; the training state is released first
             numel, layer_numel = pol_ad.numel, pol_ad.layer_numel
-            del opt, policy, ref_policy, pol_ad, ref_ad, pool, loss
+            del opt, main_opt, main_pool, policy, ref_policy, pol_ad, ref_ad, pool, loss
             eng.release()
             torch.cuda.empty_cache()
             if not args.no_exchange_probe:

@@ -323,6 +323,10 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* ctx, int adapter_id, const int32_t* ids,
 int opadpo_seq_logprobs_bwd(opadpo_ctx* ctx, opadpo_saved* saved, const float* dlogp, const float* dent, float* d_feats, int layer_hi,
                             int layer_lo, void* stream);
 int opadpo_saved_release(opadpo_ctx* ctx, opadpo_saved* saved);
+/* diagnostics (parity tests: the per-layer drift curve of the residual stream): copies the fp32 residual stream ENTERING decoder
+ * layer `layer` of a training forward, [rows, hidden], into dst (device memory, rows*hidden floats) and returns the row count in
+ * *rows (ragged passes: the compact valid rows, sequence by sequence; padded: S * L).  dst = NULL only queries *rows. */
+int opadpo_saved_residual(opadpo_ctx* ctx, const opadpo_saved* saved, int layer, float* dst, int* rows, void* stream);
 
 /* policy.generate(do_sample=True, ...) (online_generator.py:292-309): prefill of B left-padded queries [B,Q] + token 0; the KV
  * cache ([n_layers, B, heads, Q+575+max_new_tokens, head_dim] x2) lives in the context.  history [max_new_tokens, B] int32

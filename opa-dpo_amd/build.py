@@ -43,12 +43,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(src):
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        ostamp = obj + ".stamp"                     # per-object stamp: only the sources that changed (or any header) are recompiled
+        odig = _digest([src] + headers)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == odig:
+            return obj
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(ostamp, "w") as f:
+            f.write(odig)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

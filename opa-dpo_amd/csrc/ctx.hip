@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void splice_grad_kernel(const float* dX, const
 // buffers of a pass, so no GEMM / norm / SwiGLU / RoPE row is spent on padding.  Per sequence (meta row, META_STRIDE(K) ints):
 // [row_start, b_0 .. b_K, lead] - b_0 = end of the prefix, b_a = start of response a, b_K = rows of the sequence (relative), lead =
 // dropped left-pad positions.  Padded position of compact row r: r < b_0 -> lead + r; response a, token t = r - b_a -> pfx + a*T + t.
+// The meta table travels as by-value kernel arguments (no host staging buffer whose lifetime would have to outlive the launch):
+// 960 ints per launch, as many launches as the table needs (one for S*(2K+4) <= 960, i.e. up to 120 packed pairs).
 struct MetaBlob { int32_t v[960]; };
 __global__ void write_meta_kernel(MetaBlob blob, int32_t* dst, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = blob.v[i];
@@ -236,7 +238,8 @@ struct opadpo_ctx {
   std::vector<Block> cache;                       // released arenas kept for reuse (default allocator only)
   void* ws = nullptr; size_t ws_bytes = 0;        // scratch of vision / backward / decode
   size_t bytes_live = 0, bytes_peak = 0;
-  size_t arena_hint[2] = {0, 0};                  // largest activation arena requested so far (no-grad / training pass)
+  size_t arena_hint[2][16] = {};                  // largest activation arena requested so far, per (no-grad / training pass, responses per row K):
+                                                  // CoPO's K = 2 masked pass does not inherit the K = 3 pass's worst case
   std::vector<opadpo_saved*> live;
   // dispatch
   int gemm_variant = -1, use_tr = -1;             // -1: process default (opadpo_set_flags)
@@ -774,14 +777,14 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   sv->ids = ids; sv->feat_row = feat_row;
   // ragged rows: row_plan (HOST, [S][K+1]) = per sequence the number of dropped left-pad positions and the valid length of every
   // response (trailing pad dropped); the valid rows of the batch become the M of every row-wise kernel of the pass
-  MetaBlob blob;
+  std::vector<int32_t> metav;
   if (row_plan) {
     const int stride = 2 * K + 4;
-    if (S * stride > (int)(sizeof(blob.v) / sizeof(int32_t)) || K > 8) { delete sv; return cbad(c, __func__, "row_plan: too many sequences / responses for the ragged layout"); }
+    metav.assign((size_t)S * stride, 0);
     int row = 0, lmax = 0;
     for (int q = 0; q < S; ++q) {
       const int32_t* rp = row_plan + (size_t)q * (K + 1);
-      int32_t* m = blob.v + q * stride;
+      int32_t* m = metav.data() + (size_t)q * stride;
       if (rp[0] < 0 || rp[0] >= pfx) { delete sv; return cbad(c, __func__, "row_plan: dropped left padding must leave a non-empty prefix"); }
       m[0] = row; m[1] = pfx - rp[0]; m[2 + K] = rp[0];
       for (int k = 0; k < K; ++k) {
@@ -793,11 +796,11 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
     }
     int cells = 0;                                  // compact head rows, in the [k][s] order of the outputs
     for (int k = 0; k < K; ++k)
-      for (int q = 0; q < S; ++q) { blob.v[q * stride + 3 + K + k] = cells; cells += row_plan[(size_t)q * (K + 1) + 1 + k]; }
+      for (int q = 0; q < S; ++q) { metav[(size_t)q * stride + 3 + K + k] = cells; cells += row_plan[(size_t)q * (K + 1) + 1 + k]; }
     int nu = 0;                                     // rows of the compact top layer (U), sequence by sequence
     for (int q = 0; q < S; ++q) {
       const int32_t* rp = row_plan + (size_t)q * (K + 1);
-      blob.v[q * stride + 3 + 2 * K] = nu;
+      metav[(size_t)q * stride + 3 + 2 * K] = nu;
       int any = 0;
       for (int k = 0; k < K; ++k) { any |= rp[1 + k] > 0; nu += std::max(rp[1 + k] - 1, 0); }
       nu += any;
@@ -810,7 +813,7 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   sv->bytes = saved_layout(d, sv, nullptr);
   // ragged batches differ in size: ask for the largest arena seen so far for this kind of pass, so that the allocator hands the
   // same block back every time instead of growing (and fragmenting) its pool
-  size_t& hint = c->arena_hint[train ? 1 : 0];
+  size_t& hint = c->arena_hint[train ? 1 : 0][std::min(K, 15)];
   if (sv->ragged) {                               // size for the padded row count of this shape: a ragged batch can never need more
     opadpo_saved worst = *sv;
     worst.M = S * Lp; worst.L = Lp;
@@ -831,8 +834,13 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   Rag rag{sv->meta, sv->meta_stride, K, sv->M, sv->row_pos};
   const Rag* rg = sv->ragged ? &rag : nullptr;
   if (rg) {
-    hipLaunchKernelGGL(write_meta_kernel, dim3(1), dim3(256), 0, st, blob, sv->meta, S * sv->meta_stride);
-    CKS(hipGetLastError());
+    for (size_t o = 0; o < metav.size(); o += sizeof(MetaBlob) / sizeof(int32_t)) {
+      MetaBlob blob;
+      const int n = (int)std::min(metav.size() - o, sizeof(MetaBlob) / sizeof(int32_t));
+      memcpy(blob.v, metav.data() + o, (size_t)n * sizeof(int32_t));
+      hipLaunchKernelGGL(write_meta_kernel, dim3(1), dim3(256), 0, st, blob, sv->meta + o, n);
+      CKS(hipGetLastError());
+    }
     hipLaunchKernelGGL(embed_splice_ragged_kernel, dim3(sv->L, S), dim3(256), 0, st, ids, text_mask, c->embed, feats, feat_row, image_mask, sv->x,
                        sv->key_mask, sv->row_pos, sv->meta, sv->meta_stride, K, T, n_txt, P, H, OPADPO_IMAGE_TOKEN);
     CKS(hipGetLastError());
@@ -844,6 +852,12 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
                              sv->Uc > 0 ? sv->urow : nullptr);
   else hipLaunchKernelGGL(head_index_kernel, g1(Rall), dim3(256), 0, st, ids, S, n_txt, Lp, pfx, K, T, sv->rows, sv->labels);
   CKS(hipGetLastError());
+  if (R == 0) {       // every response of the batch is empty: all cells are padding (-0.0 / 0), there is no head row and no gradient
+    hipLaunchKernelGGL(fill_f32_kernel, g1(Rall), dim3(256), 0, st, logp, -0.0f, ent, 0.0f, Rall);
+    CKS(hipGetLastError());
+    if (train) *saved_out = sv; else { saved_destroy(c, sv); if (saved_out) *saved_out = nullptr; }
+    return 0;
+  }
   float* const Y = sv->x + (size_t)(train ? d.n_layers : 2) * MH;          // branch product of the o / down projections (residual deferred)
   const float* res = sv->x;
   const float* yin = nullptr;
@@ -889,6 +903,15 @@ int opadpo_saved_release(opadpo_ctx* c, opadpo_saved* saved) {
   return 0;
 }
 
+int opadpo_saved_residual(opadpo_ctx* c, const opadpo_saved* sv, int layer, float* dst, int* rows, void* stream) {
+  if (!c) return (int)hipErrorInvalidValue;
+  if (!sv || std::find(c->live.begin(), c->live.end(), sv) == c->live.end()) return cbad(c, __func__, "unknown activation handle");
+  if (!sv->train || layer < 0 || layer >= c->d.n_layers) return cbad(c, __func__, "needs a training forward and 0 <= layer < n_layers");
+  if (rows) *rows = sv->M;
+  if (dst) CK(hipMemcpyAsync(dst, sv->x + (size_t)layer * sv->M * c->d.hidden, (size_t)sv->M * c->d.hidden * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
 // ---- LoRA backward (model.py seq_logprobs_bwd; rl_trainer.py:162 accelerator.backward) -----------------------------------------
 // Layers [layer_lo, layer_hi] are processed top-down; the first call of a backward must start at layer_hi = n_layers - 1 (it runs
 // the head backward), later calls continue where the previous one stopped (the data-parallel host launches the exchange of a
@@ -912,6 +935,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
     cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); need = cv.off; }
+  if (R == 0) return 0;                               // no valid response token: every gradient of this pass is exactly zero
   const bool first = layer_hi == d.n_layers - 1;
   if (!first && (c->ws_bytes < need || !c->ws)) return cbad(c, __func__, "ranged backward must start at the top layer");
   void* base = ctx_ws(c, need, st);

@@ -80,6 +80,7 @@ SIGNATURES.update({
     "opadpo_seq_logprobs_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p],
     "opadpo_seq_logprobs_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "opadpo_saved_release": [_p, _p],
+    "opadpo_saved_residual": [_p, _p, _i, _p, _p, _p],
     "opadpo_decode_begin": [_p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _f, _u64, _i, _i, _i, _p, _p],
     "opadpo_decode_step": [_p, _p],
     "opadpo_decode_run": [_p, _i, _i, _p],

@@ -153,6 +153,16 @@ class FlatAdamW:
         self.hi = self.lo + (self.buckets[0].s_len if self.sharded else n)
         self.per = self.buckets[0].per
 
+    def release_full_master(self, adapter=None) -> None:
+        """ZeRO-1 (sharded) only: drop the full-size fp32 master - this rank's slices live in `p_shard`, nothing reads the full buffer
+        after construction (checkpoints assemble it from the shards).  `adapter`: the LoraAdapter whose `.master` is the same
+        tensor; its reference is dropped too so that the 2.5 GB (7B, r = 256) really return to the allocator."""
+        if not self.sharded:
+            return
+        self.master = None
+        if adapter is not None and getattr(adapter, "master", None) is not None:
+            adapter.master = None
+
     # ---- layout helpers -----------------------------------------------------------------------------
     def shard_ranges(self) -> List[Tuple[int, int, int]]:
         """[(flat_lo, flat_hi, shard_offset)] of the elements this rank updates."""

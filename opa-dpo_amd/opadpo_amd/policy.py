@@ -26,6 +26,25 @@ def response_keys(kwargs) -> List[str]:
             if "response" in k and "_mask" not in k and "scores" not in k and "image_relations" not in k]
 
 
+def host_row_plan(queries: torch.Tensor, queries_attn_masks: torch.Tensor, responses: Dict[str, torch.Tensor]):
+    """Ragged-row plan of a collated batch, computed where the batch is born - on the HOST (data_utils_dpo.py:363-365 pads there):
+    -> (lead int32 [B], {response key: valid length int32 [B]}), CPU tensors.  lead = leading masked query positions before the image
+    token, valid length = position after the last non-pad token of a response.  Handing these to the policy (`row_lead=`, `row_lens=`)
+    keeps the pass free of any device->host read; without them the policy derives the same numbers from the tensors it is given (on
+    the host when they are host tensors, else with two small device reductions and ONE read)."""
+    q, m = queries.cpu(), queries_attn_masks.cpu().bool()
+    Q = q.shape[1]
+    if m.shape[1] != Q:                                     # CoPO 'attention': [image mask | query mask]
+        m = m[:, -Q:]
+    img_pos = (q == IMAGE_TOKEN_INDEX).int().argmax(dim=1)
+    lead = torch.minimum((m.int().cumsum(1) == 0).sum(1), img_pos).to(torch.int32)
+    lens = {}
+    for k, r in responses.items():
+        r = r.cpu()
+        lens[k] = (r.shape[1] - ((r != PAD_ID).flip(1).int().cumsum(1) == 0).sum(1)).to(torch.int32)
+    return lead, lens
+
+
 class _SeqLogprobs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, policy, batch, feats, temperature):
@@ -66,7 +85,7 @@ class AutoregressivePolicy(torch.nn.Module):
         self._pending_bwd = 0             # training forwards whose backward has not run yet
         self.layer_done_hook = None       # callable(layer) set by the trainer on the gradient-sync micro-batch (optim.launch_bucket)
 
-    def build_batch(self, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
+    def build_batch(self, queries, queries_attn_masks, responses: Dict[str, torch.Tensor], row_lead=None, row_lens=None):
         """-> (response keys, SeqBatch).  The reference policy and the trained policy of a step see the SAME collated tensors
         (dpo_trainer.py rollout() / compute_policy_loss): the device-side concatenations and - for ragged rows - the one host read of
         the row plan are done once per distinct input (cache on the engine, keyed by storage, version counter and shape)."""
@@ -77,16 +96,19 @@ class AutoregressivePolicy(torch.nn.Module):
             (t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in [queries, queries_attn_masks] + [responses[k] for k in keys])
         cache = self.engine.__dict__.setdefault("_batch_cache", {})
         hit = cache.get(ck)
-        if hit is not None:
-            return hit[0], hit[1]
-        out = self._build_batch(keys, queries, queries_attn_masks, responses)
+        if hit is not None:           # only the SeqBatch is shared: the key NAMES are the caller's (the same tensors may arrive under other names)
+            return keys, hit[0]
+        batch = self._build_batch(keys, queries, queries_attn_masks, responses, row_lead, row_lens)
         if len(cache) >= 4:
             cache.pop(next(iter(cache)))
-        cache[ck] = (out[0], out[1], queries, queries_attn_masks, [responses[k] for k in keys])      # the inputs stay alive with their entry: a recycled address cannot alias it
-        return out
+        cache[ck] = (batch, queries, queries_attn_masks, [responses[k] for k in keys])      # the inputs stay alive with their entry: a recycled address cannot alias it
+        return keys, batch
 
-    def _build_batch(self, keys, queries, queries_attn_masks, responses: Dict[str, torch.Tensor]):
+    def _build_batch(self, keys, queries, queries_attn_masks, responses: Dict[str, torch.Tensor], row_lead=None, row_lens=None):
         dev = self.engine.dev
+        ragged = getattr(self.engine, "ragged", False)
+        if ragged and row_lead is None and not queries.is_cuda and all(not responses[k].is_cuda for k in keys):
+            row_lead, row_lens = host_row_plan(queries, queries_attn_masks, {k: responses[k] for k in keys})     # host tensors: no device read at all
         d = self.engine.d
         B, Q = queries.shape
         queries = queries.to(dev)
@@ -108,9 +130,14 @@ class AutoregressivePolicy(torch.nn.Module):
         T = responses[keys[0]].shape[1]
         assert T == self.response_len, "policy slices with args.response_len (rl_models.py:121-123, Quirk Q7)"
         plan_q = plan_r = None
-        if getattr(self.engine, "ragged", False):
+        if ragged and row_lead is not None:
+            # the collator's own numbers (host_row_plan): nothing is read back from the device
+            plan_q = torch.as_tensor(row_lead, dtype=torch.int32).cpu()
+            plan_r = [torch.as_tensor(row_lens[k], dtype=torch.int32).cpu() for k in keys]
+        elif ragged:
             # ragged rows (ctx.CtxEngine): leading masked query positions before the image token and the trailing padding of every
-            # response are not rows of the pass.  Two small reductions on the device + ONE host read per batch (cached on the batch).
+            # response are not rows of the pass.  Fallback for callers that hand over DEVICE tensors without a plan: two small
+            # reductions on the device + ONE host read per batch (cached on the batch).
             img_pos = (queries == IMAGE_TOKEN_INDEX).int().argmax(dim=1)
             lead = torch.minimum((qmask_txt.int().cumsum(1) == 0).sum(1), img_pos)
             vlen = [T - ((responses[k].to(dev) != PAD_ID).flip(1).int().cumsum(1) == 0).sum(1) for k in keys]
@@ -124,7 +151,7 @@ class AutoregressivePolicy(torch.nn.Module):
                 T=T, K=K)
             if plan_q is not None:
                 batch.row_plan = torch.stack([plan_q] + plan_r, 1).cpu().contiguous()
-            return keys, batch
+            return batch
         batch = SeqBatch(
             ids=torch.cat(ids, 0).to(torch.int32).contiguous(),
             text_mask=torch.cat(masks, 0).to(torch.uint8).contiguous(),
@@ -133,14 +160,19 @@ class AutoregressivePolicy(torch.nn.Module):
             T=T)
         if plan_q is not None:          # stacked layout: K sequences per sample, one response each
             batch.row_plan = torch.stack([plan_q.repeat(K), torch.cat(plan_r, 0)], 1).cpu().contiguous()
-        return keys, batch
+        return batch
 
     def forward(self, images: Optional[torch.Tensor] = None, queries: torch.Tensor = None,
                 queries_attn_masks: torch.Tensor = None, temperature: Optional[float] = None,
-                image_feats: Optional[torch.Tensor] = None, mode: Optional[str] = None, **kwargs) -> Dict[str, torch.Tensor]:
+                image_feats: Optional[torch.Tensor] = None, mode: Optional[str] = None, row_lead: Optional[torch.Tensor] = None,
+                row_lens: Optional[Dict[str, torch.Tensor]] = None, **kwargs) -> Dict[str, torch.Tensor]:
+        """row_lead / row_lens (optional, HOST tensors from `host_row_plan`): the ragged-row plan of this batch as the collator knows
+        it; row_lens is keyed like the response kwargs (a key missing there falls back to the derived plan)."""
         if temperature is None:
             temperature = self.temperature
-        keys, batch = self.build_batch(queries, queries_attn_masks, kwargs)
+        if row_lens is not None and any(k not in row_lens for k in response_keys(kwargs)):
+            row_lead = row_lens = None
+        keys, batch = self.build_batch(queries, queries_attn_masks, kwargs, row_lead, row_lens)
         B = queries.shape[0]
         if image_feats is None:
             image_feats = self.engine.encode_images(images)   # once per image, shared by all response keys

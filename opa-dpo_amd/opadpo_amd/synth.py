@@ -79,16 +79,20 @@ def init_lora(d: LlavaDims, seed: int = 1, b_std: float = 0.01, device="cpu", dt
     return out
 
 
-def synth_pairs(d: LlavaDims, n_pairs: int, q_len: int, t_len: int, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+def synth_pairs(d: LlavaDims, n_pairs: int, q_len: int, t_len: int, seed: int = 0, device="cpu", dense: bool = False) -> Dict[str, torch.Tensor]:
     """(image, query, chosen, rejected) batch per SURVEY.md §8d: pixels ~ N(0,1); queries left-padded with
     0 for n_pad ~ U{0..q_len/2}, ids ~ U{3..V-1}, one IMAGE_TOKEN_INDEX at a random non-pad slot; responses:
-    ids for len ~ U{t_len/6 .. t_len-1}, then EOS 2, then pad 0."""
+    ids for len ~ U{t_len/6 .. t_len-1}, then EOS 2, then pad 0.  dense: no padding anywhere (full-length queries, responses of
+    t_len - 1 ids + EOS) - the seq512 shape with nothing for the ragged layout to drop.  The returned dict also carries the
+    batch's ragged-row plan as HOST tensors (`row_lead`, `row_lens`: policy.host_row_plan)."""
     g = torch.Generator().manual_seed(seed)
     pixels = torch.randn(n_pairs, 3, d.image_size, d.image_size, generator=g).to(torch.bfloat16)
     queries = torch.randint(3, d.vocab, (n_pairs, q_len), generator=g)
     qmask = torch.ones(n_pairs, q_len, dtype=torch.bool)
     for b in range(n_pairs):
         n_pad = int(torch.randint(0, q_len // 2 + 1, (1,), generator=g))
+        if dense:
+            n_pad = 0
         queries[b, :n_pad] = 0
         qmask[b, :n_pad] = False
         slot = int(torch.randint(n_pad, q_len, (1,), generator=g))
@@ -98,12 +102,19 @@ def synth_pairs(d: LlavaDims, n_pairs: int, q_len: int, t_len: int, seed: int = 
         ids = torch.randint(3, d.vocab, (n_pairs, t_len), generator=g)
         for b in range(n_pairs):
             ln = int(torch.randint(max(1, t_len // 6), t_len, (1,), generator=g))
+            if dense:
+                ln = t_len - 1
             ids[b, ln] = 2
             ids[b, ln + 1:] = 0
         return ids
 
     out = dict(images=pixels, queries=queries, queries_attn_masks=qmask, chosen=resp(), rejected=resp())
-    return {k: v.to(device) for k, v in out.items()}
+    # the ragged-row plan of the batch, from the host tensors (what a collator hands over with the batch): HOST int32
+    from .policy import host_row_plan
+    lead, lens = host_row_plan(queries, qmask, {"chosen_response": out["chosen"], "rejected_response": out["rejected"]})
+    dev_out = {k: v.to(device) for k, v in out.items()}
+    dev_out["row_lead"], dev_out["row_lens"] = lead, lens
+    return dev_out
 
 
 def synth_rollout_batches(d: LlavaDims, args, seed: int = 0):

@@ -10,6 +10,8 @@ Q12 no hidden-state output / lm_head only on response rows, Q13 rollouts stay re
 """
 from __future__ import annotations
 
+import warnings
+
 import json
 import os
 import re
@@ -21,7 +23,9 @@ import torch.distributed as dist
 from .dims import PAD_ID
 from .losses import DPOArgs, mask_percentage_per_row, mask_single_image, policy_loss
 from .optim import FlatAdamW, cosine_lr, layer_buckets
-from .policy import AutoregressivePolicy, response_keys
+from .policy import AutoregressivePolicy, host_row_plan, response_keys
+
+RESPONSE_KEYS = ("standard_response", "original_generate_response", "AI_pseudo_response")
 
 ADAPTER_MODEL_DIR = "adapter_model"
 OPTIMIZER_NAME = "optimizer.pt"
@@ -109,6 +113,7 @@ class DPOTrainer:
                                    max_grad_norm=getattr(args, "max_grad_norm", 1.0), mode=optimizer_mode,
                                    bucket_bounds=layer_buckets(ad.layer_numel, self.engine.d.n_layers, layers_per_bucket),
                                    exchange_dtype=exchange_dtype, **(optimizer_kwargs or {}))
+        self.optimizer.release_full_master(ad)       # ZeRO-1 across ranks: the fp32 master lives in this rank's slices only
         self.sched_step = 0
         self.total_sched_steps = 1
         self.log_history: List[dict] = []
@@ -130,6 +135,10 @@ class DPOTrainer:
         dev = self.engine.dev
         outs: List[Dict[str, torch.Tensor]] = []
         for batch in queries_data:
+            # ragged-row plan from the collator's HOST tensors (valid lengths are known here: no device->host read in any pass)
+            plan = None
+            if getattr(self.engine, "ragged", False) and not batch["queries"].is_cuda:
+                plan = host_row_plan(batch["queries"], batch["queries_attention_mask"], {k: batch[k] for k in RESPONSE_KEYS})
             b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
             images = b["images"].to(torch.bfloat16)
             rb = {"images": images, "queries": b["queries"], "queries_attn_masks": b["queries_attention_mask"]}
@@ -138,6 +147,12 @@ class DPOTrainer:
                 rb[k + "_attention_mask"] = b.get(k + "_attention_mask", b[k] != PAD_ID)
             feats = self.engine.encode_images(images)
             rb["image_feats"] = feats
+            pk = {}
+            if plan is not None:                   # host tensors; they travel with the rollout rows (cat / index like everything else)
+                rb["row_lead"] = plan[0]
+                for k in RESPONSE_KEYS:
+                    rb["rowlen_" + k[:-len("_response")]] = plan[1][k]
+                pk = dict(row_lead=plan[0], row_lens=plan[1])
             new_rb = None
             if a.CoPO:
                 if a.CoPO_method in ("random", "blockwise"):
@@ -159,12 +174,12 @@ class DPOTrainer:
                 new_rb["standard_response"] = rb["standard_response"]
                 new_rb["AI_pseudo_response"] = rb["AI_pseudo_response"]
             ref_out = self.ref_policy(**{k: v for k, v in rb.items() if k not in ("masked_images", "masked_image_feats",
-                                                                                  "masked_query_attn_masks")},
-                                      temperature=a.temperature)
+                                                                                  "masked_query_attn_masks", "row_lead")},
+                                      temperature=a.temperature, **pk)
             for k, v in ref_out.items():
                 rb["ref_base_" + k] = v
             if new_rb is not None:
-                ref_new = self.ref_policy(**new_rb, temperature=a.temperature)
+                ref_new = self.ref_policy(**new_rb, temperature=a.temperature, **pk)
                 for k, v in ref_new.items():
                     rb["ref_mask_" + k] = v
             if a.detailed_report and (a.response_score or a.response_image_relation):
@@ -179,7 +194,13 @@ class DPOTrainer:
         a = self.loss_args
         common = dict(queries=rollouts["queries"], queries_attn_masks=rollouts["queries_attn_masks"],
                       temperature=a.temperature)
-        out = self.policy(images=rollouts["images"], image_feats=rollouts.get("image_feats"), **common,
+        pk, pk_m = {}, {}
+        if "row_lead" in rollouts:
+            lens = {k: rollouts["rowlen_" + k[:-len("_response")]] for k in RESPONSE_KEYS}
+            pk = dict(row_lead=rollouts["row_lead"], row_lens=lens)
+            pk_m = dict(row_lead=rollouts["row_lead"], row_lens={"mask_standard_response": lens["standard_response"],
+                                                                 "mask_AI_pseudo_response": lens["AI_pseudo_response"]})
+        out = self.policy(images=rollouts["images"], image_feats=rollouts.get("image_feats"), **common, **pk,
                           standard_response=rollouts["standard_response"],
                           original_generate_response=rollouts["original_generate_response"],
                           AI_pseudo_response=rollouts["AI_pseudo_response"])
@@ -189,11 +210,11 @@ class DPOTrainer:
                         mask_AI_pseudo_response=rollouts["AI_pseudo_response"])
             if a.CoPO_method in ("random", "blockwise"):
                 out_m = self.policy(images=rollouts["masked_images"], image_feats=rollouts.get("masked_image_feats"),
-                                    **common, **resp)
+                                    **common, **resp, **pk_m)
             else:
                 out_m = self.policy(images=rollouts["images"], image_feats=rollouts.get("image_feats"),
                                     queries=rollouts["queries"], queries_attn_masks=rollouts["masked_query_attn_masks"],
-                                    temperature=a.temperature, **resp)
+                                    temperature=a.temperature, **resp, **pk_m)
         return policy_loss(a, rollouts, out, out_m)
 
     # ---- grad-accumulate -> exchange -> clip -> step (rl_trainer.py:138-179) ---------------------------------
@@ -221,6 +242,9 @@ class DPOTrainer:
                     st["loss/grad_norm"] = torch.tensor(self.optimizer.grad_norm_post_clip())
                     self.optimizer.zero_grad()
                     self.policy.adapter.refresh_transposed()
+                    if self.policy._pending_bwd:          # a forward whose backward never ran would silence the bucket hook for good
+                        warnings.warn(f"{self.policy._pending_bwd} policy forward(s) of this step never reached backward; exchange overlap counter reset")
+                        self.policy._pending_bwd = 0
                     stats_list.append({k: v.detach().float().cpu() for k, v in st.items()})
         return {k: torch.stack([s[k] for s in stats_list]) for k in stats_list[0]} if stats_list else {}
 

@@ -133,3 +133,175 @@ def test_p6_rollout_graph_equals_eager(full):
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert int((outs[0] >= 3).sum()) == outs[0].numel()
+
+
+# ---- P7: the benchmarked path against the oracle AT THE BENCHMARKED DEPTH ---------------------------------------------------
+def _oracle_full_pass(LR, W, lora, od, images, queries, qmask, resp, emulate_bf16):
+    """One evaluation of oracle/llava_ref.py on the stacked sequences (rl_models.py:95-132), keeping the residual stream after every
+    decoder layer.  -> ({key_logprobs}, [x after layer i: [K*B, L, H]])"""
+    from oracle.dpo_ref import policy_head, response_keys, stack_policy_inputs
+    keys = response_keys(resp)
+    ids, mask = stack_policy_inputs(queries, qmask, resp)
+    B, Q = queries.shape
+    T = resp[keys[0]].shape[1]
+    feats = LR.image_features(images, W, None, od, emulate_bf16).repeat(len(keys), 1, 1)
+    x, km = LR.splice(ids, mask, feats, W[LR.LLM_PREFIX + "embed_tokens.weight"], od.n_patches, None)
+    h, layers = LR.llama_decoder(x, km, W, lora, od, emulate_bf16, return_layers=True)
+    lp, _ = policy_head(LR.lm_logits(h, W, od, emulate_bf16), ids, Q, T, 1.0)
+    return {k: lp[i * B:(i + 1) * B] for i, k in enumerate(keys)}, layers
+
+
+def _stats(got, want, valid):
+    r = ((got - want).abs()[valid] / want.abs()[valid].clamp_min(1e-3)).double()
+    return {"mean": float(r.mean()), "p99": float(torch.quantile(r, 0.99)), "max": float(r.max())}
+
+
+def test_p7_full_depth_32_layers_against_the_oracle(full):
+    """BASELINE.json's configuration at its REAL depth: LLaVA-1.5-7B, 32 decoder layers, CLIP-L/14-336, 2 synthetic pairs at seq512,
+    the product path (context API, packed ragged rows, trained adapter K-concatenated, frozen adapter merged + SwiGLU-pair) against
+    oracle/llava_ref.py evaluated in fp32 and with bf16 emulated at the HIP pipeline's HBM write points
+    (rl_models.py:114-132, utils/common_utils.py:112-118).  Records, per response token: relative log-prob error mean / p99 / max;
+    the drift curve of the fp32 residual stream layer by layer; and the error of the LOG-RATIO pi - ref when policy and reference hold the
+    SAME adapter (exactly 0 in the reference, which runs both through identical PEFT code; here the merged copy rounds differently) -
+    the quantity dpo_loss consumes (dpo_trainer.py:444-449).  Report -> gpurun_out/parity_fulldepth.json (committed copy:
+    profiles/r*_parity_fulldepth.json, quoted by bench.py's `parity` record).
+
+    north_star asks for 1e-3 relative.  A 32-layer random-init bf16 pipeline does not reach that against fp32 arithmetic - the
+    oracle's OWN bf16 emulation does not either - so the assertions pin the HIP path to the oracle's bf16 realisation (never further
+    from fp32 than 1.35 x that realisation is) and cap the absolute numbers; the measured distances are what the report states."""
+    import ctypes as C
+    import json
+    import os
+    import time
+    from opadpo_amd import lib as L
+    from opadpo_amd.model import LoraAdapter
+    from opadpo_amd.policy import AutoregressivePolicy, host_row_plan
+    from opadpo_amd.synth import init_lora, init_weights, synth_pairs
+    from oracle import llava_ref as LR
+    s = full
+    d, eng, dev = s["d"], s["eng"], s["dev"]
+    od = LR.LlavaDims()
+    assert (od.hidden, od.n_layers, od.ffn, od.vocab, od.v_layers, od.image_size) == (d.hidden, d.n_layers, d.ffn, d.vocab, d.v_layers, d.image_size)
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    t_start = time.time()
+    # the fixture's weights again (device generators are deterministic), brought to the host for the oracle
+    Wd = init_weights(d, seed=0, device=dev)
+    W = {k: v.cpu().float() for k, v in Wd.items()}
+    del Wd
+    lora_d = init_lora(d, seed=1, device=dev)
+    lora = {k: v.cpu().float() for k, v in lora_d.items()}
+    ref_ad = LoraAdapter(d, lora_d, dev, trainable=False)      # the SAME adapter as the policy's, frozen and merged (bench.py / CLI default)
+    assert torch.equal(s["ad"].work[:65536].cpu(), ref_ad.work[:65536].cpu()), "the fixture's policy adapter is not init_lora(seed=1) any more"
+    ref_ad.merge_into_base(eng.base)
+    del lora_d
+    B, Q, T = 2, 128, 384
+    p = synth_pairs(d, B, Q, T, seed=21)
+    images, queries, qmask = p["images"].float(), p["queries"], p["queries_attn_masks"]
+    resp = {"chosen_response": p["chosen"], "rejected_response": p["rejected"]}
+    # ---- HIP: merged reference pass, then the training forward of the policy (activations kept: per-layer residual stream) ----
+    kw = dict(images=p["images"].to(dev), queries=queries, queries_attn_masks=qmask, **resp)
+    with torch.no_grad():
+        r_out = {k: v.cpu() for k, v in AutoregressivePolicy(eng, ref_ad, T, pack_responses=True)(**kw).items()}
+    pol = AutoregressivePolicy(eng, s["ad"], T, pack_responses=True)
+    keys, batch = pol.build_batch(queries, qmask, resp)
+    assert batch.row_plan is not None and batch.K == 2
+    feats = eng.encode_images(kw["images"])
+    logp, _, sv = eng.seq_logprobs_fwd(s["ad"], batch, feats, 1.0, train=True)
+    p_out = {k + "_logprobs": logp[i * B:(i + 1) * B].cpu() for i, k in enumerate(keys)}
+    lead, lens = host_row_plan(queries, qmask, resp)
+    assert torch.equal(batch.row_plan[:, 0], lead) and torch.equal(batch.row_plan[:, 1], lens["chosen_response"])
+    pfx = Q + d.n_patches - 1
+    n_rows = C.c_int(0)
+    eng._call("opadpo_saved_residual", sv.handle, 0, None, C.byref(n_rows), L.stream())
+    M = n_rows.value
+    assert M == sum(pfx - int(lead[b]) + int(lens["chosen_response"][b]) + int(lens["rejected_response"][b]) for b in range(B))
+    hip_x = []
+    buf = torch.empty(M, d.hidden, dtype=torch.float32, device=dev)
+    for i in range(1, d.n_layers):                 # x entering layer i = the residual stream after layer i - 1
+        eng._call("opadpo_saved_residual", sv.handle, i, buf.data_ptr(), None, L.stream())
+        hip_x.append(buf.cpu())
+    sv.release()
+    # compact row -> (stacked oracle sequence, padded position): prefix rows from the chosen sequence, response a from sequence a*B + b
+    seq_idx, pos_idx = [], []
+    for b in range(B):
+        ld = int(lead[b])
+        seq_idx += [b] * (pfx - ld)
+        pos_idx += list(range(ld, pfx))
+        for a, k in enumerate(keys):
+            n = int(lens[k][b])
+            seq_idx += [a * B + b] * n
+            pos_idx += list(range(pfx, pfx + n))
+    seq_idx, pos_idx = torch.tensor(seq_idx), torch.tensor(pos_idx)
+    assert len(seq_idx) == M
+    t_hip = time.time()
+    # ---- oracle: fp32, and bf16 emulated at the HBM write points ----
+    rep = {"model": "LLaVA-1.5-7B", "layers": d.n_layers, "pairs": B, "query_len": Q, "response_len": T, "rows": M,
+           "path": "opadpo_ctx, packed ragged rows; policy = K-concatenated LoRA, reference = merged copy + SwiGLU-pair epilogue"}
+    oracle_lp = {}
+    with torch.no_grad():
+        for name, emu in (("fp32", False), ("emu_bf16", True)):
+            t0 = time.time()
+            lp, layers = _oracle_full_pass(LR, W, lora, od, images, queries, qmask, resp, emu)
+            oracle_lp[name] = lp
+            drift = []
+            for i in range(d.n_layers - 1):
+                want = layers[i][seq_idx, pos_idx]
+                drift.append(float((hip_x[i] - want).norm() / want.norm()))
+            rep[f"residual_drift_vs_{name}"] = drift
+            if name == "fp32":
+                f32_layers = [l_[seq_idx, pos_idx] for l_ in layers[:-1]]
+            else:
+                rep["residual_drift_emu_vs_fp32"] = [float((layers[i][seq_idx, pos_idx] - f32_layers[i]).norm() / f32_layers[i].norm())
+                                                     for i in range(d.n_layers - 1)]
+            rep[f"oracle_{name}_seconds"] = time.time() - t0
+            del layers
+    worst = {}
+    for k in keys:
+        valid = resp[k] != 0
+        kk = k
+        for name, got, want in (("policy_vs_fp32", p_out[k + "_logprobs"], oracle_lp["fp32"][kk]),
+                                ("policy_vs_emu", p_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
+                                ("ref_merged_vs_fp32", r_out[k + "_logprobs"], oracle_lp["fp32"][kk]),
+                                ("ref_merged_vs_emu_unmerged", r_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
+                                ("oracle_emu_vs_fp32", oracle_lp["emu_bf16"][kk], oracle_lp["fp32"][kk])):
+            assert bool((got[~valid] == 0).all()) and bool((want[~valid] == 0).all())            # exact zeros on pad cells (Quirk Q4)
+            st = _stats(got, want, valid)
+            rep[f"{name}_{k}"] = st
+            w = worst.setdefault(name, {"mean": 0.0, "p99": 0.0, "max": 0.0})
+            for f in w:
+                w[f] = max(w[f], st[f])
+    rep["worst"] = worst
+    # log-ratio at policy == reference adapter: the reference computes exactly 0 (dpo_trainer.py:444-449 cl = pi_c - ref_c)
+    lr = {}
+    dl = []
+    for k in keys:
+        valid = resp[k] != 0
+        dlt = (p_out[k + "_logprobs"] - r_out[k + "_logprobs"])[valid].double()
+        lr[k] = {"mean_abs": float(dlt.abs().mean()), "p99_abs": float(torch.quantile(dlt.abs(), 0.99)), "max_abs": float(dlt.abs().max()),
+                 "mean_signed": float(dlt.mean())}
+        dl.append(p_out[k + "_logprobs"] - r_out[k + "_logprobs"])
+    both = (resp["chosen_response"] != 0) & (resp["rejected_response"] != 0)
+    z = 0.1 * (dl[0] - dl[1])[both].double()                # beta * (chosen log-ratio - rejected log-ratio): the sigmoid's argument (0 in the reference)
+    lr["dpo_logit_beta_0.1"] = {"mean_abs": float(z.abs().mean()), "max_abs": float(z.abs().max()),
+                                "loss_shift_mean": float((torch.nn.functional.softplus(-z) - 0.6931471805599453).mean())}
+    rep["logratio_policy_eq_reference"] = lr
+    rep["seconds_total"] = time.time() - t_start
+    rep["seconds_hip_side"] = t_hip - t_start
+    rep["bench_line"] = {"layers": d.n_layers, "pairs": B, "vs": "oracle/llava_ref.py fp32", "mean": worst["policy_vs_fp32"]["mean"],
+                         "p99": worst["policy_vs_fp32"]["p99"], "max": worst["policy_vs_fp32"]["max"],
+                         "reference_pass": worst["ref_merged_vs_fp32"], "oracle_bf16_vs_fp32": worst["oracle_emu_vs_fp32"],
+                         "vs_bf16_oracle": worst["policy_vs_emu"], "logratio_equal_adapters_mean_abs": max(lr[k]["mean_abs"] for k in keys),
+                         "north_star_tolerance": 1e-3}
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_fulldepth.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    print("[p7]", json.dumps({"worst": worst, "logratio": lr, "t": rep["seconds_total"]}))
+    ref_ad.merged = None
+    torch.cuda.empty_cache()
+    # the HIP path is a bf16 realisation of the oracle's function: never further from fp32 than 1.35 x the oracle's own bf16 emulation
+    for a, b in (("policy_vs_fp32", "oracle_emu_vs_fp32"), ("ref_merged_vs_fp32", "oracle_emu_vs_fp32")):
+        assert worst[a]["mean"] <= 1.35 * worst[b]["mean"] + 1e-4, (a, worst[a], worst[b])
+        assert worst[a]["p99"] <= 1.35 * worst[b]["p99"] + 5e-4, (a, worst[a], worst[b])
+    assert worst["policy_vs_fp32"]["mean"] < 1e-2 and worst["policy_vs_fp32"]["max"] < 0.1
+    assert max(rep["residual_drift_vs_fp32"]) < 5e-2
