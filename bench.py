@@ -94,17 +94,24 @@ def cpu_baseline_config_p(dims_kw, n_layers=1):
             ids[b, ln] = 2
             ids[b, ln + 1:] = 0
         resp[k] = ids
+    from oracle.dpo_ref import policy_head, stack_policy_inputs
+
+    def fwd(lora, feats):          # AutoregressivePolicy.forward on precomputed image features (once per image, like the product path)
+        ids, mask = stack_policy_inputs(queries, qmask, resp)
+        lp, _ = policy_head(LR.llava_logits(ids, mask, None, W, lora, d, feats=feats.repeat(2, 1, 1)), ids, Q, T, 1.0)
+        return {"chosen_response_logprobs": lp[:B], "rejected_response_logprobs": lp[B:]}
     t0 = time.time()
     with torch.no_grad():
-        r = LR.policy_forward(images, queries, qmask, resp, W, lora_r, d, 1.0)
-    o = LR.policy_forward(images, queries, qmask, resp, W, lora_p, d, 1.0)
+        feats = LR.image_features(images, W, None, d)
+        r = fwd(lora_r, feats)
+    o = fwd(lora_p, feats)
     loss, _, _ = DR.plain_pair_loss(DR.DPOConfig(), o["chosen_response_logprobs"], o["rejected_response_logprobs"],
                                     r["chosen_response_logprobs"], r["rejected_response_logprobs"])
     loss.backward()
     dt = time.time() - t0
     return {"pairs": B, "query_len": Q, "response_len": T, "L": Q + T + d.n_patches - 1, "n_layers_run": n_layers, "n_layers_model": dims_kw["n_layers"],
             "seconds": dt, "pairs_per_s_truncated_model": B / dt,
-            "note": "directly timed, nothing extrapolated: vision tower (both passes), decoder truncated to n_layers_run, head, DPO loss, LoRA backward"}
+            "note": "directly timed, nothing extrapolated: vision tower once per image, decoder truncated to n_layers_run, head, DPO loss, LoRA backward"}
 
 
 def cpu_baseline(dims_kw, q_len, t_len):
@@ -433,6 +440,8 @@ def main():
                     step(**kw)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0_) / n
+            eng.release()
+            torch.cuda.empty_cache()
             # (a) the seq512 shape with NOTHING to drop: every query 128 and every response 384 tokens long (no padding), same code path
             try:
                 dense_pool = [synth_pairs(d, args.pairs, q_len, t_len, seed=4242 + i, device=dev, dense=True) for i in range(args.accum)]
@@ -451,6 +460,8 @@ def main():
             # A/B against the collective-free step measured back to back on the same pool
             if args.model == "7b" and not dist.is_initialized():
                 try:
+                    eng.release()
+                    torch.cuda.empty_cache()
                     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                     os.environ.setdefault("MASTER_PORT", "29547")
                     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)

@@ -239,7 +239,10 @@ def test_p7_full_depth_32_layers_against_the_oracle(full):
            "path": "opadpo_ctx, packed ragged rows; policy = K-concatenated LoRA, reference = merged copy + SwiGLU-pair epilogue"}
     oracle_lp = {}
     with torch.no_grad():
-        for name, emu in (("fp32", False), ("emu_bf16", True)):
+        # OPADPO_P7_EMU=1 adds the bf16-emulating pass (+130 s of host time); its numbers of this round are committed in
+        # profiles/r03_parity_fulldepth.json (mean 2.48e-3 / p99 8.4e-3 from fp32 - the HIP path: 2.65e-3 / 1.0e-2)
+        passes = (("fp32", False), ("emu_bf16", True)) if os.environ.get("OPADPO_P7_EMU") == "1" else (("fp32", False),)
+        for name, emu in passes:
             t0 = time.time()
             lp, layers = _oracle_full_pass(LR, W, lora, od, images, queries, qmask, resp, emu)
             oracle_lp[name] = lp
@@ -259,11 +262,12 @@ def test_p7_full_depth_32_layers_against_the_oracle(full):
     for k in keys:
         valid = resp[k] != 0
         kk = k
-        for name, got, want in (("policy_vs_fp32", p_out[k + "_logprobs"], oracle_lp["fp32"][kk]),
-                                ("policy_vs_emu", p_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
-                                ("ref_merged_vs_fp32", r_out[k + "_logprobs"], oracle_lp["fp32"][kk]),
-                                ("ref_merged_vs_emu_unmerged", r_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
-                                ("oracle_emu_vs_fp32", oracle_lp["emu_bf16"][kk], oracle_lp["fp32"][kk])):
+        cmp_ = [("policy_vs_fp32", p_out[k + "_logprobs"], oracle_lp["fp32"][kk]), ("ref_merged_vs_fp32", r_out[k + "_logprobs"], oracle_lp["fp32"][kk])]
+        if "emu_bf16" in oracle_lp:
+            cmp_ += [("policy_vs_emu", p_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
+                     ("ref_merged_vs_emu_unmerged", r_out[k + "_logprobs"], oracle_lp["emu_bf16"][kk]),
+                     ("oracle_emu_vs_fp32", oracle_lp["emu_bf16"][kk], oracle_lp["fp32"][kk])]
+        for name, got, want in cmp_:
             assert bool((got[~valid] == 0).all()) and bool((want[~valid] == 0).all())            # exact zeros on pad cells (Quirk Q4)
             st = _stats(got, want, valid)
             rep[f"{name}_{k}"] = st
@@ -289,8 +293,8 @@ def test_p7_full_depth_32_layers_against_the_oracle(full):
     rep["seconds_hip_side"] = t_hip - t_start
     rep["bench_line"] = {"layers": d.n_layers, "pairs": B, "vs": "oracle/llava_ref.py fp32", "mean": worst["policy_vs_fp32"]["mean"],
                          "p99": worst["policy_vs_fp32"]["p99"], "max": worst["policy_vs_fp32"]["max"],
-                         "reference_pass": worst["ref_merged_vs_fp32"], "oracle_bf16_vs_fp32": worst["oracle_emu_vs_fp32"],
-                         "vs_bf16_oracle": worst["policy_vs_emu"], "logratio_equal_adapters_mean_abs": max(lr[k]["mean_abs"] for k in keys),
+                         "reference_pass": worst["ref_merged_vs_fp32"], "oracle_bf16_vs_fp32": worst.get("oracle_emu_vs_fp32"),
+                         "vs_bf16_oracle": worst.get("policy_vs_emu"), "logratio_equal_adapters_mean_abs": max(lr[k]["mean_abs"] for k in keys),
                          "north_star_tolerance": 1e-3}
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -300,8 +304,10 @@ def test_p7_full_depth_32_layers_against_the_oracle(full):
     ref_ad.merged = None
     torch.cuda.empty_cache()
     # the HIP path is a bf16 realisation of the oracle's function: never further from fp32 than 1.35 x the oracle's own bf16 emulation
-    for a, b in (("policy_vs_fp32", "oracle_emu_vs_fp32"), ("ref_merged_vs_fp32", "oracle_emu_vs_fp32")):
-        assert worst[a]["mean"] <= 1.35 * worst[b]["mean"] + 1e-4, (a, worst[a], worst[b])
-        assert worst[a]["p99"] <= 1.35 * worst[b]["p99"] + 5e-4, (a, worst[a], worst[b])
-    assert worst["policy_vs_fp32"]["mean"] < 1e-2 and worst["policy_vs_fp32"]["max"] < 0.1
+    # (measured in this run with OPADPO_P7_EMU=1, else the committed 32-layer figure of the same emulation: mean 2.48e-3, p99 8.4e-3)
+    floor = worst.get("oracle_emu_vs_fp32", {"mean": 2.48e-3, "p99": 8.4e-3})
+    for a in ("policy_vs_fp32", "ref_merged_vs_fp32"):
+        assert worst[a]["mean"] <= 1.35 * floor["mean"] + 1e-4, (a, worst[a], floor)
+        assert worst[a]["p99"] <= 1.35 * floor["p99"] + 5e-4, (a, worst[a], floor)
+    assert worst["policy_vs_fp32"]["max"] < 0.05
     assert max(rep["residual_drift_vs_fp32"]) < 5e-2
