@@ -114,6 +114,49 @@ def cpu_baseline_config_p(dims_kw, n_layers=1):
             "note": "directly timed, nothing extrapolated: vision tower once per image, decoder truncated to n_layers_run, head, DPO loss, LoRA backward"}
 
 
+class GpuSampler:
+    """Background sampler of the GPU's clock / power / temperature during a sustained run (--sustained): `rocm-smi --json` once per
+    `period` seconds (the sysfs hwmon nodes are not mounted in every container).  Host-side only; nothing touches the stream."""
+
+    def __init__(self, period=2.0, device=0):
+        import threading
+        self.period, self.device, self.samples, self._stop = period, device, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        t0 = time.time()
+        while not self._stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(self.device), "--showclocks", "--showpower", "--showtemp", "--json"],
+                                   capture_output=True, text=True, timeout=10)
+                js = json.loads(r.stdout)
+                card = next(iter(js.values()))
+                rec = {"t": time.time() - t0}
+                for k, v in card.items():
+                    kl = k.lower()
+                    if "sclk" in kl and "clock" in kl:
+                        rec["sclk_mhz"] = float(str(v).strip("()Mhz ").replace("Mhz", "") or 0)
+                    elif "mclk" in kl and "clock" in kl:
+                        rec["mclk_mhz"] = float(str(v).strip("()Mhz ").replace("Mhz", "") or 0)
+                    elif "power" in kl and "(w)" in kl:
+                        rec["power_w"] = float(v)
+                    elif "temperature" in kl and ("junction" in kl or "hotspot" in kl):
+                        rec["temp_c"] = float(v)
+                self.samples.append(rec)
+            except Exception as e:  # keep sampling; the record says what went wrong
+                self.samples.append({"t": time.time() - t0, "error": repr(e)[:120]})
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._th.join(timeout=15)
+
+
 def cpu_baseline(dims_kw, q_len, t_len):
     """Reported CPU baseline: the oracle (the parity-checked CPU restatement of the reference's forward, kind
     'port') on the host cores, on a bounded sample: ONE of the 32 decoder layers at 7B width, one pair =
@@ -250,6 +293,7 @@ def main():
     ap.add_argument("--op-level", action="store_true", help="sequence the kernels from Python (model.LlavaEngine) instead of the opadpo_ctx entry points")
     ap.add_argument("--ctx-flags", type=int, default=-1, help="opadpo_ctx_set_flags use_tr word for A/B runs (-1: defaults; bit 6: SwiGLU backward fused into the dgrad epilogue, bit 7: top decoder layer on every row)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the rollout (decode) sub-record")
+    ap.add_argument("--sustained", action="store_true", help="per-step stream time stamps + a background rocm-smi sampler (clock / power / temperature): the `sustained` record (config 2: --steps 220 = 4.8k pairs)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the dense-batch and exchange-overlap sub-records (measured after the timed region)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
@@ -354,15 +398,25 @@ def main():
     L.PROFILE = [] if rank == 0 else None               # vision / adapter-refresh GEMMs launched from Python (op-level wrapper)
     if rank == 0 and hasattr(eng, "profile"):
         eng.profile(True)                               # the LLM passes: launched inside opadpo_seq_logprobs_fwd / _bwd
+    sampler = GpuSampler(device=local) if (args.sustained and rank == 0) else None
+    step_ev = []
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
         loss = step()
+        if args.sustained:      # per-step time stamps on the stream (read after the run; nothing synchronises inside the timed region)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_ev.append(ev)
         if trace:      # diagnostics only (synchronises every step)
             torch.cuda.synchronize()
             print(f"[trace] step {step_no[0]}: {(time.perf_counter() - ts) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     sync()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
     prof, L.PROFILE = L.PROFILE, None
     ctx_prof = None
     if rank == 0 and hasattr(eng, "profile"):
@@ -427,6 +481,20 @@ def main():
                "mfma_roofline_frac_end_to_end": value / world * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12),
                "hbm_peak_allocated_GB": torch.cuda.max_memory_allocated() / 1e9,
                "roofline": roof}
+        if args.sustained and len(step_ev) > 1:
+            ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(len(step_ev) - 1)]      # step i+1's duration (event to event)
+            blk = 20
+            blocks = [sum(ms[i:i + blk]) / len(ms[i:i + blk]) for i in range(0, len(ms), blk)]
+            ok = [x for x in (sampler.samples if sampler else []) if "error" not in x]
+            def col(k):
+                v = [x[k] for x in ok if k in x]
+                return {"first": v[0], "last": v[-1], "min": min(v), "max": max(v), "mean": sum(v) / len(v)} if v else None
+            out["sustained"] = {"steps": args.steps, "pairs": args.steps * pairs_per_step,
+                                "pairs_per_s_first_20": pairs_per_step / world * 1e3 / (sum(ms[:blk]) / len(ms[:blk])),
+                                "pairs_per_s_last_20": pairs_per_step / world * 1e3 / (sum(ms[-blk:]) / len(ms[-blk:])),
+                                "ms_per_step_by_block_of_20": blocks, "sclk_mhz": col("sclk_mhz"), "power_w": col("power_w"), "temp_c": col("temp_c"),
+                                "samples": len(ok), "sample_errors": len(sampler.samples) - len(ok) if sampler else 0,
+                                "trace": ok[::max(1, len(ok) // 60)]}
         par = _parity_record()
         if par is not None and args.model == "7b":
             out["parity"] = par

@@ -133,15 +133,26 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
   constexpr int TB = 128 * ROWB, SB = 2 * TB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = GROUP_M * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0, n0;
+  if (p.quarter) {      // tail of a 256x256 launch: quarter (blockIdx & 3) of tile tile0 + (blockIdx >> 2) in THAT kernel's grouped order
+    const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
+    const int swz = p.tile0 + (blockIdx.x >> 2), q = blockIdx.x & 3;
+    const int width = p.group_m * tiles_n;
+    const int first_m = (swz / width) * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
+    m0 = (first_m + (swz % width) % gsz) * 256 + (q >> 1) * 128;
+    n0 = ((swz % width) / gsz) * 256 + (q & 1) * 128;
+    if (m0 >= p.M) return;                       // block-uniform: the lower half of a ragged last row tile may be empty
+  } else {
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int width = GROUP_M * tiles_n;
+    const int group_id = swz / width;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    m0 = (first_m + (swz % width) % gsz) * BM;
+    n0 = ((swz % width) / gsz) * BN;
+  }
   const int nt1 = p.K1 / BKX, nt2 = p.K2 / BKX, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
   if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
@@ -1813,8 +1824,26 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
     if (plain && g_gemm_variant != 17) {    // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
-      // a partly filled last round (<= 128 tiles) runs as 2 / 4 / 8 K-slices per tile + a reduce / epilogue launch (gemm_nt_tail_reduce_kernel)
       const int full = pp_tiles / 256 * 256, rem = pp_tiles - full, ntt = (a.K1 + a.K2) / P_BK;
+      // DEFAULT: a partly filled last round (<= 128 tiles) runs as QUARTER tiles on the 128x128 kernel - 4 blocks per 256x256 tile, each
+      // over the FULL K range in the same k order, so every element of C is bit-identical to what the 256x256 kernel writes and the
+      // result of a row does not depend on how many rows share the batch (the split-K tail below re-associates the fp32 sums of the tail
+      // tiles, and WHICH tiles are tail tiles depends on M).  Two 64-KiB blocks share a CU, <= 512 quarter blocks = at most one wave of them.
+      static const int tail_mode = getenv("OPADPO_TAIL_MODE") ? atoi(getenv("OPADPO_TAIL_MODE")) : 1;      // 0: none, 1: quarter tiles, 2: split-K (A/B)
+      // (a deep-K problem of <= 128 tiles - x . A_d^T: N = 256, K = 11008 - runs as quarter tiles entirely: 4x the blocks on a chip it
+      // would fill to a third; variant 31 = the 256x256 kernel on every tile, the bit-for-bit cross-check of the tests)
+      if (tail_mode == 1 && g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= 128 && !a.rope_cos) {
+        if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
+        GemmNTArgs t = a;
+        t.quarter = 1; t.tile0 = full;
+        hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
+        return hipGetLastError();
+      }
+      if (tail_mode != 2) {
+        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+        return hipGetLastError();
+      }
+      // OPADPO_TAIL_MODE=2 (A/B only): the tail as 2 / 4 / 8 K-slices per tile + a reduce / epilogue launch (gemm_nt_tail_reduce_kernel)
       int S = ((full == 0 && !deep_small) || rem == 0 || rem > 128 || a.ldc % 8 || (a.R && a.ldr % 8)) ? 1 : rem <= 32 ? 8 : rem <= 64 ? 4 : 2;
       while (S > 1 && ntt / S < 8) S >>= 1;
       if (S == 2 && ntt < 128 && full > 0) S = 1;        // two slices only pay on deep K (down, dgrads: 1.730 vs 1.772 ms); at K = 4352 the reduce pass eats the gain

@@ -31,6 +31,10 @@ struct GemmNTArgs {
   // fp32 partial tile to partial[(slot * ksplit + slice) * 65536]
   int ksplit = 0, tile0 = 0;
   float* partial = nullptr;
+  // quarter-tile tail launch of the 128x128 kernel (set by launch_gemm_nt only): block b computes quarter (b & 3) of the 256x256 tile
+  // tile0 + (b >> 2) of the 4-wave kernel's grouped tile order - the full K range, so every output element keeps the summation order
+  // it has inside a 256x256 tile (results do not depend on which tiles fall into the tail, i.e. on the row count of the batch)
+  int quarter = 0;
 };
 
 struct GemmTNArgs {

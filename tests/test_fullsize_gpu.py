@@ -5,8 +5,7 @@ the path (tolerances are bf16 noise levels measured against the oracle at 7B WID
   P1  layout invariance   packed ([prefix | chosen | rejected], prefix computed once) == stacked (the reference's two
                           sequences): per-token log-probs, entropies and LoRA gradients
   P2  mask placement      pad cells are exactly 0 (-0.0) in both layouts (Quirk Q4: downstream masks compare with 0)
-  P3  batch independence  a pair's log-probs do not depend on which other pairs share the micro-batch (to the fp32 summation
-                          order of the GEMM tail tiles: bf16 noise, no leakage)
+  P3  batch independence  a pair's log-probs do not depend on which other pairs share the micro-batch: BIT-equal
   P4  backward linearity  grad(2 * dlogp) == 2 * grad(dlogp) bit-for-bit up to fp32 accumulation order (atomics)
   P5  causality           changing a response token changes only log-probs at and after its position, and nothing of
                           the other response
@@ -85,17 +84,14 @@ def test_p3_batch_independence(full):
     s = full
     all3 = _run(s, True)
     one = _run(s, True, sel=slice(1, 2))
-    # Not bit-equal any more: which 256x256 tiles of a GEMM fall into the split-K tail depends on the row count of the batch, and a tile's
-    # fp32 summation order with it.  What this property pins is the ABSENCE OF LEAKAGE between sequences (masks, segment geometry,
-    # ragged row offsets): a leak moves log-probs by O(1); re-ordered fp32 sums feed different bf16 roundings through 32 layers - the
-    # noise level of two evaluation orders of the same math (P1's bound; measured here: mean rel 1.5e-3, worst cell 0.07).
-    for k, ids in (("chosen_response", s["p"]["chosen"][1:2]), ("rejected_response", s["p"]["rejected"][1:2])):
+    # BIT-equal (round 3 again): every output element of every GEMM is summed in the same k order whichever kernel / tile takes it (the
+    # tail of a partly filled round of 256x256 tiles runs as quarter tiles over the full K range; round 2's split-K tail re-associated the
+    # sums of the tail tiles, and which tiles are tail tiles depends on the batch's row count), attention and the row-wise kernels never
+    # mix sequences: a pair's log-probs do not depend on who shares its micro-batch.
+    for k in ("chosen_response", "rejected_response"):
         a, b = all3[k + "_logprobs"][1:2], one[k + "_logprobs"]
-        valid = ids != 0
-        assert bool((a[~valid] == 0).all()) and bool((b[~valid] == 0).all())
-        e = _meanrel(a, b, valid)
-        worst = float((a - b).abs()[valid].max())
-        assert e < 2.5e-3 and worst < 0.15, f"{k}: a pair's log-probs depend on its batch neighbours (mean rel {e}, max abs {worst})"
+        assert torch.equal(a, b), f"{k}: a pair's log-probs depend on its batch neighbours (max abs {float((a - b).abs().max())})"
+        assert torch.equal(all3[k + "_entropies"][1:2], one[k + "_entropies"])
 
 
 def test_p4_backward_is_linear_in_dlogp(full):

@@ -256,11 +256,16 @@ def test_gemm_nt_grouped_a1_split_k_tail(L):
     L.set_flags(10, True)
     want = torch.cat([2.0 * a[:, g * K:(g + 1) * K].float() @ b[g * r:(g + 1) * r].float().t() for g in range(G)], 1)
     assert relerr(out, want) < 3e-3 and relerr(small, want) < 3e-3
-    assert float((out.float() - small.float()).abs().max()) <= 2e-2 * float(want.abs().max())
+    assert torch.equal(out, small), "quarter-tile tail with grouped A1 != 128x128 kernel"
     x, w = rnd(M, 11008, seed=3), rnd(256, 11008, scale=0.05, seed=4)
     t = torch.empty(M, 256, dtype=BF, device=dev())
-    L.gemm_nt(x, w, t, alpha=0.5)
+    L.gemm_nt(x, w, t, alpha=0.5)                         # deep-K one-round problem: all quarter tiles
     assert relerr(t, 0.5 * (x.float() @ w.float().t())) < 3e-3
+    L.set_flags(31, True)
+    t2 = torch.empty_like(t)
+    L.gemm_nt(x, w, t2, alpha=0.5)
+    L.set_flags(10, True)
+    assert torch.equal(t, t2)
 
 
 @pytest.mark.parametrize("tr", [1, 9, 0, 13])      # 1 = default (256x256 stream-K kernel where both dims allow), 9 = 128x128 kernel, 13 = wide tiles
@@ -942,10 +947,10 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
 @pytest.mark.parametrize("R,K,r,mode", [(17, 4096, 0, "bf16"), (17, 4096, 256, "f32"), (18, 4096, 256, "bf16_res"), (19, 2048, 0, "f32_res"),
                                          (22, 1024, 256, "bf16"), (22, 4096, 0, "alpha"), (33, 4096, 256, "bf16")])
 def test_gemm_nt_split_k_tail(L, R, K, r, mode):
-    """A partly filled last round of 256x256 tiles (R row tiles x 16 column tiles: 272 / 288 / 304 / 352 / 528 tiles) runs as a split-K
-    tail (8 / 8 / 4 / 2 / 8 slices per tile) + gemm_nt_tail_reduce_kernel: every epilogue of the plain kernel (bf16 / fp32 out, bf16 /
-    fp32 residual, alpha, K-concatenated LoRA tail, ragged last row tile) against fp32 torch and against the 128x128 kernel (no split);
-    rows >= M untouched; repeated runs identical (slice order is fixed)."""
+    """A partly filled last round of 256x256 tiles (R row tiles x 16 column tiles: 272 / 288 / 304 / 352 / 528 tiles) runs as quarter
+    tiles on the 128x128 kernel (round 2: a split-K tail + reduce launch, now OPADPO_TAIL_MODE=2): every epilogue of the plain kernel
+    (bf16 / fp32 out, bf16 / fp32 residual, alpha, K-concatenated LoRA tail, ragged last row tile) against fp32 torch, and BIT-EQUAL to the
+    256x256 kernel on every tile and to the 128x128 kernel; rows >= M untouched."""
     L.set_flags(10, True)
     N, M = 4096, R * 256 - 100
     x, w = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
@@ -968,14 +973,19 @@ def test_gemm_nt_split_k_tail(L, R, K, r, mode):
     L.set_flags(4, True)
     small = torch.empty(M, N, dtype=out_dtype, device=dev())
     L.gemm_nt(x, w, small, **kw)
+    L.set_flags(31, True)                  # the 256x256 kernel on EVERY tile (no tail handling)
+    whole = torch.empty(M, N, dtype=out_dtype, device=dev())
+    L.gemm_nt(x, w, whole, **kw)
     L.set_flags(10, True)
     torch.cuda.synchronize()
     assert relerr(got[:M], want) < (3e-3 if out_dtype == BF else 2e-5 * (K ** 0.5))
     assert float((got[M:].float() - 7.0).abs().max()) == 0.0
     assert torch.equal(got[:M], again)
-    # same products, another summation order in the tail tiles: fp32 noise (then at most a bf16 rounding flip)
-    tol = 2e-2 if out_dtype == BF else 1e-3
-    assert float((got[:M].float() - small.float()).abs().max()) <= tol * float(want.abs().max())
+    # round 3: the tail of a partly filled last round runs as QUARTER tiles over the full K range (same k order per element), so the
+    # result is bit-identical to the 256x256 kernel on every tile AND to the 128x128 kernel - which tiles are tail tiles (a function of
+    # the batch's row count) cannot change a single bit of the output
+    assert torch.equal(got[:M], whole), "quarter-tile tail != 256x256 kernel on every tile"
+    assert torch.equal(got[:M], small), "256x256 dispatch != 128x128 kernel"
 
 
 @pytest.mark.parametrize("M,F,K,r", [(300, 256, 128, 64), (1000, 768, 256, 0), (257, 1536, 512, 256), (3, 256, 64, 64)])
