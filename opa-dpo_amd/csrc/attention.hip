@@ -20,6 +20,7 @@
 // LDS tiles are [64][HD] bf16 with a 16-byte-chunk XOR swizzle that is conflict-free for BOTH
 // access patterns (row fragments via ds_read_b128, transposed fragments via ds_read_b64_tr_b16):
 //   HD=128 (256-B rows): chunk ^= (row & 7) << 1      HD=64 (128-B rows): chunk ^= ((row >> 1) & 3) << 1
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -157,7 +158,7 @@ __device__ __forceinline__ void stage_mask(uint8_t* Ms, const uint8_t* key_mask,
     const uint8_t m = (kp < L) ? (key_mask ? key_mask[row0 + kp] : (uint8_t)1) : (uint8_t)0;
     Ms[tid] = m;
     const uint64_t dead = __ballot(m == 0);
-    if (tid == 0) Ms[64] = dead != 0;
+    if (tid == 0) { Ms[64] = dead != 0; *(uint64_t*)(Ms + 72) = ~dead; }      // Ms[72..79]: bit j = key j of the tile is a valid key
   }
 }
 
@@ -423,6 +424,235 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       *(uint2*)(op + d * 16 + g * 4) = v;
     }
     if (g == 0 && p.lse) p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, round 3 (head_dim 128): 32 q rows per wave on v_mfma_f32_32x32x16_bf16.
+//
+// The 16-row kernel above reads one 1-KiB LDS fragment per 16x16x32 MFMA (16 KFLOP): four SIMDs ask the CU's 128 B/clk LDS pipe for
+// twice what it delivers before the matrix pipes are busy (PMC r02: LDS pipe 70 % busy at 16-22 % MFMA).  Here a wave owns 32 q rows:
+//   S^T[key][q] = K . Q^T   A = K fragment (32 keys x 16 d, ds_read_b128 from the swizzled K tile), B = Q fragment in registers;
+//                           D: lane (q = lane & 31, hi = lane >> 5) holds keys kb*32 + 8b + 4hi + (0..3), b = 0..3  (16 values per kb)
+//   O^T[d][q] += V^T . P^T  A = V fragment (32 d x 16 keys) through two ds_read_b64_tr_b16 whose rows are EXACTLY the keys the lane's
+//                           S accumulators hold (rows r0 = kb*32 + 16 s + 4hi .. +3 and r0 + 8 .. +3): P goes from the S registers
+//                           through v_cvt_pk_bf16_f32 straight into the B operand - no cross-lane movement, no LDS round trip
+// so every fragment feeds 32 KFLOP (half the LDS bytes per FLOP), the row maximum needs ONE cross-lane exchange (lane <-> lane ^ 32)
+// instead of two, and scale * log2(e) is folded into the exponent's FMA.  Block = 4 waves = 128 q rows; K / V tiles of 64 keys in a
+// double-buffered LDS ring (register-staged: the global loads of tile t+1 fly under the MFMAs of tile t, their ds_writes go to the
+// other buffer - one barrier per tile); a wave skips the tiles none of its 32 rows can see (causal diagonal, other responses of a
+// packed row) but keeps the block's barriers.  O leaves through LDS as whole 256-byte rows.
+// V tile swizzle (32-byte slots): slot ^= ((row & 3) << 1) | ((row >> 2) & 1) - the two 16-lane groups of a half-wave read the SAME
+// four rows at adjacent 32-byte column blocks; this keeps their eight row segments on eight different slots.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ int vswz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }
+
+__device__ __forceinline__ void tile_commit_v(char* dst, const TileRegs<128>& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 4, c16 = idx & 15;
+    *(u32x4_t*)(dst + row * 256 + (((((c16 >> 1) ^ vswz(row)) << 1) | (c16 & 1)) << 4)) = r.v[i];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HD = 128, TILE = 64 * HD * 2;            // 16 KiB per K or V tile; ring: [K0 | V0 | K1 | V1]
+  uint8_t* const ms_base = (uint8_t*)(smem + 4 * TILE);  // 2 x 80 mask bytes
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int n_qt = (p.L + 127) / 128;
+  int s, h, qi;
+  attn_block_map(p, n_qt, qi, h, s);
+  const int qt = n_qt - 1 - qi;                           // heavier (later) causal tiles first
+  const int q0 = qt * 128;
+  const Geo ge = load_geo(p, s);
+  const int L = ge.L;
+  if (q0 >= L) return;
+  // all-padding q tile (OPADPO_ATTN_SKIP_MASKED_Q): zeros, as the 16-row kernel
+  if ((p.causal & 2) && p.key_mask) {
+    const int a_ = q0 + lane, b_ = q0 + 64 + lane;
+    const uint8_t m0 = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0, m1 = b_ < L ? p.key_mask[ge.row0 + b_] : (uint8_t)0;
+    if (__ballot((m0 | m1) != 0) == 0) {
+      for (int i = tid; i < 128 * 16; i += 256) {
+        const int row = q0 + (i >> 4);
+        if (row < L) *(uint4*)(p.o + (ge.row0 + row) * p.ldo + h * HD + (i & 15) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (tid < 128 && q0 + tid < L && p.lse) p.lse[stat_idx(p, ge, s, h, q0 + tid)] = NEG_BIG;
+      return;
+    }
+  }
+  const int qlo = q0 + w * 32, qhi = min(qlo + 31, L - 1);            // this wave's rows
+  const bool wave_live = qlo < L;
+  const int qpos = qlo + ql;
+  const int qrow = min(qpos, L - 1);
+
+  bf16x8_t qf[8];
+  {
+    const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const uint4 v = *(const uint4*)(qp + ks * 16);
+      qf[ks] = *(const bf16x8_t*)&v;
+    }
+  }
+  f32x16_t o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;                     // m in RAW score units; scale2 enters in the exponent's FMA
+
+  const int n_kt = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
+  const SegSkip sk(ge, q0, n_kt);
+  const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
+  const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;      // excluded key range [xlo, .) of the wave's first / last row
+  const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
+  const float scale2 = p.scale * 1.4426950408889634f;
+  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
+  TileRegs<HD> kreg, vreg;
+  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
+  tile_commit<HD>(smem, kreg, tid);
+  tile_commit_v(smem + TILE, vreg, tid);
+  stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
+  int cur = 0;
+  const int krow_off = ql * 256;                          // K fragment: row kb*32 + ql, 16-byte chunk ks*2 + hi, swizzle (row & 7) << 1
+  const int kswz = (ql & 7) << 1;
+  const int a4 = lane & 15, vgrp = (lane >> 4) & 1;       // V fragment (transpose read): lane a of a 16-lane group addresses row a >> 2, columns (a & 3) * 4
+  for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
+    nxt = sk.next(kt);
+    const int k0 = kt * 64;
+    const char* const Ks = smem + cur * 2 * TILE;
+    const char* const Vs = Ks + TILE;
+    const uint8_t* const Ms = ms_base + cur * 80;
+    __syncthreads();                                      // tile kt is in LDS for everyone; everyone has left the other buffer
+    if (nxt < n_kt) {
+      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
+    }
+    // tiles none of this wave's rows can see: beyond its causal diagonal, or wholly inside the responses its rows exclude
+    const bool dead = !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first);
+    if (!dead) {
+      f32x16_t sc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+        }
+      }
+      // sc[kb][r] = S^T[key = k0 + kb*32 + 8*(r >> 2) + 4*hi + (r & 3)][q = qpos], raw (unscaled) scores
+      const bool clean = !Ms[64] && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
+      float mx = -INFINITY;
+      if (clean) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      } else {
+        // the lane's 64 visibility bits of this tile, built ONCE (key mask of the tile & causal limit of the row & not inside a response
+        // the row excludes), shifted so that the lane's key kb*32 + 8b + 4hi + e sits at the compile-time bit kb*32 + 8b + e: three
+        // VALU per score (and / compare / select) instead of eleven
+        uint64_t vis = *(const uint64_t*)(Ms + 72);
+        if (p.causal) {
+          const int lim = qpos - k0;                      // keys 0..lim of the tile are at or before the row
+          vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
+        }
+        {
+          const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi - k0, 0), 64);      // excluded keys [lo, hx) of the tile (empty without segments: xlo = INT_MAX)
+          if (hx > lo) {
+            const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+            vis &= ~(below_hx & ~below_lo);
+          }
+        }
+        vis >>= 4 * hi;
+        const uint32_t vw[2] = {(uint32_t)vis, (uint32_t)(vis >> 32)};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = (vw[kb] & (1u << (8 * (r >> 2) + (r & 3)))) ? sc[kb][r] : -INFINITY;
+            sc[kb][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other 32 keys of the tile for this q row
+      const float m_new = fmaxf(m_run, mx);
+      if (__ballot(m_new != m_run)) {                     // lazy rescale: the running maximum settles after a few tiles
+        const float alpha = fast_exp2((m_run - m_new) * scale2);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m_run = m_new;
+      }
+      const float mb = -m_new * scale2;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(__builtin_fmaf(sc[kb][r], scale2, mb));      // exp2(-inf) = 0 for masked scores (m stays finite: NEG_BIG floor)
+          sc[kb][r] = pv;
+          psum += pv;
+        }
+      l_run += psum;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { bf16x8_t v; uint32_t u[4]; } pf;
+          pf.u[0] = pack_bf2(sc[kb][8 * s2 + 0], sc[kb][8 * s2 + 1]); pf.u[1] = pack_bf2(sc[kb][8 * s2 + 2], sc[kb][8 * s2 + 3]);
+          pf.u[2] = pack_bf2(sc[kb][8 * s2 + 4], sc[kb][8 * s2 + 5]); pf.u[3] = pack_bf2(sc[kb][8 * s2 + 6], sc[kb][8 * s2 + 7]);
+          const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;      // 16-byte chunk of column db*32 + vgrp*16 + (a & 3)*4, byte inside it
+            union { bf16x8_t v; s16x4_t hh[2]; } vf;
+            vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r0 * 256 + (((((c16 >> 1) ^ vswz(r0)) << 1) | (c16 & 1)) << 4) + sub));
+            vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r1 * 256 + (((((c16 >> 1) ^ vswz(r1)) << 1) | (c16 & 1)) << 4) + sub));
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+          }
+        }
+    }
+    if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
+      char* const nb = smem + (cur ^ 1) * 2 * TILE;
+      tile_commit<HD>(nb, kreg, tid);
+      tile_commit_v(nb + TILE, vreg, tid);
+      stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
+    }
+    cur ^= 1;
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();                                        // every wave has left the ring: it becomes the O staging area
+  // O^T[d][q]: lane (q, hi) holds d = db*32 + 8b + 4hi + (0..3).  Through LDS as bf16 rows ([32][128] per wave, 16-byte chunks XOR
+  // (row & 15)) and out as whole 256-byte rows.
+  char* const stg = smem + w * 8192;
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      uint2 v;
+      v.x = pack_bf2(o[db][b * 4 + 0] * inv, o[db][b * 4 + 1] * inv);
+      v.y = pack_bf2(o[db][b * 4 + 2] * inv, o[db][b * 4 + 3] * inv);
+      const int d = db * 32 + b * 8 + hi * 4;             // first of the lane's 4 consecutive columns
+      *(uint2*)(stg + ql * 256 + ((((d >> 3) ^ (ql & 15))) << 4) + (d & 7) * 2) = v;
+    }
+  if (hi == 0 && qpos < L && p.lse) p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run * scale2 + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own rows only: no barrier needed
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), c16 = lane & 15;
+    const uint4 v = *(const uint4*)(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
+    if (qlo + row < L) *(uint4*)(p.o + (ge.row0 + qlo + row) * p.ldo + h * HD + c16 * 8) = v;
   }
 }
 
@@ -777,9 +1007,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 static bool g_attn_dma = false;   // measured: the 64-KiB ring allows 2 blocks/CU, the 32-KiB register-staged kernel 3 -> 0.92 vs 1.01 ms
 void opadpo_set_attn_dma(bool on) { g_attn_dma = on; }
 
+static int g_attn32 = -1;         // 1 (default): head_dim-128 forward on the 32-rows-per-wave kernel; OPADPO_ATTN32=0 keeps the 16-row kernel (A/B)
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
+  if (g_attn32 < 0) { const char* v = getenv("OPADPO_ATTN32"); g_attn32 = (v && v[0] == '0') ? 0 : 1; }
+  const bool legacy = a.use_tr >= 0 && (a.use_tr & 256);      // per-call: context flag bit 8 = the 16-row forward kernel
+  if (a.hd == 128 && g_attn32 && !legacy && (double)a.L * a.ld * 2 < 2.0e9) {
+    static bool attr32 = false;
+    if (!attr32) { (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160); attr32 = true; }
+    const dim3 grid32((unsigned)(((a.L + 127) / 128) * a.nh * a.S));
+    hipLaunchKernelGGL(attn_fwd32_kernel, grid32, dim3(256), 4 * 64 * 128 * 2 + 160, st, a);
+    return hipGetLastError();
+  }
   const dim3 grid((unsigned)(((a.L + 63) / 64) * a.nh * a.S));
   const bool tr = a.use_tr >= 0 ? (a.use_tr & 1) != 0 : opadpo_flag_tr();
   const bool dma = g_attn_dma && (double)a.L * a.ld * 2 < 2.0e9;     // per-sequence extent must fit the 32-bit descriptor

@@ -323,6 +323,7 @@ def test_peaked_distributions_on_policy_responses():
             r["near0_abs_emu_vs_fp32"] = {"mean": float((wem - w32).abs()[near0].mean()), "max": float((wem - w32).abs()[near0].max())}
         r["all_abs_emu_vs_fp32"] = {"mean": float((wem - w32).abs()[body].mean()), "max": float((wem - w32).abs()[body].max())}
         r["entropy_maxabs_vs_fp32"] = float((out[k + "_entropies"] - o32[k + "_entropies"]).abs()[body].max())
+        r["entropy_maxabs_emu_vs_fp32"] = float((oem[k + "_entropies"] - o32[k + "_entropies"]).abs()[body].max())
         rec[k] = r
     REPORT["peaked_on_policy_T0.1"] = rec
     _dump()
@@ -332,13 +333,15 @@ def test_peaked_distributions_on_policy_responses():
     assert g_["near0_tokens"] > 0.5 * g_["tokens"] and g_["logp_max"] > -0.05, g_
     assert s_["logp_min"] < -3.0, s_
     for k, r in rec.items():
-        # absolute error of the bf16 pipeline on logits of magnitude ~50 (temperature 0.1): held to 1.5 x the oracle's own bf16 emulation
-        # (+ 2e-3) on the mean and capped at 0.25 nat on the worst token; near 0 the same bound in absolute terms
+        # At temperature 0.1 every logit is multiplied by 10, and so is its bf16 noise: the oracle's OWN bf16 emulation sits 0.05-0.08 nat
+        # (mean) and 0.4-1.0 nat (worst token) from fp32 here (measured: chosen 0.057 / 0.44, rejected 0.082 / 0.99; HIP 0.055 / 0.49 and
+        # 0.072 / 0.79).  The HIP path is held to 1.5 x that emulation - on all tokens, on the near-0 tokens in ABSOLUTE terms, worst token,
+        # entropy - i.e. it is a bf16 realisation of the oracle's function in this regime too, no kernel-specific loss at large margins.
         assert r["all_abs_vs_fp32"]["mean"] <= 1.5 * r["all_abs_emu_vs_fp32"]["mean"] + 2e-3, (k, r)
-        assert r["all_abs_vs_fp32"]["max"] < 0.25, (k, r)
+        assert r["all_abs_vs_fp32"]["max"] <= 1.5 * r["all_abs_emu_vs_fp32"]["max"] + 5e-2, (k, r)
         if "near0_abs_vs_fp32" in r:
             assert r["near0_abs_vs_fp32"]["mean"] <= 1.5 * r["near0_abs_emu_vs_fp32"]["mean"] + 2e-3, (k, r)
-        assert r["entropy_maxabs_vs_fp32"] < 0.3, (k, r)
+        assert r["entropy_maxabs_vs_fp32"] <= 1.5 * r["entropy_maxabs_emu_vs_fp32"] + 5e-2, (k, r)
     eng.release()
     del eng
     torch.cuda.empty_cache()

@@ -314,7 +314,10 @@ def ref_attention(q, k, v, key_mask, causal, scale, seg=(0, 0)):
 
 @pytest.mark.parametrize("tr", [1, 0, 3])      # 3 = transposed reads + direct-to-LDS double-buffered forward
 @pytest.mark.parametrize("S,Ln,nh,hd,causal,masked", [(2, 200, 2, 128, 1, True), (1, 64, 1, 128, 1, False),
-                                                       (2, 77, 2, 64, 0, False), (1, 300, 1, 64, 1, True)])
+                                                       (2, 77, 2, 64, 0, False), (1, 300, 1, 64, 1, True),
+                                                       # several 128-row blocks / many K-V tiles of the 32-rows-per-wave kernel, ragged ends
+                                                       (2, 517, 2, 128, 1, True), (1, 1087, 4, 128, 1, False), (2, 333, 2, 128, 0, True),
+                                                       (1, 129, 1, 128, 1, True), (3, 31, 1, 128, 1, False)])
 def test_attn_fwd(L, tr, S, Ln, nh, hd, causal, masked):
     L.set_flags(True, tr)
     H = nh * hd
@@ -338,10 +341,20 @@ def test_attn_fwd(L, tr, S, Ln, nh, hd, causal, masked):
     e = maxabs(o, want)
     assert e < 3e-2, f"attn_fwd max abs err {e} (|o| ~ {float(want.abs().max()):.2f})"
     assert relerr(o, want) < 1e-2
+    # log-sum-exp (the backward's softmax statistics) against torch, on rows with at least one visible key
+    sc = torch.einsum("sqhd,skhd->shqk", q4, k4) * hd ** -0.5
+    allow = torch.ones(S, 1, Ln, Ln, dtype=torch.bool, device=dev())
+    if causal:
+        allow = allow & torch.tril(torch.ones(Ln, Ln, dtype=torch.bool, device=dev()))[None, None]
+    if km is not None:
+        allow = allow & km.bool()[:, None, None, :]
+    want_lse = torch.logsumexp(sc.masked_fill(~allow, float("-inf")), -1)
+    okr = allow.any(-1).expand(S, nh, Ln)
+    assert float((lse - want_lse)[okr].abs().max()) < 2e-2
 
 
 @pytest.mark.parametrize("tr", [1, 0])
-@pytest.mark.parametrize("S,Ln,nh,hd,masked", [(2, 150, 2, 128, True), (1, 64, 1, 128, False), (1, 200, 2, 64, True)])
+@pytest.mark.parametrize("S,Ln,nh,hd,masked", [(2, 150, 2, 128, True), (1, 64, 1, 128, False), (1, 200, 2, 64, True), (2, 413, 2, 128, True)])
 def test_attn_bwd(L, tr, S, Ln, nh, hd, masked):
     L.set_flags(True, bool(tr))
     H = nh * hd
