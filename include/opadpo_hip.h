@@ -276,7 +276,10 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
  * bit 6 = SwiGLU backward in the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD; default: its own launch, which
  * measured 0.35 % faster per step); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only
- * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest) */
+ * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest);
+ * bit 8 = the 16-rows-per-wave attention forward (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
+ * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
+ * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked from 256 MiB of fp32 logits) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);
@@ -311,7 +314,8 @@ int opadpo_vision_encode(opadpo_ctx* ctx, const uint16_t* pixels, int B, uint16_
  * row_plan (HOST memory, nullable): int32 [S][K+1] = per row the number of LEADING masked query positions to drop and the valid
  * length of every response (positions behind it are padding).  When given, the pass runs on RAGGED rows: padding positions are not
  * rows of any GEMM / norm / SwiGLU / RoPE / attention tile (the reference computes them and throws the result away: 24 % of the rows
- * of a synthetic seq512 pair), outputs on valid tokens are unchanged, pad cells still read -0.0 / 0.  NULL = the padded layout. */
+ * of a synthetic seq512 pair), outputs on valid tokens are unchanged, pad cells still read -0.0 / 0.  NULL = the padded layout.  Any S
+ * and K (the per-sequence geometry travels to the device in as many 960-int kernel-argument blocks as it needs). */
 int opadpo_seq_logprobs_fwd(opadpo_ctx* ctx, int adapter_id, const int32_t* ids, const uint8_t* text_mask, const int32_t* feat_row,
                             const uint8_t* image_mask, const uint16_t* feats, int S, int n_txt, int T, int K, float temperature, int train,
                             float* logp, float* ent, opadpo_saved** saved, const int32_t* row_plan, void* stream);

@@ -485,7 +485,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     }
   }
   const int qlo = q0 + w * 32, qhi = min(qlo + 31, L - 1);            // this wave's rows
-  const bool wave_live = qlo < L;
+  bool wave_live = qlo < L, wave_pad = false;
+  if ((p.causal & 2) && p.key_mask && wave_live) {                    // 32 rows that are all masked as keys are padding too: zeros (o = 0, l = 0 below)
+    const int a_ = qlo + ql;
+    const uint8_t mq = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0;
+    wave_live = __ballot(mq != 0) != 0;
+    wave_pad = !wave_live;
+  }
   const int qpos = qlo + ql;
   const int qrow = min(qpos, L - 1);
 
@@ -593,17 +599,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         m_run = m_new;
       }
-      const float mb = -m_new * scale2;
-      float psum = 0.f;
+      // exponent arguments and row sums two values per instruction (v_pk_fma_f32 / v_pk_add_f32: full rate on CDNA3+); the exp itself
+      // is one quarter-rate v_exp_f32 per score.  exp2(-inf) = 0 for masked scores (m stays finite: NEG_BIG floor)
+      typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
+      const f32x2v_t sc2 = {scale2, scale2}, mb2 = {-m_new * scale2, -m_new * scale2};
+      f32x2v_t ps2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = fast_exp2(__builtin_fmaf(sc[kb][r], scale2, mb));      // exp2(-inf) = 0 for masked scores (m stays finite: NEG_BIG floor)
-          sc[kb][r] = pv;
-          psum += pv;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2v_t a = __builtin_elementwise_fma(f32x2v_t{sc[kb][r], sc[kb][r + 1]}, sc2, mb2);
+          const f32x2v_t e = {fast_exp2(a[0]), fast_exp2(a[1])};
+          sc[kb][r] = e[0]; sc[kb][r + 1] = e[1];
+          ps2 += e;
         }
-      l_run += psum;
+      l_run += ps2[0] + ps2[1];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -646,7 +656,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       const int d = db * 32 + b * 8 + hi * 4;             // first of the lane's 4 consecutive columns
       *(uint2*)(stg + ql * 256 + ((((d >> 3) ^ (ql & 15))) << 4) + (d & 7) * 2) = v;
     }
-  if (hi == 0 && qpos < L && p.lse) p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run * scale2 + log2f(l_run)) * 0.6931471805599453f : NEG_BIG;
+  // rows of a skipped 32-row group sit inside q tiles the backward still walks (its skip granularity is 64 rows): their log-sum-exp is
+  // +BIG so that the recomputed P = exp(s - lse) is exactly 0 there (NEG_BIG would give inf * 0 on the clean-tile path)
+  if (hi == 0 && qpos < L && p.lse)
+    p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run * scale2 + log2f(l_run)) * 0.6931471805599453f : (wave_pad ? -NEG_BIG : NEG_BIG);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own rows only: no barrier needed
 #pragma unroll
   for (int it = 0; it < 8; ++it) {

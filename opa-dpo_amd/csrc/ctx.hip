@@ -206,6 +206,9 @@ struct opadpo_saved {
   uint8_t* key_mask; float* hs; bf16_t* hn; float* rstd_f; float* logits; float* lse_head; float* ent;
   int32_t *rows, *labels;
   int Rc = 0;                       // head rows actually computed: R (padded layout) or the number of valid response cells (ragged)
+  int head_chunk = 0;               // > 0: chunked head - the lm_head GEMM, the online log-sum-exp and (backward) the recomputed logits run over
+                                    // `head_chunk` vocabulary columns at a time; `logits` is [R, head_chunk], nothing of size [R, vocab] exists
+  float *h_s = nullptr, *h_zl = nullptr;      // chunked head: running sum exp / label logit (running max -> lse_head, sum z exp -> ent)
   int32_t* cell = nullptr; float* logp_c = nullptr;      // ragged: flat [K,S,T] index of every compact head row; compact log-probs
   int Uc = 0;                       // > 0: compact last layer - rows of the top layer's o-projection / MLP (head_index_ragged_kernel)
   int32_t* urow = nullptr; bf16_t* attn_u = nullptr;     // U list; attention output gathered on U (saved for the o-projection wgrads)
@@ -535,7 +538,9 @@ size_t saved_layout(const opadpo_dims& d, opadpo_saved* sv, void* base) {
   sv->hs = cv.take<float>(R * H);
   sv->hn = cv.take<bf16_t>(R * H);
   sv->rstd_f = cv.take<float>(R);
-  sv->logits = cv.take<float>(R * (size_t)std::max(d.vocab, d.hidden));      // also parks the head rows of the deferred branch product ([R,H]) before the lm_head GEMM writes it
+  sv->logits = cv.take<float>(R * (size_t)std::max(sv->head_chunk > 0 ? sv->head_chunk : d.vocab, d.hidden));      // also parks the head rows of the deferred branch product ([R,H]) before the lm_head GEMM writes it
+  sv->h_s = cv.take<float>(sv->head_chunk > 0 ? R : 1);
+  sv->h_zl = cv.take<float>(sv->head_chunk > 0 ? R : 1);
   sv->lse_head = cv.take<float>(R);
   sv->ent = cv.take<float>(R);
   sv->rows = cv.take<int32_t>(R);
@@ -810,6 +815,13 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   } else {
     sv->Rc = sv->R;
   }
+  // chunked head: automatically from 256 MiB of fp32 logits (the benchmark's 22 pairs: 1.2 GB -> 0.15 GB; 13B, K = 3 or T = 896 recipes
+  // scale that buffer with every valid token); context flag (use_tr) bit 9 forces it for any size, bit 10 switches it off
+  {
+    const int ut = c->use_tr >= 0 ? c->use_tr : 0;
+    const bool want = (ut & 512) || (!(ut & 1024) && (size_t)std::max(sv->Rc, 1) * d.vocab * sizeof(float) >= ((size_t)256 << 20));
+    sv->head_chunk = (want && d.vocab > 4096) ? 4096 : 0;
+  }
   sv->bytes = saved_layout(d, sv, nullptr);
   // ragged batches differ in size: ask for the largest arena seen so far for this kind of pass, so that the allocator hands the
   // same block back every time instead of growing (and fragmenting) its pool
@@ -873,9 +885,24 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
   CKS(launch_gather_rows((const bf16_t*)Y, 2 * H, sv->rows, (bf16_t*)sv->logits, R, 2 * H, st));
   CKS(launch_rmsnorm_sum_fwd(sv->hs, 1, sv->logits, 1, (size_t)R * H, c->norm, sv->hs, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
-  { GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head, H, H, sv->logits, d.vocab, 1, R, d.vocab); CKS(run_gemm(c, g, st)); }
+  float* const head_logp = rg ? sv->logp_c : logp;
+  if (sv->head_chunk > 0) {
+    // lm_head + online log-sum-exp + label gather + entropy, one vocabulary chunk at a time (rl_models.py:121-132, common_utils.py:112-118):
+    // running max in lse_head, sum z exp(z - m) in ent, sum exp in h_s, label logit in h_zl; the finish kernel turns them into the outputs
+    const int VC = sv->head_chunk;
+    for (int c0 = 0; c0 < d.vocab; c0 += VC) {
+      const int n = std::min(VC, d.vocab - c0);
+      GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head + (size_t)c0 * H, H, H, sv->logits, VC, 1, R, n);
+      CKS(run_gemm(c, g, st));
+      CKS(launch_head_fwd_chunk(sv->logits, VC, sv->labels, 1.0f / temperature, c0, n, c0 == 0, sv->lse_head, sv->h_s, sv->ent, sv->h_zl, R, st));
+    }
+    CKS(launch_head_fwd_finish(sv->labels, sv->lse_head, sv->h_s, sv->ent, sv->h_zl, head_logp, sv->ent, sv->lse_head, R, st));
+  } else {
+    GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head, H, H, sv->logits, d.vocab, 1, R, d.vocab);
+    CKS(run_gemm(c, g, st));
+    CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, head_logp, sv->ent, sv->lse_head, R, d.vocab, st));
+  }
   if (rg) {       // compact head rows -> the rectangular outputs (padding cells: -0.0 / 0, Quirk Q4)
-    CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, sv->logp_c, sv->ent, sv->lse_head, R, d.vocab, st));
     hipLaunchKernelGGL(fill_f32_kernel, g1(Rall), dim3(256), 0, st, logp, -0.0f, ent, 0.0f, Rall);
     CKS(hipGetLastError());
     if (R > 0) {
@@ -883,7 +910,6 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
       CKS(hipGetLastError());
     }
   } else {
-    CKS(launch_head_fwd(sv->logits, d.vocab, sv->labels, 1.0f / temperature, logp, sv->ent, sv->lse_head, R, d.vocab, st));
     CKS(hipMemcpyAsync(ent, sv->ent, (size_t)R * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
 #undef CKS
@@ -931,7 +957,9 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   const size_t MH = (size_t)M * H;
   // workspace (persists between the ranged calls of one backward)
   size_t need = 0;
-  { Carve cv(nullptr); cv.take<bf16_t>((size_t)R * V); cv.take<bf16_t>((size_t)R * H); cv.take<float>((size_t)R * H); cv.take<float>(MH); cv.take<bf16_t>(MH);
+  const int VC = sv->head_chunk;                      // chunked head: dz and the recomputed logits exist for one vocabulary chunk at a time
+  const size_t dz_cols = VC > 0 ? (size_t)VC : (size_t)V;
+  { Carve cv(nullptr); cv.take<bf16_t>((size_t)R * dz_cols); cv.take<float>(VC > 0 ? (size_t)R * H : 1); cv.take<bf16_t>((size_t)R * H); cv.take<float>((size_t)R * H); cv.take<float>(MH); cv.take<bf16_t>(MH);
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
     cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); need = cv.off; }
@@ -941,7 +969,8 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   void* base = ctx_ws(c, need, st);
   if (!base) return cfail(c, hipErrorOutOfMemory, __func__);
   Carve cv(base);
-  bf16_t* dz = cv.take<bf16_t>((size_t)R * V); bf16_t* d_hn = cv.take<bf16_t>((size_t)R * H); float* d_hs = cv.take<float>((size_t)R * H);
+  bf16_t* dz = cv.take<bf16_t>((size_t)R * dz_cols); float* d_hn32 = cv.take<float>(VC > 0 ? (size_t)R * H : 1);
+  bf16_t* d_hn = cv.take<bf16_t>((size_t)R * H); float* d_hs = cv.take<float>((size_t)R * H);
   float* dX = cv.take<float>(MH); bf16_t* dXb = cv.take<bf16_t>(MH); float* d_h = cv.take<float>(MH); bf16_t* d_hb = cv.take<bf16_t>(MH);
   bf16_t* d_n = cv.take<bf16_t>(MH); bf16_t* d_act = cv.take<bf16_t>((size_t)M * F); bf16_t* d_gu = cv.take<bf16_t>((size_t)M * 2 * F);
   bf16_t* d_attn = cv.take<bf16_t>(MH); bf16_t* dqkv = cv.take<bf16_t>((size_t)M * 3 * H); float* delta = cv.take<float>((size_t)S * nh * Lp);
@@ -957,8 +986,23 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
       CK(hipGetLastError());
       dlogp = dl_c; if (dent) dent = de_c;
     }
-    CK(launch_head_bwd(sv->logits, V, sv->labels, sv->lse_head, dlogp, dent ? sv->ent : nullptr, dent, 1.0f / sv->temperature, dz, V, R, V, st));
-    { GemmNTArgs g = gemm(c, dz, V, c->lm_head_t, V, V, d_hn, H, 0, R, H); CK(run_gemm(c, g, st)); }
+    if (VC > 0) {
+      // per vocabulary chunk: recompute the logits (hn . W_c^T), dz_c from the row statistics of the forward, d_hn += dz_c . W_c (fp32
+      // accumulation across the chunks, ONE rounding to bf16 at the end - what the single K = vocab GEMM does inside its accumulators)
+      for (int c0 = 0; c0 < V; c0 += VC) {
+        const int n = std::min(VC, V - c0);
+        { GemmNTArgs g = gemm(c, sv->hn, H, c->lm_head + (size_t)c0 * H, H, H, sv->logits, VC, 1, R, n); CK(run_gemm(c, g, st)); }
+        CK(launch_head_bwd(sv->logits, VC, sv->labels, sv->lse_head, dlogp, dent ? sv->ent : nullptr, dent, 1.0f / sv->temperature, dz, VC, R, n, st, c0));
+        GemmNTArgs g = gemm(c, dz, VC, c->lm_head_t + c0, V, n, d_hn32, H, 1, R, H);
+        if (c0 > 0) resid(g, d_hn32, H, 1);
+        CK(run_gemm(c, g, st));
+      }
+      CK(launch_f32_to_bf16(d_hn32, d_hn, (size_t)R * H, st));
+    } else {
+      CK(launch_head_bwd(sv->logits, V, sv->labels, sv->lse_head, dlogp, dent ? sv->ent : nullptr, dent, 1.0f / sv->temperature, dz, V, R, V, st));
+      GemmNTArgs g = gemm(c, dz, V, c->lm_head_t, V, V, d_hn, H, 0, R, H);
+      CK(run_gemm(c, g, st));
+    }
     CK(launch_rmsnorm_bwd(d_hn, sv->hs, 1, c->norm, sv->rstd_f, nullptr, 0, d_hs, nullptr, R, H, st));
     CK(hipMemsetAsync(dX, 0, MH * sizeof(float), st));
     if (sv->K > 1 || sv->ragged) CK(launch_scatter_add_rows_f32(d_hs, sv->rows, dX, H, R, H, st));     // rows repeat: the last prefix row feeds token 0 of every response (ragged: compact head rows; with the compact top layer `rows` index the U rows that dX holds for that layer)

@@ -127,7 +127,13 @@ hipError_t launch_head_fwd(const float* logits, int ldl, const int32_t* labels, 
                            float* lse, int rows, int V, hipStream_t st);
 hipError_t launch_head_bwd(const float* logits, int ldl, const int32_t* labels, const float* lse, const float* dlogp,
                            const float* ent, const float* dent,
-                           float inv_temp, bf16_t* dz, int ldz, int rows, int V, hipStream_t st);
+                           float inv_temp, bf16_t* dz, int ldz, int rows, int V, hipStream_t st, int col0 = 0);
+// chunked head (no [rows, vocab] buffer): fold the logits of vocabulary columns [col0, col0 + n) into the running (max, sum exp, sum z exp,
+// label logit) of every row; finish -> log-prob, entropy, log-sum-exp
+hipError_t launch_head_fwd_chunk(const float* logits, int ldl, const int32_t* labels, float inv_temp, int col0, int n, int first, float* m,
+                                 float* s, float* t, float* zl, int rows, hipStream_t st);
+hipError_t launch_head_fwd_finish(const int32_t* labels, const float* m, const float* s, const float* t, const float* zl, float* logp, float* ent,
+                                  float* lse, int rows, hipStream_t st);
 
 hipError_t launch_sumsq(const float* g, size_t n, float* out, hipStream_t st);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,

@@ -162,6 +162,7 @@ def test_wide_7b_forward_is_bit_identical():
                   image_size=56, patch=14)
     base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
     op, cx = LlavaEngine(base), CtxEngine(base, ragged=False)
+    cx.set_flags(use_tr=1 | 1024)          # bit 10: the un-chunked head (one [rows, vocab] logits buffer), what the op-level sequencing runs
     ad = LoraAdapter(d, init_lora(d, seed=1, device=dev), dev, True)
     p = synth_pairs(d, 6, 128, 384, seed=7, device=dev)
     g = torch.Generator().manual_seed(1)
@@ -177,13 +178,27 @@ def test_wide_7b_forward_is_bit_identical():
     assert float((res[0][2] - res[1][2]).norm() / res[0][2].norm()) < 1e-5
     # opt-in flag bit 6: SwiGLU backward inside the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD) - same bits
     # into the wgrads, so the gradient differs from the two-kernel form only by the order of the fp32 atomics
-    cx.set_flags(use_tr=1 | 64)
+    cx.set_flags(use_tr=1 | 64 | 1024)
     ad.grad.zero_()
     out = _policy(cx, ad, 384, True)(**_kw(p, cx))
     sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
     torch.cuda.synchronize()
     assert torch.equal(out["chosen_response_logprobs"].detach(), res[1][0])
     assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-5
+    # CHUNKED head (default from 256 MiB of logits; bit 9 forces it): lm_head + online log-sum-exp + label gather + entropy over 4096
+    # vocabulary columns at a time, logits recomputed chunk by chunk in the backward - no [rows, vocab] buffer.  Same function in another
+    # fp32 association: log-probs / entropies to fp32 rounding, gradients to the bf16 rounding of d_hn (accumulated over the chunks in fp32)
+    peak0 = cx._lib.opadpo_ctx_bytes_peak(cx.ctx)
+    cx.set_flags(use_tr=1 | 512)
+    ad.grad.zero_()
+    out = _policy(cx, ad, 384, True)(**_kw(p, cx))
+    sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+    torch.cuda.synchronize()
+    assert float((out["chosen_response_logprobs"].detach() - res[1][0]).abs().max()) < 2e-5
+    assert float((out["rejected_response_entropies"] - res[1][1]).abs().max()) < 2e-4
+    valid = p["chosen"] != 0
+    assert bool((out["chosen_response_logprobs"].detach()[~valid] == 0).all())
+    assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-2      # measured 5e-3: bf16 rounding flips of d_hn, amplified by two layers
     cx.close()
     op.release()
 

@@ -71,6 +71,27 @@ def main():
             res.append(dict(kernel="attn_bwd_packed", ms=t * 1e3, tflops=2.5 * fl / t / 1e12))
             print(res[-1], flush=True)
         return
+    if only == "attn3":    # dense causal attention (no key mask, no segments): the kernels' clean-tile ceiling at the 7B head geometry
+        S, nh, hd, Ln = int(os.environ.get("GB_S", 22)), 32, 128, int(os.environ.get("GB_L", 1087))
+        H = nh * hd
+        qkv = torch.randn(S * Ln, 3 * H, device=dev).to(BF)
+        o = torch.empty(S * Ln, H, dtype=BF, device=dev)
+        lse = torch.empty(S, nh, Ln, device=dev)
+        fl = S * nh * 4 * hd * (Ln * Ln / 2)
+        dqkv = torch.empty(S * Ln, 3 * H, dtype=BF, device=dev)
+        delta = torch.empty(S, nh, Ln, device=dev)
+        do = torch.randn(S * Ln, H, device=dev).to(BF)
+        L.set_flags(True, int(os.environ.get("GB_TR", 1)))
+        f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
+                           lse.data_ptr(), None, S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
+        t = timeit(f, iters=5, warm=2)
+        print(dict(kernel="attn_fwd_dense_causal", L=Ln, ms=t * 1e3, tflops=fl / t / 1e12), flush=True)
+        f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
+                           do.data_ptr(), H, lse.data_ptr(), None, dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
+                           None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
+        t = timeit(f, iters=5, warm=2)
+        print(dict(kernel="attn_bwd_dense_causal", L=Ln, ms=t * 1e3, tflops=2.5 * fl / t / 1e12), flush=True)
+        return
     if only == "tail":     # partial last round of 256x256 tiles: row-tile count sweep at the ragged bench row counts
         for name, N, K1, K2, grp in shapes[:4]:
             for R in [int(v) for v in os.environ.get("GB_RT", "96,97,100,104,108,112").split(",")]:
