@@ -221,7 +221,19 @@ def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
         per_step = (t[steps + 2] - t[2]) / steps
         ctx = 128 + d.n_patches - 1 + 2 + steps / 2
         kv = 2 * 2 * d.n_layers * d.hidden * ctx * B
+        # the shipped rollout length (response_len 896, online_generator.py:292-309): prefill + 896 decode steps, end to end, one run
+        n_full = 896
+        kwf = dict(image_feats=feats, max_new_tokens=n_full, top_k=30, top_p=0.95, suppress_eos=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gen.generate(p["queries"], p["queries_attn_masks"], seed=3, **kwf)
+        torch.cuda.synchronize()
+        t_full = time.perf_counter() - t0
+        prefill_ms = max(t[2] - 2 * per_step, 0.0) * 1e3
         out[f"b{B}"] = {"batch": B, "decode_ms_per_step": per_step * 1e3, "tokens_per_s": B / per_step, "prefill_plus_2_steps_ms": t[2] * 1e3,
+                        "prefill_ms": prefill_ms, "prefill_tokens_per_s": B * (128 + d.n_patches - 1) / max(prefill_ms * 1e-3, 1e-9),
+                        "end_to_end_896_new_tokens": {"seconds": t_full, "tokens_per_s": B * n_full / t_full,
+                                                      "ms_per_step_mean": (t_full - prefill_ms * 1e-3) / n_full * 1e3, "ctx_final": 128 + d.n_patches - 1 + n_full},
                         "bytes_per_step_GB": (wbytes + kv) / 1e9, "weight_GB": wbytes / 1e9, "kv_GB": kv / 1e9,
                         "hbm_frac": (wbytes + kv) / per_step / 8e12, "steps_timed": steps}
         del feats, p

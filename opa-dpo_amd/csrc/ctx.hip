@@ -815,11 +815,13 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   } else {
     sv->Rc = sv->R;
   }
-  // chunked head: automatically from 256 MiB of fp32 logits (the benchmark's 22 pairs: 1.2 GB -> 0.15 GB; 13B, K = 3 or T = 896 recipes
-  // scale that buffer with every valid token); context flag (use_tr) bit 9 forces it for any size, bit 10 switches it off
+  // chunked head: automatically from 2 GiB of fp32 logits (K = 3 responses at T = 896, large rollout batches: the buffer and its bf16
+  // gradient scale with every valid token); context flag (use_tr) bit 9 forces it for any size, bit 10 switches it off.  Same-box A/B at
+  // the benchmark's 22 pairs (1.27 GB of logits): chunked 977.2 ms / 217.9 GB, un-chunked 972.9 ms / 220.2 GB per step - below the
+  // threshold the one-buffer form is kept (the recomputed lm_head GEMM and 8 short launches cost 0.4 %)
   {
     const int ut = c->use_tr >= 0 ? c->use_tr : 0;
-    const bool want = (ut & 512) || (!(ut & 1024) && (size_t)std::max(sv->Rc, 1) * d.vocab * sizeof(float) >= ((size_t)256 << 20));
+    const bool want = (ut & 512) || (!(ut & 1024) && (size_t)std::max(sv->Rc, 1) * d.vocab * sizeof(float) >= ((size_t)2 << 30));
     sv->head_chunk = (want && d.vocab > 4096) ? 4096 : 0;
   }
   sv->bytes = saved_layout(d, sv, nullptr);

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_bench
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-22} --accum 1 --no-cpu-baseline --no-rollout --no-exchange-probe > $OUT/$C.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -- python $R/bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-22} --accum 1 --no-cpu-baseline --no-rollout --no-exchange-probe --no-side-legs > $OUT/$C.log 2>&1
   echo "pass $C rc=$?"
 done
 python - <<PY
@@ -28,7 +28,7 @@ for k, d in agg.items():
               "hbm_bytes_per_launch_corrected": (2 * sum(f) / len(f) + sum(w) / max(1, len(w))) * 1024}
 nt = [res[k] for k in ("gemm_nt_w4", "gemm_nt_p8", "gemm_nt_pp", "gemm_nt_x") if k in res]
 tot_l = sum(r["launches"] for r in nt)
-full = {"command": "tools/pmc_bench.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes; python bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-22} --accum 1 --no-rollout --no-exchange-probe; ragged rows, context path)",
+full = {"command": "tools/pmc_bench.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes; python bench.py --steps 1 --warmup 0 --pairs ${PAIRS:-22} --accum 1 --no-rollout --no-exchange-probe --no-side-legs; ragged rows, context path)",
         "correction": "FETCH_SIZE x2 on gfx950 for wide coalesced streaming reads (MI355X_MICROARCH.md HBM section); values are KiB in the raw counters; the memory-side counters include Infinity-Cache hits",
         "kernels": res,
         "gemm_nt_avg_hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch_corrected"] * r["launches"] for r in nt) / max(1, tot_l)}
