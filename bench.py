@@ -133,12 +133,16 @@ class GpuSampler:
                 js = json.loads(r.stdout)
                 card = next(iter(js.values()))
                 rec = {"t": time.time() - t0}
+                import re
+                if not self.samples:      # the raw clock fields once, so that a parsing miss on another rocm-smi build stays visible
+                    rec["raw_clock_fields"] = {k: str(v) for k, v in card.items() if "clk" in k.lower()}
                 for k, v in card.items():
                     kl = k.lower()
-                    if "sclk" in kl and "clock" in kl:
-                        rec["sclk_mhz"] = float(str(v).strip("()Mhz ").replace("Mhz", "") or 0)
-                    elif "mclk" in kl and "clock" in kl:
-                        rec["mclk_mhz"] = float(str(v).strip("()Mhz ").replace("Mhz", "") or 0)
+                    num = re.search(r"(\d+(?:\.\d+)?)\s*mhz", str(v).lower())
+                    if "sclk" in kl and num:
+                        rec["sclk_mhz"] = float(num.group(1))
+                    elif "mclk" in kl and num:
+                        rec["mclk_mhz"] = float(num.group(1))
                     elif "power" in kl and "(w)" in kl:
                         rec["power_w"] = float(v)
                     elif "temperature" in kl and ("junction" in kl or "hotspot" in kl):
@@ -435,8 +439,16 @@ def main():
         ctx_prof = eng.profile_read()
         eng.profile(False)
     tmax = torch.tensor([dt], device=dev)
+    dist_rec = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # what the collective backend actually saw: every rank's (rank, local device, device name) through RCCL itself
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local)})
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                       # sum of ones over RCCL = number of ranks in the communicator
+        dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(probe), "ranks": seen,
+                    "exchange": f"{args.optimizer_mode}: per-bucket {'reduce_scatter + all_gather' if args.optimizer_mode == 'zero1' else 'all_reduce'} of the flat LoRA gradient, launched from the backward's layer hook"}
     dt = float(tmax)
     pairs_per_step = args.pairs * args.accum * world
     value = pairs_per_step * args.steps / dt
@@ -507,6 +519,8 @@ def main():
                                 "ms_per_step_by_block_of_20": blocks, "sclk_mhz": col("sclk_mhz"), "power_w": col("power_w"), "temp_c": col("temp_c"),
                                 "samples": len(ok), "sample_errors": len(sampler.samples) - len(ok) if sampler else 0,
                                 "trace": ok[::max(1, len(ok) // 60)]}
+        if dist_rec is not None:
+            out["dist"] = dist_rec
         par = _parity_record()
         if par is not None and args.model == "7b":
             out["parity"] = par

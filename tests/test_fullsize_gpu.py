@@ -128,7 +128,7 @@ def test_p6_rollout_graph_equals_eager(full):
                                  seed=4, suppress_eos=True))
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    assert int((outs[0] >= 3).sum()) == outs[0].numel()
+    assert int((outs[0] == 2).sum()) == 0      # EOS suppressed; ids 0 / 1 are ordinary vocabulary entries of a random-init model
 
 
 # ---- P7: the benchmarked path against the oracle AT THE BENCHMARKED DEPTH ---------------------------------------------------
