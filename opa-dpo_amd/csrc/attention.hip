@@ -669,261 +669,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Forward, 8-wave ping-pong (head_dim 128; OPADPO_ATTN_PP=1 - experiment of round 3): the 32-rows-per-wave arithmetic of attn_fwd32_kernel
-// with the two waves of every SIMD held in COMPLEMENTARY phases by block barriers.  Block = 8 waves = 256 q rows; waves w and w + 4 share a
-// SIMD and form the groups G0 (w < 4) and G1.  Time runs in slots, one block barrier per slot:
-//     slot 2t   : G0  M(t)    = PV(t-1) then QK(t)   (32 MFMAs, all fragment reads)      |  G1  S(t-1) = softmax of its tile t-1 (VALU only)
-//     slot 2t+1 : G0  S(t)                                                                |  G1  M(t)
-// so that on every SIMD one wave feeds the matrix pipe while its partner runs the exp chain.  K(t) and V(t-1) are live during slots
-// 2t and 2t+1; K(t+1) and V(t) are fetched (global -> registers) at the start of slot 2t and written into the buffers of K(t-1) / V(t-2)
-// at the end of slot 2t+1 (every thread stages 32 bytes per tile: 4 registers).  Key masks: two 80-byte buffers, mask(t) written with
-// K(t), read in slots 2t+1 and 2t+2.
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HD = 128, TILE = 64 * HD * 2;            // ring: [K0 | K1 | V0 | V1]
-  uint8_t* const ms_base = (uint8_t*)(smem + 4 * TILE);  // 2 x 80 mask bytes
-  int* const kt_list = (int*)(smem + 4 * TILE + 160);     // K/V tiles of this block in order (<= 64)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int grp = w >> 2;
-  const int ql = lane & 31, hi = lane >> 5;
-  const int n_qt = (p.L + 255) / 256;
-  int s, h, qi;
-  attn_block_map(p, n_qt, qi, h, s);
-  const int qt = n_qt - 1 - qi;
-  const int q0 = qt * 256;
-  const Geo ge = load_geo(p, s);
-  const int L = ge.L;
-  if (q0 >= L) return;
-  const int qlo = q0 + w * 32, qhi = min(qlo + 31, L - 1);
-  bool wave_live = qlo < L, wave_pad = false;
-  if ((p.causal & 2) && p.key_mask && wave_live) {
-    const int a_ = qlo + ql;
-    const uint8_t mq = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0;
-    wave_live = __ballot(mq != 0) != 0;
-    wave_pad = !wave_live;
-  }
-  const int qpos = qlo + ql;
-  const int qrow = min(qpos, L - 1);
-  bf16x8_t qf[8];
-  {
-    const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const uint4 v = *(const uint4*)(qp + ks * 16);
-      qf[ks] = *(const bf16x8_t*)&v;
-    }
-  }
-  f32x16_t o[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
-  const int n_kt_all = p.causal ? (min(L, q0 + 256) + 63) / 64 : (L + 63) / 64;
-  const SegSkip sk(ge, q0, n_kt_all);
-  if (tid == 0) {
-    int n = 0;
-    for (int kt = sk.first(); kt < n_kt_all; kt = sk.next(kt)) kt_list[n++] = kt;
-    kt_list[64] = n;
-  }
-  __syncthreads();
-  const int nT = kt_list[64];
-  const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
-  const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;
-  const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
-  const float scale2 = p.scale * 1.4426950408889634f;
-  // staging: 512 threads x 2 x 16 B per tile.  idx = tid + i*512 -> row idx >> 4, chunk idx & 15
-  const int srow = tid >> 4, sc16 = tid & 15;
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + ge.row0 * p.ld), 0, L * p.ld * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v + ge.row0 * p.ld), 0, L * p.ld * 2, 0x00020000);
-  const int svoff = (srow * p.ld + h * HD + sc16 * 8) * 2, sstep = 32 * p.ld * 2;
-  u32x4_t kst[2], vst[2];
-  auto fetch_k = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, svoff, kt * 64 * p.ld * 2 + i * sstep, 0);
-  };
-  auto fetch_v = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, svoff, kt * 64 * p.ld * 2 + i * sstep, 0);
-  };
-  auto commit_k = [&](char* dst) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow + i * 32;
-      *(u32x4_t*)(dst + row * 256 + ((sc16 ^ swz_mask<HD>(row)) << 4)) = kst[i];
-    }
-  };
-  auto commit_v = [&](char* dst) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow + i * 32;
-      *(u32x4_t*)(dst + row * 256 + (((((sc16 >> 1) ^ vswz(row)) << 1) | (sc16 & 1)) << 4)) = vst[i];
-    }
-  };
-  // prologue: K(0) and mask(0)
-  if (nT > 0) {
-    fetch_k(kt_list[0]);
-    commit_k(smem);
-    stage_mask(ms_base, p.key_mask, ge.row0, L, kt_list[0] * 64, tid);
-  }
-  __syncthreads();
-  const int krow_off = ql * 256, kswz = (ql & 7) << 1;
-  const int a4 = lane & 15, vgrp = (lane >> 4) & 1;
-  f32x16_t sc[2];
-  bf16x8_t pfr[2][2];
-  bool p_valid = false;                                   // pfr holds P of the wave's previous tile (false: that tile was dead for this wave)
-  auto tile_dead = [&](int k0) { return !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first); };
-
-  auto phase_M = [&](int t) {                             // PV(t-1) then QK(t)
-    if (t >= 1 && p_valid) {
-      const char* const Vs = smem + 2 * TILE + ((t - 1) & 1) * TILE;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;
-            union { bf16x8_t v; s16x4_t hh[2]; } vf;
-            vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r0 * 256 + (((((c16 >> 1) ^ vswz(r0)) << 1) | (c16 & 1)) << 4) + sub));
-            vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r1 * 256 + (((((c16 >> 1) ^ vswz(r1)) << 1) | (c16 & 1)) << 4) + sub));
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pfr[kb][s2], o[db], 0, 0, 0);
-          }
-        }
-    }
-    if (t < nT && !tile_dead(kt_list[t] * 64)) {
-      const char* const Ks = smem + (t & 1) * TILE;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
-          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
-        }
-      }
-    }
-  };
-  auto phase_S = [&](int t) {                             // softmax of tile t: sc -> pfr, m / l / o rescale
-    const int k0 = kt_list[t] * 64;
-    p_valid = !tile_dead(k0);
-    if (!p_valid) return;
-    const uint8_t* const Ms = ms_base + (t & 1) * 80;
-    const bool clean = !Ms[64] && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
-    float mx = -INFINITY;
-    if (clean) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-    } else {
-      uint64_t vis = *(const uint64_t*)(Ms + 72);
-      if (p.causal) {
-        const int lim = qpos - k0;
-        vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
-      }
-      {
-        const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi - k0, 0), 64);
-        if (hx > lo) {
-          const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
-          vis &= ~(below_hx & ~below_lo);
-        }
-      }
-      vis >>= 4 * hi;
-      const uint32_t vw[2] = {(uint32_t)vis, (uint32_t)(vis >> 32)};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = (vw[kb] & (1u << (8 * (r >> 2) + (r & 3)))) ? sc[kb][r] : -INFINITY;
-          sc[kb][r] = v;
-          mx = fmaxf(mx, v);
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    if (__ballot(m_new != m_run)) {
-      const float alpha = fast_exp2((m_run - m_new) * scale2);
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-      m_run = m_new;
-    }
-    typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
-    const f32x2v_t sc2 = {scale2, scale2}, mb2 = {-m_new * scale2, -m_new * scale2};
-    f32x2v_t ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2v_t a = __builtin_elementwise_fma(f32x2v_t{sc[kb][r], sc[kb][r + 1]}, sc2, mb2);
-        const f32x2v_t e = {fast_exp2(a[0]), fast_exp2(a[1])};
-        sc[kb][r] = e[0]; sc[kb][r + 1] = e[1];
-        ps2 += e;
-      }
-    l_run += ps2[0] + ps2[1];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        union { bf16x8_t v; uint32_t u[4]; } pf;
-        pf.u[0] = pack_bf2(sc[kb][8 * s2 + 0], sc[kb][8 * s2 + 1]); pf.u[1] = pack_bf2(sc[kb][8 * s2 + 2], sc[kb][8 * s2 + 3]);
-        pf.u[2] = pack_bf2(sc[kb][8 * s2 + 4], sc[kb][8 * s2 + 5]); pf.u[3] = pack_bf2(sc[kb][8 * s2 + 6], sc[kb][8 * s2 + 7]);
-        pfr[kb][s2] = pf.v;
-      }
-  };
-
-  const int n_slots = 2 * nT + 2;
-  for (int sl = 0; sl < n_slots; ++sl) {
-    const int te = sl >> 1;                               // slots 2te, 2te+1 stage K(te+1) and V(te)
-    if (!(sl & 1)) {
-      if (te + 1 < nT) fetch_k(kt_list[te + 1]);
-      if (te < nT) fetch_v(kt_list[te]);
-    }
-    if (((sl & 1) ^ grp) == 0) {                          // G0 on even slots, G1 on odd slots: the MFMA phase of tile te
-      phase_M(te);
-    } else {                                              // the other group: softmax of ITS current tile (G1 runs one slot behind G0)
-      const int t = te - grp;
-      if (t >= 0 && t < nT) phase_S(t);
-    }
-    if (sl & 1) {
-      if (te + 1 < nT) {
-        commit_k(smem + ((te + 1) & 1) * TILE);
-        stage_mask(ms_base + ((te + 1) & 1) * 80, p.key_mask, ge.row0, L, kt_list[te + 1] * 64, tid);
-      }
-      if (te < nT) commit_v(smem + 2 * TILE + (te & 1) * TILE);
-    }
-    __syncthreads();
-  }
-  l_run += __shfl_xor(l_run, 32, 64);
-  char* const stg = smem + w * 8192;
-  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      uint2 v;
-      v.x = pack_bf2(o[db][b * 4 + 0] * inv, o[db][b * 4 + 1] * inv);
-      v.y = pack_bf2(o[db][b * 4 + 2] * inv, o[db][b * 4 + 3] * inv);
-      const int d = db * 32 + b * 8 + hi * 4;
-      *(uint2*)(stg + ql * 256 + ((((d >> 3) ^ (ql & 15))) << 4) + (d & 7) * 2) = v;
-    }
-  if (hi == 0 && qpos < L && p.lse)
-    p.lse[stat_idx(p, ge, s, h, qpos)] = l_run > 0.f ? (m_run * scale2 + log2f(l_run)) * 0.6931471805599453f : (wave_pad ? -NEG_BIG : NEG_BIG);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 4 + (lane >> 4), c16 = lane & 15;
-    const uint4 v = *(const uint4*)(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
-    if (qlo + row < L) *(uint4*)(p.o + (ge.row0 + qlo + row) * p.ldo + h * HD + c16 * 8) = v;
-  }
-}
-
 // delta[s,h,pos] = sum_d dO * O.  HD/8 lanes per (row, head), 16 bytes of dO and of O per lane (a wave covers 64 / (HD/8) heads of
 // one row: 512 contiguous bytes per operand at HD = 128), shuffle reduction inside the lane group.
 template <int HD>
@@ -1281,15 +1026,6 @@ hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   if (g_attn32 < 0) { const char* v = getenv("OPADPO_ATTN32"); g_attn32 = (v && v[0] == '0') ? 0 : 1; }
   const bool legacy = a.use_tr >= 0 && (a.use_tr & 256);      // per-call: context flag bit 8 = the 16-row forward kernel
-  static int g_pp = -1;
-  if (g_pp < 0) { const char* v = getenv("OPADPO_ATTN_PP"); g_pp = (v && v[0] == '1') ? 1 : 0; }
-  if (a.hd == 128 && g_pp && !legacy && (double)a.L * a.ld * 2 < 2.0e9) {      // experiment: 8-wave ping-pong forward
-    static bool attrpp = false;
-    if (!attrpp) { (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160 + 272); attrpp = true; }
-    const dim3 gridpp((unsigned)(((a.L + 255) / 256) * a.nh * a.S));
-    hipLaunchKernelGGL(attn_fwd_pp_kernel, gridpp, dim3(512), 4 * 64 * 128 * 2 + 160 + 272, st, a);
-    return hipGetLastError();
-  }
   if (a.hd == 128 && g_attn32 && !legacy && (double)a.L * a.ld * 2 < 2.0e9) {
     static bool attr32 = false;
     if (!attr32) { (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160); attr32 = true; }

@@ -1836,6 +1836,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
         if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
         GemmNTArgs t = a;
         t.quarter = 1; t.tile0 = full;
+        // (a four-stage ring for these blocks - three K-tiles in flight, one block per CU - measured 973.1 vs 969.9 ms per step: no gain,
+        // a lone 4-wave 128x128 block runs at ~0.6 PF/s per CU whatever its prefetch depth; removed)
         hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
         return hipGetLastError();
       }

@@ -107,7 +107,7 @@ def test_p4_backward_is_linear_in_dlogp(full):
 def test_p5_causality_and_response_isolation(full):
     s, p = full, full["p"]
     base = _run(s, True, sel=slice(0, 1))
-    q = {k: v.clone() for k, v in p.items()}
+    q = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in p.items()}       # (the host row plan entries are not tensors to edit)
     pos = 40
     assert int(q["chosen"][0, pos]) != 0
     q["chosen"][0, pos] = 3 + (int(q["chosen"][0, pos]) - 2) % 1000
