@@ -1832,7 +1832,9 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       static const int tail_mode = getenv("OPADPO_TAIL_MODE") ? atoi(getenv("OPADPO_TAIL_MODE")) : 1;      // 0: none, 1: quarter tiles, 2: split-K (A/B)
       // (a deep-K problem of <= 128 tiles - x . A_d^T: N = 256, K = 11008 - runs as quarter tiles entirely: 4x the blocks on a chip it
       // would fill to a third; variant 31 = the 256x256 kernel on every tile, the bit-for-bit cross-check of the tests)
-      if (tail_mode == 1 && g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= 128 && !a.rope_cos) {
+      // measured (GB_ONLY=tail, N = 4096): a 16- or 64-tile tail costs 0.5-0.6 of a round as quarter tiles, a 128-tile tail 1.1-1.3 rounds
+      // (two quarter blocks share a CU there) - more than the plain partly filled round: quarter tiles up to 64 tiles only
+      if (tail_mode == 1 && g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= (deep_small && full == 0 ? 128 : 64) && !a.rope_cos) {
         if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
         GemmNTArgs t = a;
         t.quarter = 1; t.tile0 = full;
