@@ -77,6 +77,15 @@ int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ld
                         uint16_t* C, int ldc, int M, int N, const float* cos_tab, const float* sin_tab, int L, int rope_cols,
                         int seg_prefix, int seg_len, void* stream);
 
+/* The same projection with a TABLE-FREE rotary epilogue (round 3; what the context's ragged passes run): the position of every output
+ * row comes from row_pos [M] int32 (device), the angles are computed in the epilogue - v_sin / v_cos of the fractional revolution
+ * pos * theta^(-2i/128) / 2pi at a lane's first row, the angle-addition recurrence along runs of consecutive positions, a recomputation
+ * at every jump (next sequence, next response of a packed row).  No cos / sin traffic, no position arithmetic: ~2 us per 256x256 block
+ * instead of 7.7; angles within 2e-4 rad of HF's fp32 tables (the bf16 rounding of the result is 4e-3 relative). */
+int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                            const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
+                            uint16_t* C, int ldc, int M, int N, const int32_t* row_pos, float theta, int rope_cols, void* stream);
+
 /* Decode projection for up to 64 tokens (rollout at 33..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
  * no bias / residual / LoRA tail (adapter-free or merged adapter).  Both operands are streamed through a 4-stage LDS ring by
  * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup.  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
@@ -279,7 +288,8 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest);
  * bit 8 = the 16-rows-per-wave attention forward (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
- * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked from 2 GiB of fp32 logits) */
+ * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked from 2 GiB of fp32 logits);
+ * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);

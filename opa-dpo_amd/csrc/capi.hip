@@ -69,6 +69,25 @@ int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ld
   return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt_rope");
 }
 
+int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
+                            const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
+                            uint16_t* C, int ldc, int M, int N, const int32_t* row_pos, float theta, int rope_cols, void* stream) {
+  if (M < 0 || N <= 0 || N % 256) return bad("opadpo_gemm_nt_rope_pos", "N must be a positive multiple of 256");
+  if (K1 <= 0 || K2 < 0 || K1 % 64 || K2 % 64) return bad("opadpo_gemm_nt_rope_pos", "K1/K2 must be multiples of 64");
+  if (!A1 || !B1 || (K2 && (!A2 || !B2)) || !C || !row_pos) return bad("opadpo_gemm_nt_rope_pos", "null operand");
+  if (lda1 % 8 || ldb1 % 8 || (K2 && (lda2 % 8 || ldb2 % 8)) || ldc % 8) return bad("opadpo_gemm_nt_rope_pos", "leading dimensions must keep 16-byte alignment");
+  if (a2_group_n && a2_group_n % 256) return bad("opadpo_gemm_nt_rope_pos", "group width must be a multiple of the 256-column tile");
+  if (rope_cols < 0 || rope_cols > N || rope_cols % 128 || !(theta > 1.0f)) return bad("opadpo_gemm_nt_rope_pos", "rope_cols must be whole heads of 128 within N; theta > 1");
+  GemmNTArgs a;
+  a.A1 = A1; a.B1 = B1; a.A2 = A2; a.B2 = B2; a.C = C; a.R = nullptr; a.bias = nullptr;
+  a.M = M; a.N = N; a.K1 = K1; a.K2 = K2;
+  a.lda1 = lda1; a.ldb1 = ldb1; a.lda2 = lda2; a.ldb2 = ldb2; a.ldc = ldc; a.ldr = 0;
+  a.a2_group_n = a2_group_n; a.a2_group_stride = a2_group_stride; a.a1_group_n = 0; a.a1_group_stride = 0;
+  a.alpha = 1.0f; a.act = 0; a.out_f32 = 0; a.r_f32 = 0;
+  a.rope_pos = row_pos; a.rope_l2theta = log2f(theta); a.rope_cols = rope_cols;
+  return done(launch_gemm_nt(a, S(stream)), "opadpo_gemm_nt_rope_pos");
+}
+
 int opadpo_gemm_nt_decode(const uint16_t* A, int lda, const uint16_t* B, int ldb, int K, void* C, int ldc, int mode, int M, int N, int splits,
                           void* stream) {
   if (M < 0 || M > 64) return bad("opadpo_gemm_nt_decode", "M must be 0..64 (one token per sequence)");

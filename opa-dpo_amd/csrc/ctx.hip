@@ -472,16 +472,24 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
   if (yin) e = launch_rmsnorm_sum_fwd(res, 1, yin, 1, MH, w0.ln1, x, b.n1, b.rstd1, M, H, d.rms_eps, st);
   else e = (res == x) ? launch_rmsnorm_fwd(x, 1, w0.ln1, b.n1, b.rstd1, M, H, d.rms_eps, st) : hipErrorInvalidValue;
   if (e != hipSuccess) return e;
+  // rotary embedding: on ragged rows (per-row positions at hand) inside the q|k|v projection's epilogue, table-free - one 130-us pass over
+  // q and k less per layer and pass; context flag bit 11 keeps the separate in-place kernel (also: padded rows, head_dim 64, small problems
+  // that the 256x256 kernel does not take)
+  const bool fuse_rope = rg && hd == 128 && (3 * H) % 256 == 0 && !(c->use_tr >= 0 && (c->use_tr & 2048)) &&
+                         (double)M * H * 2 < 4.0e9 && ((M + 255) / 256) * (3 * H / 256) >= 150;
+  auto with_rope = [&](GemmNTArgs& g) { if (fuse_rope) { g.rope_pos = rg->row_pos; g.rope_l2theta = log2f(d.rope_theta); g.rope_cols = 2 * H; } };
   if (lw) {
     GemmNTArgs g1_ = gemm(c, b.n1, H, lw + o.a_qkv, H, H, b.t_qkv, 3 * r, 0, M, 3 * r); g1_.alpha = s;
     if ((e = run_gemm(c, g1_, st)) != hipSuccess) return e;
     GemmNTArgs g2 = gemm(c, b.n1, H, w.wqkv, H, H, b.qkv, 3 * H, 0, M, 3 * H); tail(g2, b.t_qkv, 3 * r, lw + o.b_qkv, r, r, H, r);
+    with_rope(g2);
     if ((e = run_gemm(c, g2, st)) != hipSuccess) return e;
   } else {
     GemmNTArgs g2 = gemm(c, b.n1, H, w.wqkv, H, H, b.qkv, 3 * H, 0, M, 3 * H);
+    with_rope(g2);
     if ((e = run_gemm(c, g2, st)) != hipSuccess) return e;
   }
-  if ((e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st, rg ? rg->row_pos : nullptr)) != hipSuccess) return e;
+  if (!fuse_rope && (e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st, rg ? rg->row_pos : nullptr)) != hipSuccess) return e;
   if (kc) {                                        // rollout prefill: post-RoPE k, v -> head-major KV cache
     hipLaunchKernelGGL(kv_fill_kernel, dim3(std::min<size_t>(4096, ((size_t)M * nh * (hd / 8) + 255) / 256)), dim3(256), 0, st, b.qkv, kc, vc, S, Lp, nh, hd, max_ctx);
     if ((e = hipGetLastError()) != hipSuccess) return e;

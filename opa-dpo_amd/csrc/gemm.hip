@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       p.a1_group_n = p.a2_group_n; p.a1_group_stride = p.a2_group_stride; p.a2_group_n = 0;
     }
     p.C = p.partial + ((size_t)(bid * KS + ks) << 16) - ((size_t)m0 * P_BN + n0);
-    p.ldc = P_BN; p.out_f32 = 1; p.R = nullptr; p.alpha = 1.0f; p.act = 0; p.rope_cos = nullptr;
+    p.ldc = P_BN; p.out_f32 = 1; p.R = nullptr; p.alpha = 1.0f; p.act = 0; p.rope_cos = nullptr; p.rope_pos = nullptr;
   }
 
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
@@ -626,6 +626,54 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           }
           *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(dg);
           *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + p.N + n) = pack8(du);
+        }
+        return;
+      }
+      if (p.rope_pos && ncol0 < p.rope_cols) {
+        // fused rotary embedding WITHOUT table traffic (round 3; the table form below pays 64 KiB of fp32 cos / sin reads per 32 KiB of output
+        // and a position computation per row: 7.7 us per block, as much as the in-place rope kernel costs).  Lane (row0 = lane >> 4, g =
+        // lane & 15) rotates 8 columns of rows row0, row0 + 4, ...: the angles of its 8 frequencies come from v_sin / v_cos of the
+        // fractional revolution pos * inv_freq / 2pi at its first row and from the angle-addition recurrence (cos, sin)(pos + 4) while the
+        // positions of its rows advance by 4 (inside a sequence); a jump (next sequence / next response of a packed row) recomputes.
+        // Same arithmetic on the bf16-ROUNDED staged values as rope_kernel; angles differ from the table's by <= 2e-4 rad.
+        const int row0 = lane >> 4, g = lane & 15, gh = g & 7;
+        const float sign = g < 8 ? -1.0f : 1.0f;
+        float frev[8], c4[8], s4[8], cs[8], sn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) frev[e] = __builtin_amdgcn_exp2f(-(float)(2 * (gh * 8 + e)) * (1.0f / 128.0f) * p.rope_l2theta) * 0.15915494309189535f;
+        auto direct = [&](float posf, float (&c)[8], float (&sv)[8]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = __builtin_amdgcn_fractf(posf * frev[e]);
+            c[e] = __builtin_amdgcn_cosf(x);
+            sv[e] = __builtin_amdgcn_sinf(x);
+          }
+        };
+        direct(4.0f, c4, s4);
+        int pos = p.rope_pos[min(mb + row0, p.M - 1)];
+        direct((float)pos, cs, sn);
+#pragma unroll 2
+        for (int ps = 0; ps < 32; ++ps) {
+          const int row = ps * 4 + row0, m = mb + row;
+          const int pn = p.rope_pos[min(m + 4, p.M - 1)];                    // next row of this lane: requested before the math of this one
+          const char* rp = stg + row * 256;
+          float xs[8], xp[8], o[8];
+          unpack8(*(const uint4*)(rp + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xs);
+          unpack8(*(const uint4*)(rp + ((((g ^ 8) >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = xs[e] * cs[e] + sign * (xp[e] * sn[e]);
+          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = pack8(o);
+          if (pn == pos + 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float c = cs[e] * c4[e] - sn[e] * s4[e];
+              sn[e] = sn[e] * c4[e] + cs[e] * s4[e];
+              cs[e] = c;
+            }
+          } else {
+            direct((float)pn, cs, sn);
+          }
+          pos = pn;
         }
         return;
       }
@@ -1734,11 +1782,12 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
-  if (a.rope_cos) {      // fused rotary embedding: only the 4-wave 256x256 kernel implements it (bf16 out, alpha-only epilogue)
+  if (a.rope_cos || a.rope_pos) {      // fused rotary embedding: only the 4-wave 256x256 kernel implements it (bf16 out, alpha-only epilogue)
     const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
                       (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));
-    if (a.bias || a.act || a.R || a.out_f32 || a.N % P_BN || !ok32 || a.rope_L < 4 || a.rope_cols % 128 ||
-        (a.rope_seg_len > 0 && a.rope_seg_len < 4)) return hipErrorInvalidValue;
+    if (a.bias || a.act || a.R || a.out_f32 || a.N % P_BN || !ok32 || a.rope_cols % 128) return hipErrorInvalidValue;
+    if (a.rope_cos && (a.rope_L < 4 || (a.rope_seg_len > 0 && a.rope_seg_len < 4))) return hipErrorInvalidValue;
+    if (a.rope_pos && !(a.rope_l2theta > 0.f)) return hipErrorInvalidValue;
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
     hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
     return hipGetLastError();

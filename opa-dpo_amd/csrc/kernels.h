@@ -25,6 +25,10 @@ struct GemmNTArgs {
   const float* rope_cos = nullptr;
   const float* rope_sin = nullptr;
   int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
+  // table-free form (round 3): per-row positions (int32 [M], e.g. the ragged pass's row_pos) and log2(theta); the epilogue computes the
+  // angles itself (hardware sin / cos of the fractional revolution at the first row, angle-addition recurrence along position runs)
+  const int32_t* rope_pos = nullptr;
+  float rope_l2theta = 0.f;
   int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
   int variant = -1;                     // kernel-variant override of this call (opadpo_ctx_set_flags); -1 = process default (opadpo_set_flags)
   // split-K tail launch of the 256x256 kernel (set by launch_gemm_nt only): block = (tile tile0 + blockIdx / ksplit, K-slice blockIdx % ksplit),

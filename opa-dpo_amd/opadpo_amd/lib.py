@@ -27,6 +27,7 @@ _u64 = C.c_uint64
 SIGNATURES = {
     "opadpo_gemm_nt": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p, _i, _i, _f, _i, _p],
     "opadpo_gemm_nt_rope": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "opadpo_gemm_nt_rope_pos": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _f, _i, _p],
     "opadpo_gemm_nt_decode": [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p],
     "opadpo_gemm_nt_decode_splits": [_i, _i, _i],
     "opadpo_rmsnorm_sum_fwd": [_p, _i, _p, _i, _sz, _p, _p, _p, _p, _i, _i, _f, _p],

@@ -1078,6 +1078,51 @@ def test_gemm_nt_rope(L, S, Lp, seg, lora):
     assert float((d > 0).float().mean()) < 0.02                        # and almost everywhere identical
 
 
+@pytest.mark.parametrize("lora", [False, True])
+def test_gemm_nt_rope_pos(L, lora):
+    """opadpo_gemm_nt_rope_pos: the q|k|v projection with the TABLE-FREE rotary epilogue (per-row positions, hardware sin / cos at a lane's
+    first row, angle-addition recurrence along position runs, recomputation at every jump) == projection followed by the rotation of the
+    bf16-rounded result with exact fp32 angles: within one bf16 ulp everywhere (the angles differ by <= 2e-4 rad), v columns and rows
+    >= M untouched.  Row positions as a ragged batch has them: sequences of different lengths, packed responses restarting at their
+    prefix end, large positions (precision of the fractional revolution), runs shorter than the 4-row stride of a lane."""
+    L.set_flags(10, True)
+    nh, hd, K, r = 2, 128, 192, 64
+    H = nh * hd
+    pos = []
+    for n_pfx, resp in ((300, (60, 45)), (7, (3, 2)), (1500, (130, 1)), (64, (64, 64)), (2, ())):
+        pos += list(range(n_pfx))
+        for n in resp:
+            pos += list(range(n_pfx, n_pfx + n))
+    pos += [1999, 0, 5, 4, 3, 1000, 1001]          # no run at all
+    M = len(pos)
+    assert M % 256 != 0
+    row_pos = torch.tensor(pos, dtype=torch.int32, device=dev())
+    x, w = rnd(M, K, seed=1), rnd(3 * H, K, scale=0.3, seed=2)
+    kw = {}
+    if lora:
+        kw = dict(a2=rnd(M, 3 * r, seed=3), b2=rnd(3 * H, r, scale=0.3, seed=4), a2_group_n=H, a2_group_stride=r)
+    plain = torch.empty(M, 3 * H, dtype=BF, device=dev())
+    L.gemm_nt(x, w, plain, **kw)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.outer(torch.tensor(pos, dtype=torch.float32), inv).to(dev())          # HF: fp32 angle = pos * inv_freq
+    cos, sin = ang.cos()[:, None, :], ang.sin()[:, None, :]
+    qk = plain[:, :2 * H].float().view(M, 2 * nh, hd)
+    x1, x2 = qk[..., :hd // 2], qk[..., hd // 2:]
+    want = torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1).view(M, 2 * H)
+    got = torch.full((M + 1, 3 * H), 7.0, dtype=BF, device=dev())
+    a2, b2 = kw.get("a2"), kw.get("b2")
+    L.call("opadpo_gemm_nt_rope_pos", L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), K, L.ptr(a2), a2.stride(0) if lora else 0,
+           L.ptr(b2), b2.stride(0) if lora else 0, r if lora else 0, kw.get("a2_group_n", 0), kw.get("a2_group_stride", 0),
+           L.ptr(got), got.stride(0), M, 3 * H, L.ptr(row_pos), 10000.0, 2 * H, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got[:M, 2 * H:], plain[:, 2 * H:])                  # v columns: not rotated
+    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
+    d = (got[:M, :2 * H].float() - want).abs()
+    tol = 2.0 ** -7 * want.abs() + 2e-4 * (x1.abs().amax() + 1.0)          # one bf16 ulp of the result + the angle error on an O(1) operand
+    assert bool((d <= tol).all()), f"max excess {(d - tol).max().item()}"
+    assert float((got[:M, :2 * H].float() - want.to(BF).float()).abs().gt(0).float().mean()) < 0.06      # almost everywhere the same bf16 value
+
+
 @pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
 @pytest.mark.parametrize("shape", [(4096, 4096), (4096, 11008), (12288, 4096), (1024, 512)])
 def test_gemm_nt_decode_modes(L, M, shape):
