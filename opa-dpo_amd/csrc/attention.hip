@@ -76,6 +76,28 @@ __device__ __forceinline__ bf16x8_t pack_frag(const f32x4_t& a, const f32x4_t& b
   return u.v;
 }
 
+// Inverse rotary embedding of a gradient row held in the 16x16 accumulator layout (lane holds d = df*16 + g*4 + r, df = 0 .. HD/16 - 1):
+// the pair (d, d + HD/2) sits in the SAME lane (df, df + HD/32), so the rotation is lane-local.  g' = g*cos - rot(g)*sin with
+// rot(x) = [-x2, x1]  ->  o1 = x1*c + x2*s, o2 = x2*c - x1*s.  Angles: hardware sin / cos of the fractional revolution
+// pos * theta^(-2i/HD) / 2pi, once per row (the forward's table-free epilogue computes the same angles).
+template <int HD>
+__device__ __forceinline__ void rope_inverse_rows(f32x4_t (&acc)[HD / 16], int g, int pos, float l2theta) {
+  constexpr int HF = HD / 32;
+  const float posf = (float)pos;
+#pragma unroll
+  for (int df = 0; df < HF; ++df)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = df * 16 + g * 4 + r;                                        // frequency index d % (HD/2)
+      const float frev = __builtin_amdgcn_exp2f(-(float)(2 * i) * (1.0f / HD) * l2theta) * 0.15915494309189535f;
+      const float x = __builtin_amdgcn_fractf(posf * frev);
+      const float c = __builtin_amdgcn_cosf(x), sn = __builtin_amdgcn_sinf(x);
+      const float x1 = acc[df][r], x2 = acc[df + HF][r];
+      acc[df][r] = x1 * c + x2 * sn;
+      acc[df + HF][r] = x2 * c - x1 * sn;
+    }
+}
+
 // Global side of a [64][HD] tile stream: one buffer descriptor per (operand, sequence) whose extent is exactly the L rows
 // of the sequence, so rows past L read as ZERO in hardware (no per-lane predicate, no exec juggling) and the per-tile
 // offset lives in the scalar soffset: a tile fetch is HD/32 buffer_load_dwordx4 with ONE precomputed VGPR offset.
@@ -857,6 +879,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs p) {
       }
     }
   }
+  if (p.rope_pos) rope_inverse_rows<HD>(dk, g, p.rope_pos[ge.row0 + krow], p.rope_l2theta);      // dK back through the rotary embedding of k
   if (kpos < L) {
     bf16_t* dkp = p.dk + (ge.row0 + kpos) * p.ld + h * HD;
     bf16_t* dvp = p.dv + (ge.row0 + kpos) * p.ld + h * HD;
@@ -996,6 +1019,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     }
     __syncthreads();
   }
+  if (p.rope_pos) rope_inverse_rows<HD>(dq, g, p.rope_pos[ge.row0 + qrow], p.rope_l2theta);       // dQ back through the rotary embedding of q
   if (qpos < L) {
     if (p.dq) {
       bf16_t* dst = p.dq + (ge.row0 + qpos) * p.ld + h * HD;

@@ -1075,8 +1075,12 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     a.dout = d_attn; a.dq_acc = nullptr; a.dq = dqkv; a.dk = dqkv + H; a.dv = dqkv + 2 * H; a.delta = delta;
     a.seg_prefix = sv->seg_prefix; a.seg_len = sv->seg_len; a.use_tr = c->use_tr;
     if (sv->ragged) { a.seq_meta = sv->meta; a.meta_stride = sv->meta_stride; a.n_seg = sv->K; a.rows_total = M; a.seg_prefix = 0; a.seg_len = 0; }
+    // ragged rows: dQ / dK leave the attention backward already rotated back (lane-local in its accumulator layout) - no pass over dq | dk;
+    // context flag bit 11 (and padded rows) keep the separate inverse rope kernel
+    const bool fuse_rope_bwd = sv->ragged && !(c->use_tr >= 0 && (c->use_tr & 2048));
+    if (fuse_rope_bwd) { a.rope_pos = sv->row_pos; a.rope_l2theta = log2f(d.rope_theta); }
     CK(launch_attn_bwd(a, st));
-    CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr));
+    if (!fuse_rope_bwd) CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr));
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r, M));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0, M));

@@ -74,6 +74,10 @@ struct AttnArgs {
   // key_mask is per row.
   const int32_t* seq_meta;
   int meta_stride, n_seg, rows_total;
+  // backward only, nullable: per-row rotary positions (int32 [rows], the ragged pass's row_pos) + log2(theta).  When given, dQ and dK
+  // leave the kernels ALREADY rotated back (the gradient of apply_rotary_pos_emb: g*cos - rot(g)*sin) - no separate pass over dq | dk
+  const int32_t* rope_pos;
+  float rope_l2theta;
 };
 
 // up to 8 gemm_tn problems with the same M run as ONE launch of the 256x256 kernel (tile lists concatenated)
