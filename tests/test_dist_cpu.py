@@ -93,6 +93,11 @@ def _worker(rank, world, port, q, mode, wire, bucketed):
     work = master.to(torch.bfloat16)
     opt = FlatAdamW(master, grad, work, lr=1e-2, max_grad_norm=1.0, mode=mode, bucket_bounds=BOUNDS if bucketed else None,
                     exchange_dtype=wire, **CPU_KW)
+    # ZeRO-1: the full-size fp32 master is dropped (this rank's slices live in p_shard; state_dict() still assembles the whole tensor)
+    import types
+    holder = types.SimpleNamespace(master=master)
+    opt.release_full_master(holder)
+    assert (opt.master is None and holder.master is None) == (mode == "zero1")
     norms = []
     for step in range(3):
         grad.copy_(_grads(step)[rank])

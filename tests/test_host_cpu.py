@@ -101,6 +101,50 @@ def test_build_batch_stacking(golden_dir):
     assert abs(DM.pair_flops_packed(DM.LlavaDims(), 128, 384, 2) / DM.pair_flops(DM.LlavaDims(), 128, 384) - 0.682) < 0.01
 
 
+def test_host_row_plan_and_ragged_batches():
+    """The ragged-row plan is computed on the HOST from the collated tensors (policy.host_row_plan): leading masked query positions in
+    front of the image token, response lengths up to the last non-pad token; a ragged engine receives it through build_batch without any
+    device tensor being read (host inputs -> derived there; `row_lead` / `row_lens` -> taken as given; cache hits keep the caller's key
+    names; a key missing from row_lens falls back to the derived plan)."""
+    from opadpo_amd.policy import AutoregressivePolicy, host_row_plan
+    from opadpo_amd.synth import synth_pairs
+    d = DM.LlavaDims.tiny()
+    p = synth_pairs(d, 5, 16, 24, seed=11)
+    q, qm = p["queries"].clone(), p["queries_attn_masks"].clone()
+    q[0, :] = 7; q[0, 0] = DM.IMAGE_TOKEN_INDEX; qm[0, :] = True; qm[0, 0] = False      # image token at slot 0 behind a masked slot: lead = min(pads, image position) = 0
+    resp = {"chosen_response": p["chosen"].clone(), "rejected_response": p["rejected"].clone()}
+    resp["chosen_response"][1, :] = 0                                                    # an all-pad response: length 0
+    resp["rejected_response"][2, 5] = 0                                                  # a pad INSIDE a response does not end it
+    lead, lens = host_row_plan(q, qm, resp)
+    for b in range(5):
+        img = int((q[b] == DM.IMAGE_TOKEN_INDEX).nonzero()[0])
+        n_pad = 0
+        while n_pad < 16 and not bool(qm[b, n_pad]):
+            n_pad += 1
+        assert int(lead[b]) == min(n_pad, img)
+        for k, ids in resp.items():
+            nz = (ids[b] != 0).nonzero()
+            assert int(lens[k][b]) == (int(nz[-1]) + 1 if nz.numel() else 0)
+    assert int(lead[0]) == 0 and int(lens["chosen_response"][1]) == 0 and int(lens["rejected_response"][2]) > 5
+    eng = types.SimpleNamespace(dev=torch.device("cpu"), d=d, ragged=True)
+    ad = types.SimpleNamespace(trainable=False)
+    for pack in (True, False):
+        pol = AutoregressivePolicy(eng, ad, response_len=24, pack_responses=pack)
+        keys, b1 = pol.build_batch(q, qm, resp)                                        # host tensors: plan derived on the host
+        want = torch.stack([lead, lens["chosen_response"], lens["rejected_response"]], 1) if pack else \
+            torch.stack([lead.repeat(2), torch.cat([lens["chosen_response"], lens["rejected_response"]])], 1)
+        assert b1.row_plan.dtype == torch.int32 and torch.equal(b1.row_plan, want)
+        eng.__dict__.pop("_batch_cache", None)
+        fake = (lead + 1, {k: v - 1 for k, v in lens.items()})                           # a GIVEN plan is taken as is
+        _, b2 = pol.build_batch(q, qm, resp, fake[0], fake[1])
+        assert torch.equal(b2.row_plan[:, 0], fake[0] if pack else fake[0].repeat(2))
+        # cache: same tensors under other names -> the caller's names, the cached batch
+        other = {"mask_standard_response": resp["chosen_response"], "mask_AI_pseudo_response": resp["rejected_response"]}
+        keys3, b3 = pol.build_batch(q, qm, other)
+        assert keys3 == list(other) and b3 is b2
+        eng.__dict__.pop("_batch_cache", None)
+
+
 def test_schedule_shards_and_arith():
     assert cosine_lr(0, 1e-6, 5, 300) == 0.0 and abs(cosine_lr(5, 1e-6, 5, 300) - 1e-6) < 1e-18
     assert cosine_lr(300, 1e-6, 5, 300) < 1e-12
