@@ -24,4 +24,6 @@ OPADPO_P7_EMU=1 python -m pytest tests/test_fullsize_gpu.py -x -q -m gpu -k p7 >
 python bench.py --model 13b --steps 6 --warmup 2 --no-rollout --no-side-legs --no-exchange-probe > $O/bench_13b.json 2> $O/bench_13b.err
 python -c "import json;r=json.load(open('$O/bench_13b.json'));print('13b', r['value'], r['ms_per_step'], r['hbm_peak_allocated_GB'])"
 GB_M=24576 python tools/gemm_bench.py > $O/gemm_bench.txt 2>/dev/null      # per shape: this library's kernels and the vendor GEMM (torch.matmul -> hipBLASLt) side by side
+python tools/sample_bench.py > $O/sample_bench.txt 2>&1      # native OPA-DPO unit (3 responses + CoPO + AncPO)
+python tools/sft_bench.py > $O/sft_bench.txt 2>&1            # OPA LoRA-SFT step
 cp $R/gpurun_out/parity_bench_config.json $O/ 2>/dev/null
