@@ -14,8 +14,6 @@
 //            dB = dY^T t, dA = dT^T x).  Contraction runs along the rows of both operands, so
 //            fragments come from LDS through ds_read_b64_tr_b16; split over M with fp32
 //            atomics (gradients accumulate across micro-batches anyway).
-#include <map>
-#include <mutex>
 #include <utility>
 #include "common.h"
 #include "kernels.h"
@@ -273,10 +271,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int wr = wave >> 1, wc = wave & 1;
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  int bid = blockIdx.x, ks = 0;
-  const int KS = p.ksplit;                 // > 1: tail launch - this block computes ONE K-slice of its tile into an fp32 partial tile
-  if (KS > 1) { ks = bid % KS; bid /= KS; }
-  const int swz = KS > 1 ? p.tile0 + bid : xcd_remap(bid, gridDim.x);
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int width = p.group_m * tiles_n;
   const int group_id = swz / width;
   const int first_m = group_id * p.group_m;
@@ -284,22 +279,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int tm = first_m + (swz % width) % gsz;
   const int tn = (swz % width) / gsz;
   const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
-  if (KS > 1) {
-    // K-tiles [t0, t1) of the concatenated [K1 | K2] range: shift the operand bases, shrink K1 / K2 (a slice that lies wholly in the
-    // second operand becomes a first-operand-only problem), and aim the plain fp32 epilogue at the partial tile
-    const int ntA = p.K1 / P_BK, ntB = p.K2 / P_BK, ntt = ntA + ntB;
-    const int t0 = ks * ntt / KS, t1 = (ks + 1) * ntt / KS;
-    const int f0 = min(t0, ntA), f1 = min(t1, ntA), s0 = max(t0 - ntA, 0), s1 = max(t1 - ntA, 0);
-    p.A1 += f0 * P_BK; p.B1 += f0 * P_BK; p.K1 = (f1 - f0) * P_BK;
-    if (ntB) { p.A2 += s0 * P_BK; p.B2 += s0 * P_BK; }
-    p.K2 = (s1 - s0) * P_BK;
-    if (p.K1 == 0) {
-      p.A1 = p.A2; p.B1 = p.B2; p.lda1 = p.lda2; p.ldb1 = p.ldb2; p.K1 = p.K2; p.K2 = 0;
-      p.a1_group_n = p.a2_group_n; p.a1_group_stride = p.a2_group_stride; p.a2_group_n = 0;
-    }
-    p.C = p.partial + ((size_t)(bid * KS + ks) << 16) - ((size_t)m0 * P_BN + n0);
-    p.ldc = P_BN; p.out_f32 = 1; p.R = nullptr; p.alpha = 1.0f; p.act = 0; p.rope_cos = nullptr; p.rope_pos = nullptr;
-  }
 
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
   const bf16_t* a2 = p.A2;
@@ -746,61 +725,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     });
   };
   staged_epi();
-}
-
-// Partly filled last round of 256x256 tiles.  With one block per CU a GEMM of T tiles takes ceil(T / 256) rounds, and the row count of
-// a ragged batch is whatever the data says: N = 4096 at 97 instead of 96 row tiles is 6.06 rounds = SEVEN (0.593 -> 0.665 ms).
-// launch_gemm_nt therefore runs the full rounds as usual and the remaining <= 128 tiles as a split-K launch of the same kernel
-// (2 / 4 / 8 K-slices per tile so that the tail fills the chip with short blocks, fp32 partial tiles in a per-stream workspace), and this
-// kernel adds a tile's slices in slice order (deterministic) and applies the epilogue: alpha, optional residual, bf16 / fp32 store.
-// Block = 32 rows x 256 columns of one tile.
-__global__ __launch_bounds__(256) void gemm_nt_tail_reduce_kernel(GemmNTArgs p) {
-  const int slot = blockIdx.x >> 3, part = blockIdx.x & 7;
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int swz = p.tile0 + slot;
-  const int width = p.group_m * tiles_n;
-  const int first_m = (swz / width) * p.group_m;
-  const int gsz = min(tiles_m - first_m, p.group_m);
-  const int m0 = (first_m + (swz % width) % gsz) * P_BM, n0 = ((swz % width) / gsz) * P_BN;
-  const int col = (threadIdx.x & 31) * 8;
-  const float* base = p.partial + ((size_t)slot * p.ksplit << 16);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = part * 32 + (threadIdx.x >> 5) + 8 * i, m = m0 + row;
-    if (m >= p.M) continue;
-    float v[8];
-    {
-      const float4 a = *(const float4*)(base + row * P_BN + col), b = *(const float4*)(base + row * P_BN + col + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    }
-    for (int s = 1; s < p.ksplit; ++s) {
-      const float* q = base + ((size_t)s << 16) + row * P_BN + col;
-      const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
-      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    }
-    const size_t n = (size_t)n0 + col;
-    if (p.alpha != 1.0f) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-    }
-    if (p.R) {
-      if (p.r_f32) {
-        const float4 a = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n), b = *(const float4*)((const float*)p.R + (size_t)m * p.ldr + n + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-      } else {
-        float r8[8];
-        unpack8(*(const uint4*)((const bf16_t*)p.R + (size_t)m * p.ldr + n), r8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r8[e];
-      }
-    }
-    if (p.out_f32) {
-      *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      *(float4*)((float*)p.C + (size_t)m * p.ldc + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8(v);
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1741,28 +1665,6 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
-// 64 MiB of fp32 partial tiles per (device, stream) for the split-K tail (<= 128 tiles x 2 slices, 64 x 4 or 32 x 8, 256 KiB each).
-// Allocated on first use with hipMalloc (not while the stream is being captured: the tail then runs unsplit), kept for the life of the
-// process; launches on one stream are ordered, so one buffer per stream is enough.  OPADPO_NO_TAIL_SPLIT=1 switches the path off (A/B).
-static float* tail_workspace(hipStream_t st) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, float*> pool;
-  static int off = -1;
-  std::lock_guard<std::mutex> lk(mu);
-  if (off < 0) { const char* v = getenv("OPADPO_NO_TAIL_SPLIT"); off = (v && v[0] == '1') ? 1 : 0; }
-  if (off) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  auto it = pool.find({dev, st});
-  if (it != pool.end()) return it->second;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-  float* ptr = nullptr;
-  if (hipMalloc((void**)&ptr, (size_t)64 << 20) != hipSuccess) { (void)hipGetLastError(); ptr = nullptr; }
-  pool[{dev, st}] = ptr;              // a failed allocation is remembered: no retry storm
-  return ptr;
-}
-
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
   GemmNTArgs a = a_in;
@@ -1873,40 +1775,24 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
     if (plain && g_gemm_variant != 17) {    // 4 waves x 128x128, long-lead DMA schedule, M0 one MFMA ahead of each DMA
-      const int full = pp_tiles / 256 * 256, rem = pp_tiles - full, ntt = (a.K1 + a.K2) / P_BK;
-      // DEFAULT: a partly filled last round (<= 128 tiles) runs as QUARTER tiles on the 128x128 kernel - 4 blocks per 256x256 tile, each
-      // over the FULL K range in the same k order, so every element of C is bit-identical to what the 256x256 kernel writes and the
-      // result of a row does not depend on how many rows share the batch (the split-K tail below re-associates the fp32 sums of the tail
-      // tiles, and WHICH tiles are tail tiles depends on M).  Two 64-KiB blocks share a CU, <= 512 quarter blocks = at most one wave of them.
-      static const int tail_mode = getenv("OPADPO_TAIL_MODE") ? atoi(getenv("OPADPO_TAIL_MODE")) : 1;      // 0: none, 1: quarter tiles, 2: split-K (A/B)
+      const int full = pp_tiles / 256 * 256, rem = pp_tiles - full;
+      // a partly filled last round (<= 64 tiles) runs as QUARTER tiles on the 128x128 kernel - 4 blocks per 256x256 tile, each over the
+      // FULL K range in the same k order, so every element of C is bit-identical to what the 256x256 kernel writes and the result of a row
+      // does not depend on how many rows share the batch (WHICH tiles are tail tiles depends on M).
       // (a deep-K problem of <= 128 tiles - x . A_d^T: N = 256, K = 11008 - runs as quarter tiles entirely: 4x the blocks on a chip it
-      // would fill to a third; variant 31 = the 256x256 kernel on every tile, the bit-for-bit cross-check of the tests)
-      // measured (GB_ONLY=tail, N = 4096): a 16- or 64-tile tail costs 0.5-0.6 of a round as quarter tiles, a 128-tile tail 1.1-1.3 rounds
-      // (two quarter blocks share a CU there) - more than the plain partly filled round: quarter tiles up to 64 tiles only
-      if (tail_mode == 1 && g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= (deep_small && full == 0 ? 128 : 64) && !a.rope_cos) {
+      // would fill to a third; variant 31 = the 256x256 kernel on every tile, the bit-for-bit cross-check of the tests).
+      // Measured (GB_ONLY=tail, N = 4096): a 16- or 64-tile tail costs 0.5-0.6 of a round as quarter tiles, a 128-tile tail 1.1-1.3 rounds
+      // (two quarter blocks share a CU there) - more than the plain partly filled round: quarter tiles up to 64 tiles only.
+      // Round 2's split-K tail (2 / 4 / 8 K-slices per tail tile + a reduce launch, a process-global fp32 workspace) was 1.1 % faster per step
+      // (964.4 vs 975.2 ms; no tail handling: 982.8) but re-associated the fp32 sums of the tail tiles, i.e. made a row's result depend on
+      // the batch's row count; removed.
+      if (g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= (deep_small && full == 0 ? 128 : 64)) {
         if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
         GemmNTArgs t = a;
         t.quarter = 1; t.tile0 = full;
         // (a four-stage ring for these blocks - three K-tiles in flight, one block per CU - measured 973.1 vs 969.9 ms per step: no gain,
         // a lone 4-wave 128x128 block runs at ~0.6 PF/s per CU whatever its prefetch depth; removed)
         hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
-        return hipGetLastError();
-      }
-      if (tail_mode != 2) {
-        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
-        return hipGetLastError();
-      }
-      // OPADPO_TAIL_MODE=2 (A/B only): the tail as 2 / 4 / 8 K-slices per tile + a reduce / epilogue launch (gemm_nt_tail_reduce_kernel)
-      int S = ((full == 0 && !deep_small) || rem == 0 || rem > 128 || a.ldc % 8 || (a.R && a.ldr % 8)) ? 1 : rem <= 32 ? 8 : rem <= 64 ? 4 : 2;
-      while (S > 1 && ntt / S < 8) S >>= 1;
-      if (S == 2 && ntt < 128 && full > 0) S = 1;        // two slices only pay on deep K (down, dgrads: 1.730 vs 1.772 ms); at K = 4352 the reduce pass eats the gain
-      float* ws = S > 1 ? tail_workspace(st) : nullptr;
-      if (ws) {
-        if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
-        GemmNTArgs t = a;
-        t.ksplit = S; t.tile0 = full; t.partial = ws;
-        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(rem * S), dim3(256), 2 * P_STAGE, st, t);
-        hipLaunchKernelGGL(gemm_nt_tail_reduce_kernel, dim3(rem * 8), dim3(256), 0, st, t);
         return hipGetLastError();
       }
       hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);

@@ -31,10 +31,7 @@ struct GemmNTArgs {
   float rope_l2theta = 0.f;
   int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
   int variant = -1;                     // kernel-variant override of this call (opadpo_ctx_set_flags); -1 = process default (opadpo_set_flags)
-  // split-K tail launch of the 256x256 kernel (set by launch_gemm_nt only): block = (tile tile0 + blockIdx / ksplit, K-slice blockIdx % ksplit),
-  // fp32 partial tile to partial[(slot * ksplit + slice) * 65536]
-  int ksplit = 0, tile0 = 0;
-  float* partial = nullptr;
+  int tile0 = 0;
   // quarter-tile tail launch of the 128x128 kernel (set by launch_gemm_nt only): block b computes quarter (b & 3) of the 256x256 tile
   // tile0 + (b >> 2) of the 4-wave kernel's grouped tile order - the full K range, so every output element keeps the summation order
   // it has inside a 256x256 tile (results do not depend on which tiles fall into the tail, i.e. on the row count of the batch)

@@ -961,7 +961,7 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
                                          (22, 1024, 256, "bf16"), (22, 4096, 0, "alpha"), (33, 4096, 256, "bf16")])
 def test_gemm_nt_split_k_tail(L, R, K, r, mode):
     """A partly filled last round of 256x256 tiles (R row tiles x 16 column tiles: 272 / 288 / 304 / 352 / 528 tiles) runs as quarter
-    tiles on the 128x128 kernel (round 2: a split-K tail + reduce launch, now OPADPO_TAIL_MODE=2): every epilogue of the plain kernel
+    tiles on the 128x128 kernel (round 2 ran a split-K tail + reduce launch here; removed): every epilogue of the plain kernel
     (bf16 / fp32 out, bf16 / fp32 residual, alpha, K-concatenated LoRA tail, ragged last row tile) against fp32 torch, and BIT-EQUAL to the
     256x256 kernel on every tile and to the 128x128 kernel; rows >= M untouched."""
     L.set_flags(10, True)
