@@ -79,9 +79,9 @@ int opadpo_gemm_nt_rope(const uint16_t* A1, int lda1, const uint16_t* B1, int ld
 
 /* The same projection with a TABLE-FREE rotary epilogue (round 3; what the context's ragged passes run): the position of every output
  * row comes from row_pos [M] int32 (device), the angles are computed in the epilogue - v_sin / v_cos of the fractional revolution
- * pos * theta^(-2i/128) / 2pi at a lane's first row, the angle-addition recurrence along runs of consecutive positions, a recomputation
- * at every jump (next sequence, next response of a packed row).  No cos / sin traffic, no position arithmetic: ~2 us per 256x256 block
- * instead of 7.7; angles within 2e-4 rad of HF's fp32 tables (the bf16 rounding of the result is 4e-3 relative). */
+ * pos * theta^(-2i/128) / 2pi per (row, frequency), a function of those two numbers only (a row's bits do not depend on its place in the
+ * batch).  No cos / sin traffic, no position arithmetic: ~3 us per 256x256 block instead of 7.7; angles within 2e-4 rad of HF's fp32
+ * tables (the bf16 rounding of the result is 4e-3 relative). */
 int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, int ldb1, int K1,
                             const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
                             uint16_t* C, int ldc, int M, int N, const int32_t* row_pos, float theta, int rope_cols, void* stream);

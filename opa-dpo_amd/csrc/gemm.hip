@@ -611,26 +611,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       if (p.rope_pos && ncol0 < p.rope_cols) {
         // fused rotary embedding WITHOUT table traffic (round 3; the table form below pays 64 KiB of fp32 cos / sin reads per 32 KiB of output
         // and a position computation per row: 7.7 us per block, as much as the in-place rope kernel costs).  Lane (row0 = lane >> 4, g =
-        // lane & 15) rotates 8 columns of rows row0, row0 + 4, ...: the angles of its 8 frequencies come from v_sin / v_cos of the
-        // fractional revolution pos * inv_freq / 2pi at its first row and from the angle-addition recurrence (cos, sin)(pos + 4) while the
-        // positions of its rows advance by 4 (inside a sequence); a jump (next sequence / next response of a packed row) recomputes.
+        // lane & 15) rotates 8 columns of rows row0, row0 + 4, ...; the angles come from v_sin / v_cos of the fractional revolution
+        // pos * inv_freq / 2pi, evaluated per (row, frequency).  (An angle-addition recurrence along the rows was 1.4 us per block cheaper but
+        // made a row's last bit depend on its offset inside the 128-row block, i.e. on the batch around it.)
         // Same arithmetic on the bf16-ROUNDED staged values as rope_kernel; angles differ from the table's by <= 2e-4 rad.
         const int row0 = lane >> 4, g = lane & 15, gh = g & 7;
         const float sign = g < 8 ? -1.0f : 1.0f;
-        float frev[8], c4[8], s4[8], cs[8], sn[8];
+        float frev[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) frev[e] = __builtin_amdgcn_exp2f(-(float)(2 * (gh * 8 + e)) * (1.0f / 128.0f) * p.rope_l2theta) * 0.15915494309189535f;
-        auto direct = [&](float posf, float (&c)[8], float (&sv)[8]) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float x = __builtin_amdgcn_fractf(posf * frev[e]);
-            c[e] = __builtin_amdgcn_cosf(x);
-            sv[e] = __builtin_amdgcn_sinf(x);
-          }
-        };
-        direct(4.0f, c4, s4);
         int pos = p.rope_pos[min(mb + row0, p.M - 1)];
-        direct((float)pos, cs, sn);
 #pragma unroll 2
         for (int ps = 0; ps < 32; ++ps) {
           const int row = ps * 4 + row0, m = mb + row;
@@ -639,19 +629,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           float xs[8], xp[8], o[8];
           unpack8(*(const uint4*)(rp + (((g >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xs);
           unpack8(*(const uint4*)(rp + ((((g ^ 8) >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), xp);
+          const float posf = (float)pos;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = xs[e] * cs[e] + sign * (xp[e] * sn[e]);
-          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = pack8(o);
-          if (pn == pos + 4) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float c = cs[e] * c4[e] - sn[e] * s4[e];
-              sn[e] = sn[e] * c4[e] + cs[e] * s4[e];
-              cs[e] = c;
-            }
-          } else {
-            direct((float)pn, cs, sn);
+          for (int e = 0; e < 8; ++e) {
+            // the angle of (position, frequency) is a function of those two numbers ONLY - no recurrence along the rows of the tile - so a
+            // row's result does not depend on where the row sits in the batch (tests/test_fullsize_gpu.py P3: bit-equal)
+            const float x = __builtin_amdgcn_fractf(posf * frev[e]);
+            o[e] = xs[e] * __builtin_amdgcn_cosf(x) + sign * (xp[e] * __builtin_amdgcn_sinf(x));
           }
+          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = pack8(o);
           pos = pn;
         }
         return;

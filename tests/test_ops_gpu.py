@@ -1080,8 +1080,8 @@ def test_gemm_nt_rope(L, S, Lp, seg, lora):
 
 @pytest.mark.parametrize("lora", [False, True])
 def test_gemm_nt_rope_pos(L, lora):
-    """opadpo_gemm_nt_rope_pos: the q|k|v projection with the TABLE-FREE rotary epilogue (per-row positions, hardware sin / cos at a lane's
-    first row, angle-addition recurrence along position runs, recomputation at every jump) == projection followed by the rotation of the
+    """opadpo_gemm_nt_rope_pos: the q|k|v projection with the TABLE-FREE rotary epilogue (per-row positions, hardware sin / cos of the
+    fractional revolution per (row, frequency)) == projection followed by the rotation of the
     bf16-rounded result with exact fp32 angles: within one bf16 ulp everywhere (the angles differ by <= 2e-4 rad), v columns and rows
     >= M untouched.  Row positions as a ragged batch has them: sequences of different lengths, packed responses restarting at their
     prefix end, large positions (precision of the fractional revolution), runs shorter than the 4-row stride of a lane."""
@@ -1121,6 +1121,20 @@ def test_gemm_nt_rope_pos(L, lora):
     tol = 2.0 ** -7 * want.abs() + 2e-4 * (x1.abs().amax() + 1.0)          # one bf16 ulp of the result + the angle error on an O(1) operand
     assert bool((d <= tol).all()), f"max excess {(d - tol).max().item()}"
     assert float((got[:M, :2 * H].float() - want.to(BF).float()).abs().gt(0).float().mean()) < 0.06      # almost everywhere the same bf16 value
+    # a row's result does not depend on where the row sits in the batch: the same rows behind 37 other rows -> the same bits
+    sh = 37
+    x2 = torch.cat([rnd(sh, K, seed=9), x], 0).contiguous()
+    pos2 = torch.cat([torch.arange(sh, dtype=torch.int32, device=dev()), row_pos]).contiguous()
+    kw2 = dict(kw)
+    if lora:
+        kw2["a2"] = torch.cat([rnd(sh, 3 * r, seed=10), a2], 0).contiguous()
+    got2 = torch.empty(M + sh, 3 * H, dtype=BF, device=dev())
+    a22 = kw2.get("a2")
+    L.call("opadpo_gemm_nt_rope_pos", L.ptr(x2), x2.stride(0), L.ptr(w), w.stride(0), K, L.ptr(a22), a22.stride(0) if lora else 0,
+           L.ptr(b2), b2.stride(0) if lora else 0, r if lora else 0, kw.get("a2_group_n", 0), kw.get("a2_group_stride", 0),
+           L.ptr(got2), got2.stride(0), M + sh, 3 * H, L.ptr(pos2), 10000.0, 2 * H, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(got2[sh:], got[:M])
 
 
 @pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
