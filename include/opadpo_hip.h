@@ -286,7 +286,7 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * bit 6 = SwiGLU backward in the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD; default: its own launch, which
  * measured 0.35 % faster per step); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only
  * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest);
- * bit 8 = the 16-rows-per-wave attention forward (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
+ * bit 8 = the 16-rows-per-wave attention forward and dQ kernels (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
  * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked from 2 GiB of fp32 logits);
  * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos) */

@@ -1039,6 +1039,185 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
 }
 
+// ---- backward part 2, round 3 (head_dim 128): dQ on 32 q rows per wave, the geometry of attn_fwd32_kernel ----------------------------
+//   S^T[key][q]  = K . Q^T      A = K row fragment (ds_read_b128),  B = Q in registers
+//   dP^T[key][q] = V . dO^T     A = V row fragment (ds_read_b128),  B = dO in registers
+//   dS^T = P^T * (dP^T - delta) * scale, P^T = exp2(S^T * scale2 - lse2)      (lane (q, hi) holds keys kb*32 + 8b + 4hi + (0..3))
+//   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]     A = K fragment through two ds_read_b64_tr_b16 at exactly those key rows, B = dS^T from
+//                                                 the accumulators (v_cvt_pk_bf16_f32) - the forward's P . V trick
+// K and V tiles both live in the vswz layout (conflict-free for the row reads AND the transposing reads), double-buffered ring,
+// register-staged, one barrier per tile; one 32-key block at a time so that S and dP cost 32 registers, not 64.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HD = 128, TILE = 64 * HD * 2;
+  uint8_t* const ms_base = (uint8_t*)(smem + 4 * TILE);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int n_qt = (p.L + 127) / 128;
+  int s, h, qi;
+  attn_block_map(p, n_qt, qi, h, s);
+  const int qt = n_qt - 1 - qi;
+  const int q0 = qt * 128;
+  const Geo ge = load_geo(p, s);
+  const int L = ge.L;
+  if (q0 >= L) return;
+  const int qlo = q0 + w * 32, qhi = min(qlo + 31, L - 1);
+  bool wave_live = qlo < L;
+  if ((p.causal & 2) && p.key_mask && wave_live) {      // 32 rows that are all padding: dQ = 0 (their dO is zero)
+    const int a_ = qlo + ql;
+    const uint8_t mq = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0;
+    wave_live = __ballot(mq != 0) != 0;
+  }
+  const int qpos = qlo + ql;
+  const int qrow = min(qpos, L - 1);
+  bf16x8_t qf[8], dof[8];
+  {
+    const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD + hi * 8;
+    const bf16_t* dp_ = p.dout + (ge.row0 + qrow) * p.ldo + h * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const uint4 a = *(const uint4*)(qp + ks * 16), b = *(const uint4*)(dp_ + ks * 16);
+      qf[ks] = *(const bf16x8_t*)&a;
+      dof[ks] = *(const bf16x8_t*)&b;
+    }
+  }
+  const size_t li = stat_idx(p, ge, s, h, qrow);
+  const float lse2 = p.lse[li] * 1.4426950408889634f, dlt = p.delta[li];
+  const float scale2 = p.scale * 1.4426950408889634f;
+  f32x16_t dq[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+  const int n_kt = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
+  const SegSkip sk(ge, q0, n_kt);
+  const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
+  const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;
+  const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
+  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
+  TileRegs<HD> kreg, vreg;
+  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
+  tile_commit_v(smem, kreg, tid);
+  tile_commit_v(smem + TILE, vreg, tid);
+  stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
+  int cur = 0;
+  const int a4 = lane & 15, vgrp = (lane >> 4) & 1;
+  auto row_off = [&](int row, int c16) { return row * 256 + (((((c16 >> 1) ^ vswz(row)) << 1) | (c16 & 1)) << 4); };
+  for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
+    nxt = sk.next(kt);
+    const int k0 = kt * 64;
+    const char* const Ks = smem + cur * 2 * TILE;
+    const char* const Vs = Ks + TILE;
+    const uint8_t* const Ms = ms_base + cur * 80;
+    __syncthreads();
+    if (nxt < n_kt) {
+      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
+    }
+    const bool dead = !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first);
+    if (!dead) {
+      const bool clean = !Ms[64] && qhi == qlo + 31 && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
+      uint32_t vw[2] = {~0u, ~0u};
+      if (!clean) {
+        uint64_t vis = *(const uint64_t*)(Ms + 72);
+        if (qpos >= L) vis = 0;
+        if (p.causal) {
+          const int lim = qpos - k0;
+          vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
+        }
+        {
+          const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi - k0, 0), 64);
+          if (hx > lo) {
+            const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+            vis &= ~(below_hx & ~below_lo);
+          }
+        }
+        vis >>= 4 * hi;
+        vw[0] = (uint32_t)vis; vw[1] = (uint32_t)(vis >> 32);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+        const int krow = kb * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + row_off(krow, ks * 2 + hi));
+          const bf16x8_t vf = *(const bf16x8_t*)(Vs + row_off(krow, ks * 2 + hi));
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float arg = __builtin_fmaf(sc[r], scale2, -lse2);
+          const bool ok = clean || (vw[kb] & (1u << (8 * (r >> 2) + (r & 3))));
+          const float pv = fast_exp2(ok ? arg : -INFINITY);
+          dp[r] = pv * (dp[r] - dlt) * p.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { bf16x8_t v; uint32_t u[4]; } df;
+          df.u[0] = pack_bf2(dp[8 * s2 + 0], dp[8 * s2 + 1]); df.u[1] = pack_bf2(dp[8 * s2 + 2], dp[8 * s2 + 3]);
+          df.u[2] = pack_bf2(dp[8 * s2 + 4], dp[8 * s2 + 5]); df.u[3] = pack_bf2(dp[8 * s2 + 6], dp[8 * s2 + 7]);
+          const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;
+            union { bf16x8_t v; s16x4_t hh[2]; } kf2;
+            kf2.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r0, c16) + sub));
+            kf2.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r1, c16) + sub));
+            dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf2.v, df.v, dq[db], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (nxt < n_kt) {
+      char* const nb = smem + (cur ^ 1) * 2 * TILE;
+      tile_commit_v(nb, kreg, tid);
+      tile_commit_v(nb + TILE, vreg, tid);
+      stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
+    }
+    cur ^= 1;
+  }
+  // dQ^T[d][q]: lane (q, hi) holds d = db*32 + 8b + 4hi + (0..3); the rotary pair (d, d + 64) = (db, db + 2) sits in the same lane
+  if (p.rope_pos) {
+    const float posf = (float)p.rope_pos[ge.row0 + qrow];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = db * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+        const float frev = __builtin_amdgcn_exp2f(-(float)(2 * i) * (1.0f / HD) * p.rope_l2theta) * 0.15915494309189535f;
+        const float x = __builtin_amdgcn_fractf(posf * frev);
+        const float c = __builtin_amdgcn_cosf(x), sn = __builtin_amdgcn_sinf(x);
+        const float x1 = dq[db][r], x2 = dq[db + 2][r];
+        dq[db][r] = x1 * c + x2 * sn;
+        dq[db + 2][r] = x2 * c - x1 * sn;
+      }
+  }
+  __syncthreads();
+  char* const stg = smem + w * 8192;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      uint2 v;
+      v.x = pack_bf2(dq[db][b * 4 + 0], dq[db][b * 4 + 1]);
+      v.y = pack_bf2(dq[db][b * 4 + 2], dq[db][b * 4 + 3]);
+      const int d = db * 32 + b * 8 + hi * 4;
+      *(uint2*)(stg + ql * 256 + ((((d >> 3) ^ (ql & 15))) << 4) + (d & 7) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4), c16 = lane & 15;
+    const uint4 v = *(const uint4*)(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
+    if (qlo + row < L) *(uint4*)(p.dq + (ge.row0 + qlo + row) * p.ld + h * HD + c16 * 8) = v;
+  }
+}
+
 }  // namespace
 
 static bool g_attn_dma = false;   // measured: the 64-KiB ring allows 2 blocks/CU, the 32-KiB register-staged kernel 3 -> 0.92 vs 1.01 ms
@@ -1091,10 +1270,18 @@ hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st) {
     attr_set = true;
   }
   if ((double)a.L * a.ld * 2 >= 2.0e9 || (double)a.L * a.ldo * 2 >= 2.0e9) return hipErrorInvalidValue;   // 32-bit buffer extents
+  static int g_dq32 = -1;
+  if (g_dq32 < 0) {
+    const char* v = getenv("OPADPO_DQ32");
+    g_dq32 = (v && v[0] == '0') ? 0 : 1;      // default: the 32-rows-per-wave dQ kernel at head_dim 128 (bf16 dQ, no fp32 copy); OPADPO_DQ32=0 / context flag bit 8 keep the 16-row kernel
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160);
+  }
+  const bool dq32 = g_dq32 && a.dq && !a.dq_acc && !(a.use_tr >= 0 && (a.use_tr & 256));
 #define LAUNCH_BWD(HD_, TR_)                                                                              \
   hipLaunchKernelGGL((attn_delta_kernel<HD_>), dim3((unsigned)((total + 4 * (512 / HD_) - 1) / (4 * (512 / HD_)))), dim3(256), 0, st, a); \
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HD_, TR_>), grid, dim3(256), 4 * 64 * HD_ * 2 + 1024 + 80 + 64, st, a); \
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
+  if (HD_ == 128 && dq32) hipLaunchKernelGGL(attn_bwd_dq32_kernel, dim3((unsigned)(((a.L + 127) / 128) * a.nh * a.S)), dim3(256), 4 * 64 * 128 * 2 + 160, st, a); \
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, TR_>), grid, dim3(256), 0, st, a)
   if (a.hd == 128) {
     if (tr) { LAUNCH_BWD(128, true); } else { LAUNCH_BWD(128, false); }
   } else {
