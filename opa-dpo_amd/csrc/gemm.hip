@@ -172,7 +172,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
       const int gr = min(m0 + r, p.M - 1);
       char* dA = smem + buf * SB + piece * 1024;
       __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, dA), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + r) * ldb + k0 + c * 8), LDS_PTR(void, dA + TB), 16, 0, 0);
+      // B tile: LDS row r holds the tile's row (r & 64) + 4 * (r & 15) + ((r >> 4) & 3), i.e. column slot s of B fragment j is row 4s + j
+      // of the wave's 64: a lane ends up with 4 CONSECUTIVE output columns per (row block, r) and 16 lanes store 128 contiguous bytes of
+      // a row (bf16) instead of 32-byte pieces of 16 rows; the permutation lives in the source address only
+      const int rb = (r & 64) + 4 * (r & 15) + ((r >> 4) & 3);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + rb) * ldb + k0 + c * 8), LDS_PTR(void, dA + TB), 16, 0, 0);
     }
   };
   const int wm = wave >> 1, wn = wave & 1;
@@ -209,22 +213,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
+  // acc[i][j][r] of lane (frow, fchk): row i*16 + 4*fchk + r, column 4*frow + j of the wave's 64x64 block
   epi_dispatch(p, [&](auto MD_) {
     constexpr int md = decltype(MD_)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + frow;
-      if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        epilogue4<md>(p, m, n0 + wn * 64 + j * 16 + fchk * 4, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + 4 * fchk + r;
+        if (m < p.M) epilogue4<md>(p, m, n0 + wn * 64 + 4 * frow, acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+      }
     }
   });
 }
@@ -300,6 +305,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const __amdgpu_buffer_rsrc_t rB2 = __builtin_amdgcn_make_buffer_rsrc(uni(nt2 ? p.B2 : p.B1), 0, (int)0xffffffffu, 0x00020000);
   const unsigned lrow = (unsigned)(wave * 64 + srow);                     // row of this wave's piece 0 inside the 256-row tile
   const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  // B tile: LDS row P holds the tile's row L(P) = P with bits 0 and 3 exchanged, its 16-byte chunks XOR-ed with (P >> 4) & 7.  The MFMA
+  // column slot s of B fragment f is the tile row 8s + f (so a lane ends up with 8 CONSECUTIVE output columns, one per fragment: 16-byte
+  // stores straight from the accumulators, 256 contiguous bytes per row and instruction); with the exchange the 16 lanes of a fragment
+  // read sit 2 KiB apart in pairs of adjacent LDS rows and the XOR spreads the pairs over the 8 chunks of a row: conflict-free, and
+  // all 8 fragments of a lane are one base address + immediates.  The permutation costs nothing: it lives in the per-lane source offsets.
+  const unsigned lrowB_lo = (unsigned)((srow & 1) * 8 + (srow & 6));     // + (pi & 1) + (pi >> 1) * 16 + wave * 64
   const unsigned m_last = (unsigned)(p.M - 1);
   // q = 0..7: A pieces (8 rows x 128 B each) wave*8 + q, q = 8..15: B pieces.  No vector ALU work per piece: the 16 per-lane
   // byte offsets sit in registers (recomputed only where the K-concatenated tail switches operands), the K position is the
@@ -311,7 +322,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #pragma unroll
     for (int pi = 0; pi < 8; ++pi) {
       if (which != 2) voff[pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
-      if (which != 1) voff[8 + pi] = ((unsigned)n0 + lrow + pi * 8u) * ldb + csw[pi & 1];
+      if (which != 1) voff[8 + pi] = ((unsigned)n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb +
+                                     (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
     }
   };
   auto issue_piece = [&](int t, int q) {
@@ -352,12 +364,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   bf16x8_t fa[2][8], fb[2][8];
   const int frow = lane & 15, fchk = lane >> 4;
   const int fsw = (frow >> 1) & 7;                                       // swizzle term: same for every fragment of a lane
-  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + frow) * 128;
+  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128;
   // fragment r of set kk of tile t: r = 0..7 -> B fragments, 8..15 -> A fragments
   auto read_frag = [&](int t, int kk, int r) {
     const char* st = smem + (t & 1) * P_STAGE;
     const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
-    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + r * 2048 + cb);
+    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + ((r & 1) * 8 + (r & 6)) * 128 + cb);
     else fa[kk][r - 8] = *(const bf16x8_t*)(st + offA + (r - 8) * 2048 + cb);
   };
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #pragma unroll
     for (int e = 0; e < n; ++e) {
       const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[kk][j]), "v"(fa[kk][i]));
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
     }
   };
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
@@ -470,24 +482,76 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 #undef W4_PIN
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
   __builtin_amdgcn_sched_barrier(0);                                             // ... and no accumulator read may be scheduled above them
+  // Accumulator layout (B tile rows interleaved, see above): acc[i][j][r] of lane (frow, fchk) is row i*16 + 4*fchk + r, column 8*frow + j
+  // of the wave's 128x128 block - the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns.
   auto staged_epi = [&]() {
-    // Row-contiguous epilogue: an accumulator fragment holds 4 columns of 16 different rows per 16 lanes, so storing it
-    // directly writes 32-byte pieces of 16 rows per instruction - measured 27 us per block (a fifth of its lifetime).  Each
-    // wave instead transposes its 128x128 block through its own 32 KiB of the (now dead) stages, 64 rows at a time in fp32
-    // (16-byte chunks XOR-swizzled by the row), and writes whole rows: 256 B (bf16) / 512 B (fp32) contiguous per row.
-    __builtin_amdgcn_s_barrier();                       // every wave has read its last fragments out of the stages
     char* stg = smem + wave * 32768;
     const int ncol0 = n0 + wc * 128;
+    const bool special = p.act == OPADPO_ACT_SWIGLU_PAIR || p.act == OPADPO_ACT_SWIGLU_BWD || ((p.rope_pos || p.rope_cos) && n0 < p.rope_cols);
+    if (!p.R && !special) {
+      // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
+      // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
+      // then held 4 columns of 16 rows: 32-byte pieces, 27 us per block.)
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+      const unsigned esz = p.out_f32 ? 4u : 2u;
+      const bool small = ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * esz < 0xffffffffull;
+      const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(uni(p.C), 0, small ? (int)((unsigned)p.M * (unsigned)p.ldc * esz) : 0, 0x00020000);
+      const int mrow0 = m0 + wr * 128 + 4 * fchk, col = ncol0 + 8 * frow;
+      epi_dispatch_plain(p, [&](auto MD_) {
+        constexpr int md = decltype(MD_)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v[8][4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc_read4(acc[i][j], v[j]);
+            epi_pre4<md>(p, 0, v[j]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + i * 16 + r;
+            if (p.out_f32) {
+              u32x4s_t lo, hi;
+              lo[0] = __float_as_uint(v[0][r]); lo[1] = __float_as_uint(v[1][r]); lo[2] = __float_as_uint(v[2][r]); lo[3] = __float_as_uint(v[3][r]);
+              hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
+              if (small) {
+                const unsigned vo = ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 0);
+              } else if (m < p.M) {
+                *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col) = lo;
+                *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col + 4) = hi;
+              }
+            } else {
+              u32x4s_t o;
+              o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
+              if (small) __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 0);
+              else if (m < p.M) *(u32x4s_t*)((bf16_t*)p.C + (size_t)m * p.ldc + col) = o;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);      // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
+        }
+      });
+      return;
+    }
+    // Staged epilogues (residual operand, SwiGLU pair / backward, rotary embedding): each wave passes its 128x128 block through its own
+    // 32 KiB of the (now dead) stages and works on whole rows: 256 B (bf16) / 512 B (fp32) contiguous per row.
+    __builtin_amdgcn_s_barrier();                       // every wave has read its last fragments out of the stages
     auto half = [&](auto HF, auto MD_) {
       constexpr int hf = decltype(HF)::value, md = decltype(MD_)::value;
 #pragma unroll
       for (int i4 = 0; i4 < 4; ++i4) {
+        float v[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float v[4];
-          acc_read4(acc[hf * 4 + i4][j], v);
-          epi_pre4<md>(p, ncol0 + j * 16 + fchk * 4, v);
-          *(float4*)(stg + (i4 * 16 + frow) * 512 + (((j * 4 + fchk) ^ frow) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+          acc_read4(acc[hf * 4 + i4][j], v[j]);
+          epi_pre4<md>(p, 0, v[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i4 * 16 + 4 * fchk + r;
+          *(float4*)(stg + row * 512 + (((2 * frow) ^ (row & 15)) << 4)) = make_float4(v[0][r], v[1][r], v[2][r], v[3][r]);
+          *(float4*)(stg + row * 512 + (((2 * frow + 1) ^ (row & 15)) << 4)) = make_float4(v[4][r], v[5][r], v[6][r], v[7][r]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -543,19 +607,23 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     };
     if (!p.out_f32 && (!p.R || p.act == OPADPO_ACT_SWIGLU_BWD)) {
       // bf16 result without residual: the whole 128x128 block fits the wave's 32 KiB as bf16 -> one LDS round trip, half the bytes
-      // (32-byte groups XOR-swizzled by row & 7; 8-byte writes in fragment layout, 16-byte reads along rows)
+      // (32-byte groups XOR-swizzled by row & 7; 16-byte writes of a lane's 8 columns, 16-byte reads along rows)
       epi_dispatch_plain(p, [&](auto MD_) {
         constexpr int md = decltype(MD_)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+          float v[8][4];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float v[4];
-            acc_read4(acc[i][j], v);
-            epi_pre4<md>(p, ncol0 + j * 16 + fchk * 4, v);
-            uint2 o;
-            o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)(stg + (i * 16 + frow) * 256 + ((j ^ (frow & 7)) << 5) + fchk * 8) = o;
+            acc_read4(acc[i][j], v[j]);
+            epi_pre4<md>(p, 0, v[j]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + 4 * fchk + r;
+            uint4 o;
+            o.x = pack_bf2(v[0][r], v[1][r]); o.y = pack_bf2(v[2][r], v[3][r]); o.z = pack_bf2(v[4][r], v[5][r]); o.w = pack_bf2(v[6][r], v[7][r]);
+            *(uint4*)(stg + row * 256 + (((frow >> 1) ^ (row & 7)) << 5) + (frow & 1) * 16) = o;
           }
           __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps 8, not 64, accumulators live in VGPRs
         }

@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libopadpo_hip.so")
+# OPADPO_LIB_PATH: another build of the same library (same-box A/B runs of two kernel versions); never a different implementation
+LIB_PATH = os.environ.get("OPADPO_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libopadpo_hip.so")
 
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_SWIGLU_PAIR, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4
 CAUSAL_SKIP_MASKED_Q = 3      # `causal` of opadpo_attn_fwd / _bwd: 1 = causal, | 2 = OPADPO_ATTN_SKIP_MASKED_Q (all-padding q tiles write zeros)
