@@ -269,6 +269,12 @@ constexpr int P_STAGE = 2 * P_TILE;              // A + B
 // piece (tools/micro/mfma_dma.hip).  1.40-1.48 PF/s on the training shapes; DESIGN.md section 8.1 keeps the numbers of the
 // schedules this one replaced (single barrier, 8-wave 4-phase, register-staged operands, in-kernel s_memtime stamps).
 // ------------------------------------------------------------------------------------------
+// ORDER_B: the 16 DMA pieces of a K-tile go B half first (pieces 8..15, then 0..7) instead of A half first.  Nothing else changes (both
+// halves are waited for together), yet same-box sustained runs (tools/ab_gemm.sh, 300 launches per shape) show a stable preference by shape:
+// N <= 4096 (o / down projection, every dgrad into the hidden width, the r-wide LoRA products) is 1.5-4 % faster B first, the wide
+// projections (q|k|v, gate|up, lm_head) 2.5-3 % faster A first - independent of group_m, of a third / fourth barrier per K-tile that
+// lengthens every piece's lead by 50 MFMAs, and of hand-placed lgkmcnt waits (all built and measured in round 3, none moved the time).
+template <bool ORDER_B>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
     constexpr bool dma = has_next2;
+    auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };      // k-th piece issued -> piece id (0..7 = A rows, 8..15 = B rows)
     // schedule knobs.  R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
     // DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after); one MFMA sits
     // between each s_waitcnt and its s_barrier
@@ -419,11 +426,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
         const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
         mfma_run(gi >> 6, gi & 63, 1);
         if constexpr (dma) {
-          if ((m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(t + 2, (m + 2) / DSTEP - 1); W4_PIN(); }
+          if ((m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(t + 2, piece_of((m + 2) / DSTEP - 1)); W4_PIN(); }
         }
         if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
           W4_PIN();
-          if constexpr (dma) dma_go(t + 2, (m + 1) / DSTEP - 1);
+          if constexpr (dma) dma_go(t + 2, piece_of((m + 1) / DSTEP - 1));
           W4_PIN();
         }
       }
@@ -444,12 +451,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       mfma_run(1, 36 + g * 3, 2);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, 13 + (g - 1) / 3); }
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, piece_of(13 + (g - 1) / 3)); }
       W4_PIN();
       mfma_run(1, 36 + g * 3 + 2, 1);
       W4_PIN();
       if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_go(t + 2, 13 + (g - 1) / 3); }
+      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_go(t + 2, piece_of(13 + (g - 1) / 3)); }
       W4_PIN();
     }
     mfma_run(1, 60, 4);
@@ -1719,9 +1726,19 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
+// piece order of the 4-wave 256x256 kernel by shape (see gemm_nt_w4_kernel): B half first for N <= 16 column tiles
+static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B first (experiments)
+#define W4_LAUNCH(GRID_)                                                                                                     \
+  do {                                                                                                                       \
+    const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
+    if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                         \
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                            \
+  } while (0)
+
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
   GemmNTArgs a = a_in;
+  if (g_w4_order == -1) { const char* v = getenv("OPADPO_W4_ORDER"); g_w4_order = v ? atoi(v) : -2; }
   // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
   // (N <= 4096: o / down and three of the four dgrads) - measured at M = 32362: down 1.363 -> 1.397 PF/s, o 1.394 -> 1.401,
   // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).
@@ -1734,7 +1751,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
@@ -1745,7 +1763,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     if (a.rope_cos && (a.rope_L < 4 || (a.rope_seg_len > 0 && a.rope_seg_len < 4))) return hipErrorInvalidValue;
     if (a.rope_pos && !(a.rope_l2theta > 0.f)) return hipErrorInvalidValue;
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    W4_LAUNCH(tiles);
     return hipGetLastError();
   }
   if (a.act == OPADPO_ACT_SWIGLU_BWD) {       // fused SwiGLU backward epilogue (R = stored [gate | up], C = [d_gate | d_up]): the 4-wave 256x256 kernel only
@@ -1753,7 +1771,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
                       (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));
     if (a.bias || !a.R || a.r_f32 || a.out_f32 || a.alpha != 1.0f || a.N % P_BN || !ok32 || a.ldr % 8 || a.ldc % 8 || a.rope_cos) return hipErrorInvalidValue;
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    W4_LAUNCH(tiles);
     return hipGetLastError();
   }
   if (a.act == OPADPO_ACT_SWIGLU_PAIR) {      // fused SwiGLU epilogue: the 4-wave 256x256 kernel, or the weight-streaming kernel for decode
@@ -1776,7 +1794,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       return hipGetLastError();
     }
     const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
-    hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(tiles), dim3(256), 2 * P_STAGE, st, a);
+    W4_LAUNCH(tiles);
     return hipGetLastError();
   }
   // decode-sized problems (M <= 64): weight-streaming kernel, one workgroup per 16 (or 32) weight rows
@@ -1841,7 +1859,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       // (964.4 vs 975.2 ms; no tail handling: 982.8) but re-associated the fp32 sums of the tail tiles, i.e. made a row's result depend on
       // the batch's row count; removed.
       if (g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= (deep_small && full == 0 ? 128 : 64)) {
-        if (full > 0) hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(full), dim3(256), 2 * P_STAGE, st, a);
+        if (full > 0) W4_LAUNCH(full);
         GemmNTArgs t = a;
         t.quarter = 1; t.tile0 = full;
         // (a four-stage ring for these blocks - three K-tiles in flight, one block per CU - measured 973.1 vs 969.9 ms per step: no gain,
@@ -1849,7 +1867,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
         hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
         return hipGetLastError();
       }
-      hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3(pp_tiles), dim3(256), 2 * P_STAGE, st, a);
+      W4_LAUNCH(pp_tiles);
     }
     else                                    // bias / activation epilogues (vision tower, projector): 8 waves x 128x64, 4 phases per K-tile
       hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);

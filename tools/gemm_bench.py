@@ -14,6 +14,7 @@ BF = torch.bfloat16
 
 
 def timeit(fn, iters=10, warm=3):
+    iters = int(os.environ.get("GB_ITERS", iters))      # GB_ITERS=300: long enough for the socket's sustained power state
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
