@@ -2,8 +2,10 @@
 """Headline benchmark: preference-pairs/sec, LLaVA-1.5-7B LoRA DPO, seq_len 512 (query 128 + response 384,
 L = 1087 LLM positions), synthetic image+text batches, random-init weights of the 7B architecture.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher environment: re-executes ITSELF through
+                                                           # torch.distributed.run (one rank per GPU, RCCL, rendezvous on 127.0.0.1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     # same thing, launched from outside
+    python bench.py --gpus 2 --dry-run                     # launcher + rendezvous + bucketed exchange self-check, no kernels (gloo on a CPU box)
 
 One STEP = one optimizer step on every rank: `accum` (default 1) micro-batches of `pairs` (default 22) (image, chosen, rejected)
 pairs -> vision encode (once per image) -> frozen-reference forward (no grad) -> policy forward (activations
@@ -288,6 +290,133 @@ def exchange_probe(numel, dev, layer_numel, n_layers):
         if made:
             dist.destroy_process_group()
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (RANK / WORLD_SIZE unset): start the N ranks the way
+    the reference's run/train_opa_dpo.sh:96-100 starts the trainer (`torchrun --nproc-per-node=$GPUS_PER_NODE`, one process per GPU) - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free port> bench.py <same arguments>` - and hand its exit code back.  Rank 0's JSON line goes
+    straight through to this process's stdout (the children inherit it)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank, local):
+    """`--dry-run`: everything of the N > 1 path that is not a kernel - the launcher, the rendezvous, rank -> device binding, the
+    barrier-bracketed max-over-ranks timing and the bucketed ZeRO-1 exchange of optim.FlatAdamW (reduce-scatter per bucket launched
+    last bucket first like the backward's layer hook does, sharded clip + AdamW, all-gather) on a flat buffer of the model's
+    layer-major LoRA layout, with torch stand-ins for the two HIP update kernels.  Self-check: every rank ends with the SAME bf16
+    working copy, and it equals the 1-rank step on the rank-averaged gradient.  Runs on gloo / CPU when there are fewer GPUs than
+    ranks (tests/test_bench_launcher_cpu.py), on RCCL otherwise.  Prints the bench line with "dry_run": true and value null."""
+    import math
+    from opadpo_amd.dims import LlavaDims, lora_param_count
+    from opadpo_amd.optim import FlatAdamW, layer_buckets, torch_cast
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world and args.backend != "gloo"
+    dev = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local)
+    backend = "nccl" if use_gpu else "gloo"
+    if world > 1:
+        dist.init_process_group(backend, **({"device_id": dev} if use_gpu else {}))
+
+    def t_sumsq(g, out):
+        out += (g.double() ** 2).sum().float()
+
+    def t_adamw(p, g, m, v, p_bf16, *, lr, beta1, beta2, eps, weight_decay, step, sumsq, max_norm, grad_div):
+        scale = grad_div
+        if sumsq is not None and max_norm:
+            norm = math.sqrt(float(sumsq)) * grad_div
+            scale *= min(1.0, max_norm / (norm + 1e-6))
+        gi = g.float() * scale
+        m.mul_(beta1).add_(gi, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+        p.addcdiv_(m, v.sqrt() / math.sqrt(1 - beta2 ** step) + eps, value=-lr / (1 - beta1 ** step))
+        p_bf16.copy_(p.to(p_bf16.dtype))
+    kw = dict(sumsq_fn=t_sumsq, adamw_fn=t_adamw, cast_fn=torch_cast)
+    d = {"7b": LlavaDims.llava15_7b, "13b": LlavaDims.llava15_13b, "tiny": LlavaDims.tiny}[args.model]()
+    numel = lora_param_count(d)
+    layer_numel = numel // d.n_layers
+    bounds = layer_buckets(layer_numel, d.n_layers, 1 if args.model == "tiny" else 4)
+    g0 = torch.Generator().manual_seed(7)
+    p0 = torch.randn(numel, generator=g0) * 0.02
+
+    def grad_of(r, s):
+        return torch.randn(numel, generator=torch.Generator().manual_seed(1000 * s + r)) * 0.01
+    master = p0.clone().to(dev)
+    grad = torch.zeros(numel, device=dev)
+    work = master.to(torch.bfloat16)
+    opt = FlatAdamW(master, grad, work, lr=1e-3, max_grad_norm=1.0, mode=args.optimizer_mode, bucket_bounds=bounds,
+                    exchange_dtype=torch.float32, **kw)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if use_gpu:
+            torch.cuda.synchronize()
+    steps = max(1, args.steps)
+    sync()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        grad.copy_(grad_of(rank, s))
+        for bi in range(len(opt.buckets) - 1, -1, -1):        # the order the backward's layer hook launches them in
+            opt.launch_bucket(bi)
+        opt.step()
+        opt.zero_grad()
+    sync()
+    dt = time.perf_counter() - t0
+    # 1-rank step on the rank-averaged gradient (the parity definition of SURVEY.md §8e), on the host
+    m1, w1 = p0.clone(), p0.to(torch.bfloat16)
+    ref = FlatAdamW(m1, torch.zeros(numel), w1, lr=1e-3, max_grad_norm=1.0, mode="allreduce", local_only=True, **kw)
+    for s in range(steps):
+        ref.grad.copy_(sum(grad_of(r, s) for r in range(world)))
+        ref.step(grad_accum_div=world)
+    err = float((work.float().cpu() - w1.float()).abs().max())
+    tt = torch.tensor([dt, -dt, err], dtype=torch.float64, device=dev)
+    seen, same = [{"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local) if use_gpu else "cpu"}], True
+    ones = 1.0
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local) if use_gpu else "cpu"})
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        ones = float(probe)
+        chk = [torch.empty_like(work) for _ in range(world)]
+        dist.all_gather(chk, work)
+        same = all(torch.equal(chk[0], c) for c in chk[1:])
+    ok = same and float(tt[2]) <= 2.0 ** -7 * float(p0.abs().max()) and ones == world
+    out = None
+    if rank == 0:
+        out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": None, "unit": "pairs/s", "n_gpus": world,
+               "steps": steps, "warmup": 0, "ms_per_step": float(tt[0]) / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True,
+               "config": {"workload": f"DRY RUN (no kernels): launcher + rendezvous + bucketed {args.optimizer_mode} exchange of a {numel}-element "
+                                      f"flat LoRA buffer ({args.model} layout, {len(opt.buckets)} buckets) with torch stand-ins for the update kernels",
+                          "parallelism": f"dp{world}"},
+               "dist": {"backend": backend if world > 1 else None, "world_size": world, "allreduce_of_ones": ones, "ranks": seen,
+                        "ms_per_step_min_over_ranks": -float(tt[1]) / steps * 1e3, "ms_per_step_max_over_ranks": float(tt[0]) / steps * 1e3,
+                        "replicas_identical_after_step": same, "max_abs_diff_vs_1_rank_step_on_averaged_gradient": float(tt[2]), "self_check": ok},
+               "roofline": None, "cpu_baseline": None}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return 0 if ok else 3
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -313,7 +442,16 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true", help="skip the dense-batch and exchange-overlap sub-records (measured after the timed region)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / exchange self-check without kernels (gloo on a box with fewer GPUs than ranks)")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"], help="--dry-run only: force the process-group backend")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher environment: start the ranks ourselves (the driver calls `python bench.py --gpus N` the same way as for N = 1)
+        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): nothing to launch "
+                  "(--dry-run exercises the launcher and the exchange on gloo / CPU)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     pack = not args.no_pack
     if args.pairs <= 0:
         args.pairs = (22 if pack else 15) if args.model != "13b" else (12 if pack else 8)      # 13B: activations of 12 packed pairs fit the 288 GB
@@ -321,7 +459,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        sys.stdout.flush()
+        rc = dry_run(args, world, rank, local)
+        sys.stdout.flush()
+        os.dup2(2, 1)
+        sys.exit(rc)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("OPADPO_FORCE_COLLECTIVES") == "1":
@@ -447,8 +593,40 @@ def main():
         dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local)})
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                       # sum of ones over RCCL = number of ranks in the communicator
+        tmin = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(probe), "ranks": seen,
+                    "ms_per_step_min_over_ranks": float(tmin) / args.steps * 1e3, "ms_per_step_max_over_ranks": float(tmax) / args.steps * 1e3,
                     "exchange": f"{args.optimizer_mode}: per-bucket {'reduce_scatter + all_gather' if args.optimizer_mode == 'zero1' else 'all_reduce'} of the flat LoRA gradient, launched from the backward's layer hook"}
+        if not args.no_side_legs:
+            # what the exchange costs a step at THIS world size: the same step on the same pool with a collective-free optimizer
+            # (every rank updates its own replica, nothing on the wire), barrier-bracketed, max over ranks both ways
+            try:
+                def timed_all(n_warm, n, **kw):
+                    for _ in range(n_warm):
+                        step(**kw)
+                    sync()
+                    t0_ = time.perf_counter()
+                    for _ in range(n):
+                        step(**kw)
+                    sync()
+                    t_ = torch.tensor([time.perf_counter() - t0_], device=dev)
+                    dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                    return float(t_) / n
+                n_ab = max(4, min(8, len(main_pool)))
+                step_no[0] = 0
+                t_with = timed_all(1, n_ab)
+                m_local = pol_ad.master if getattr(pol_ad, "master", None) is not None else pol_ad.work.float()
+                opt_l = FlatAdamW(m_local, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode="allreduce", local_only=True)
+                step_no[0] = 0
+                t_without = timed_all(1, n_ab, opt=opt_l, hook=lambda layer: None)
+                dist_rec["exposed_exchange"] = {"steps": n_ab, "ms_per_step_with_collectives": t_with * 1e3, "ms_per_step_without": t_without * 1e3,
+                                                "exposed_ms_per_step": (t_with - t_without) * 1e3, "frac_of_step": (t_with - t_without) / t_without,
+                                                "wire_bytes_per_rank_GB": 2 * (world - 1) / world * 2 * pol_ad.numel / 1e9,
+                                                "note": "same batches both ways; 'without' = replicated local update, no collective (the replicas diverge: timing only, measured after the timed region)"}
+                del opt_l
+            except Exception as e:
+                dist_rec["exposed_exchange"] = {"error": repr(e)}
     dt = float(tmax)
     pairs_per_step = args.pairs * args.accum * world
     value = pairs_per_step * args.steps / dt

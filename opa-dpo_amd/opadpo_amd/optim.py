@@ -99,9 +99,11 @@ class FlatAdamW:
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, max_grad_norm: Optional[float] = 1.0,
                  mode: str = "allreduce", group=None, sumsq_fn: Callable = hip_sumsq, adamw_fn: Callable = hip_adamw,
                  cast_fn: Callable = hip_cast, bucket_bounds: Optional[Sequence[int]] = None,
-                 exchange_dtype: Optional[torch.dtype] = None, align: int = 256):
+                 exchange_dtype: Optional[torch.dtype] = None, align: int = 256, local_only: bool = False):
         """bucket_bounds: ascending cut points [0, ..., numel] of the flat buffer (whole decoder layers, see
-        `layer_buckets`); None = one bucket.  exchange_dtype: dtype on the wire of the zero1 reduce-scatter (default bf16)."""
+        `layer_buckets`); None = one bucket.  exchange_dtype: dtype on the wire of the zero1 reduce-scatter (default bf16).
+        local_only: ignore an initialised process group (no collective, replicated update): the collective-free leg of bench.py's
+        exposed-exchange A/B at world > 1."""
         assert mode in ("allreduce", "zero1")
         self.master, self.grad, self.work = master, grad, work_bf16
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -109,11 +111,11 @@ class FlatAdamW:
         self.mode = mode
         self.group = group
         self.sumsq_fn, self.adamw_fn, self.cast_fn = sumsq_fn, adamw_fn, cast_fn
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() and not local_only else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         # OPADPO_FORCE_COLLECTIVES=1 (diagnostics / 1-GPU timing of the exchange): run the collective code path in a 1-rank group
-        self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
-                                                and os.environ.get("OPADPO_FORCE_COLLECTIVES") == "1")
+        self._collective = not local_only and (self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                                                   and os.environ.get("OPADPO_FORCE_COLLECTIVES") == "1"))
         n = master.numel()
         self.numel = n
         self.sharded = mode == "zero1" and self._collective
