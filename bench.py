@@ -443,11 +443,11 @@ def main():
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / exchange self-check without kernels (gloo on a box with fewer GPUs than ranks)")
-    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"], help="--dry-run only: force the process-group backend")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"], help="force the process-group backend (gloo: --dry-run on CPU, or the one-device test of the N > 1 path)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # no launcher environment: start the ranks ourselves (the driver calls `python bench.py --gpus N` the same way as for N = 1)
-        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        if not args.dry_run and torch.cuda.device_count() < args.gpus and os.environ.get("OPADPO_BENCH_SHARE_DEVICE") != "1":
             print(f"[bench] --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): nothing to launch "
                   "(--dry-run exercises the launcher and the exchange on gloo / CPU)", file=sys.stderr)
             sys.exit(2)
@@ -468,6 +468,9 @@ def main():
         sys.stdout.flush()
         os.dup2(2, 1)
         sys.exit(rc)
+    share = os.environ.get("OPADPO_BENCH_SHARE_DEVICE") == "1"      # tests only: every rank on cuda:0 (RCCL refuses two ranks per device: gloo wire)
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or os.environ.get("OPADPO_FORCE_COLLECTIVES") == "1":
@@ -475,7 +478,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share or args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from opadpo_amd import lib as L
     from opadpo_amd.dims import LlavaDims, lora_param_count, pair_flops, pair_flops_packed
