@@ -470,12 +470,43 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ int vswz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }
 
+// Byte offset of 16-byte chunk c16 of row `row` in the 32-rows-per-wave kernels' [64][128] tiles.  Two access patterns meet here:
+//  * transposing reads (ds_read_b64_tr_b16, serviced per 32-lane half): four rows x 64 contiguous bytes -> the 32-byte slot is XOR-ed with
+//    vswz(row), which sends the four rows of a half to four different 64-byte segments of the 256-byte bank row;
+//  * row fragments (ds_read_b128, lane = row & 31, chunk = 2 ks + (lane >> 5)): the hardware services a b128 read in the four 16-lane
+//    groups {0-3,12-15,20-27} {4-11,16-19,28-31} {32-35,...} {36-43,...} (MI355X_MICROARCH.md LDS table), i.e. 16 ROWS at one chunk
+//    parity per group.  A swizzle of row & 7 alone leaves only 8 distinct chunks for them - a 2-way conflict on every fragment read,
+//    measured in round 3 as SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 24 % (forward) and 32 % (dQ).  In each of those groups the two rows with
+//    equal row & 7 differ in bit 4 of the row, so with FLIP the chunk's low bit is XOR-ed with (row >> 4) & 1: 16 lanes -> 16 chunks.
+// FLIP is used for tiles that are ONLY read as row fragments (the forward's K tile has its own kswz32 form, the dQ kernel's V tile uses
+// off32<true>): there the flip is a per-lane constant.  For a tile that is also read through the transposing reads (dQ's K tile) bit 4 of
+// the row is a compile-time term of the read address, every (slot, flip) pair wants its own address register, and attn_bwd_dq32_kernel -
+// 254 VGPRs - starts to spill (measured: conflicts 32 % -> 0.3 %, kernel 4.5 % SLOWER); that tile keeps the plain layout.
+template <bool FLIP>
+__device__ __forceinline__ int off32(int row, int c16) {
+  return row * 256 + (((((c16 >> 1) ^ vswz(row)) << 1) | ((FLIP ? (c16 ^ (row >> 4)) : c16) & 1)) << 4);
+}
+
+// the dQ kernel's V tile: with the flip its row-read offsets differ from the K tile's (which cannot take it, above) and the second set of
+// eight address registers spills too (60 bytes of scratch per lane, measured slower) - both tiles keep ONE set of offsets, no flip
+constexpr bool DQ32_VFLIP = false;
+template <bool FLIP = false>
 __device__ __forceinline__ void tile_commit_v(char* dst, const TileRegs<128>& r, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + i * 256;
     const int row = idx >> 4, c16 = idx & 15;
-    *(u32x4_t*)(dst + row * 256 + (((((c16 >> 1) ^ vswz(row)) << 1) | (c16 & 1)) << 4)) = r.v[i];
+    *(u32x4_t*)(dst + off32<FLIP>(row, c16)) = r.v[i];
+  }
+}
+// K tile of the forward (row fragments only): chunk ^= ((row & 7) << 1) | ((row >> 4) & 1), conflict-free for the b128 lane groups above
+__device__ __forceinline__ int kswz32(int row) { return ((row & 7) << 1) | ((row >> 4) & 1); }
+__device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 4, c16 = idx & 15;
+    *(u32x4_t*)(dst + row * 256 + ((c16 ^ kswz32(row)) << 4)) = r.v[i];
   }
 }
 
@@ -543,12 +574,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   TileRegs<HD> kreg, vreg;
   tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
   tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
-  tile_commit<HD>(smem, kreg, tid);
+  tile_commit_k32(smem, kreg, tid);
   tile_commit_v(smem + TILE, vreg, tid);
   stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   int cur = 0;
-  const int krow_off = ql * 256;                          // K fragment: row kb*32 + ql, 16-byte chunk ks*2 + hi, swizzle (row & 7) << 1
-  const int kswz = (ql & 7) << 1;
+  const int krow_off = ql * 256;                          // K fragment: row kb*32 + ql, 16-byte chunk ks*2 + hi, swizzle kswz32(row) (bit 4 of the row = bit 4 of ql)
+  const int kswz = kswz32(ql);
   const int a4 = lane & 15, vgrp = (lane >> 4) & 1;       // V fragment (transpose read): lane a of a 16-lane group addresses row a >> 2, columns (a & 3) * 4
   for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
     nxt = sk.next(kt);
@@ -648,15 +679,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           for (int db = 0; db < 4; ++db) {
             const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;      // 16-byte chunk of column db*32 + vgrp*16 + (a & 3)*4, byte inside it
             union { bf16x8_t v; s16x4_t hh[2]; } vf;
-            vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r0 * 256 + (((((c16 >> 1) ^ vswz(r0)) << 1) | (c16 & 1)) << 4) + sub));
-            vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + r1 * 256 + (((((c16 >> 1) ^ vswz(r1)) << 1) | (c16 & 1)) << 4) + sub));
+            vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r0, c16) + sub));
+            vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r1, c16) + sub));
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
           }
         }
     }
     if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
       char* const nb = smem + (cur ^ 1) * 2 * TILE;
-      tile_commit<HD>(nb, kreg, tid);
+      tile_commit_k32(nb, kreg, tid);
       tile_commit_v(nb + TILE, vreg, tid);
       stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
     }
@@ -1045,7 +1076,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 //   dS^T = P^T * (dP^T - delta) * scale, P^T = exp2(S^T * scale2 - lse2)      (lane (q, hi) holds keys kb*32 + 8b + 4hi + (0..3))
 //   dQ^T[d][q] += K^T[d][key] . dS^T[key][q]     A = K fragment through two ds_read_b64_tr_b16 at exactly those key rows, B = dS^T from
 //                                                 the accumulators (v_cvt_pk_bf16_f32) - the forward's P . V trick
-// K and V tiles both live in the vswz layout (conflict-free for the row reads AND the transposing reads), double-buffered ring,
+// K tile in the off32<false> layout (transposing reads conflict-free, row reads 2-way), V tile in off32<true> (row reads only: conflict-free), double-buffered ring,
 // register-staged, one barrier per tile; one 32-key block at a time so that S and dP cost 32 registers, not 64.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1098,12 +1129,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
   TileRegs<HD> kreg, vreg;
   tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
   tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
-  tile_commit_v(smem, kreg, tid);
-  tile_commit_v(smem + TILE, vreg, tid);
+  tile_commit_v<false>(smem, kreg, tid);
+  tile_commit_v<DQ32_VFLIP>(smem + TILE, vreg, tid);
   stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   int cur = 0;
   const int a4 = lane & 15, vgrp = (lane >> 4) & 1;
-  auto row_off = [&](int row, int c16) { return row * 256 + (((((c16 >> 1) ^ vswz(row)) << 1) | (c16 & 1)) << 4); };
+  auto row_off = [&](int row, int c16) { return off32<false>(row, c16); };      // K tile: row fragments AND transposing reads
+  auto row_off_v = [&](int row, int c16) { return off32<DQ32_VFLIP>(row, c16); };     // V tile: row fragments only
   for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
     nxt = sk.next(kt);
     const int k0 = kt * 64;
@@ -1145,7 +1177,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           const bf16x8_t kf = *(const bf16x8_t*)(Ks + row_off(krow, ks * 2 + hi));
-          const bf16x8_t vf = *(const bf16x8_t*)(Vs + row_off(krow, ks * 2 + hi));
+          const bf16x8_t vf = *(const bf16x8_t*)(Vs + row_off_v(krow, ks * 2 + hi));
           sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
         }
@@ -1175,8 +1207,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
     }
     if (nxt < n_kt) {
       char* const nb = smem + (cur ^ 1) * 2 * TILE;
-      tile_commit_v(nb, kreg, tid);
-      tile_commit_v(nb + TILE, vreg, tid);
+      tile_commit_v<false>(nb, kreg, tid);
+      tile_commit_v<DQ32_VFLIP>(nb + TILE, vreg, tid);
       stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
     }
     cur ^= 1;

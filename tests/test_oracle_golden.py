@@ -125,6 +125,50 @@ def test_clip_against_hf(golden_dir):
     np.testing.assert_allclose(feats, g["feats"], rtol=2e-4, atol=2e-4)
 
 
+def _lora_pin(g):
+    d = _tiny_dims()
+    W = LR.init_weights(d, seed=int(g["seed"]), std=float(g["std"]))
+    lora = LR.init_lora(d, seed=int(g["lora_seed"]), b_std=float(g["lora_b_std"]), with_vision=True)
+    return d, W, lora
+
+
+def test_unmerged_lora_path_against_hf_llama_with_merged_weights(golden_dir):
+    """Round-3 gap: the LoRA arithmetic y = x W^T + (alpha/r) (x A^T) B^T of oracle.llava_ref._Ctx.linear was checked against nothing but
+    itself.  Pin: the installed transformers Llama loaded with W + (alpha/r) B A (merged with plain torch in tests/golden/make_lora_pins.py,
+    not with oracle.merge_llm_lora) must give the logits of the oracle's UNMERGED path; the adapter moves the logits by O(1)."""
+    g = load(golden_dir, "hf_llama_lora.npz")
+    d, W, lora = _lora_pin(g)
+    ids, mask = t(g["ids"]), t(g["mask"]).bool()
+    x = W["model.embed_tokens.weight"][ids]
+    logits = LR.lm_logits(LR.llama_decoder(x, mask, W, lora, d), W, d).numpy()
+    valid = g["mask"].astype(bool)
+    effect = np.abs(g["logits"][valid] - g["logits_without_adapter"][valid]).mean()
+    assert effect > 0.05, effect                                   # the pin would be vacuous with a negligible adapter
+    np.testing.assert_allclose(logits[valid], g["logits"][valid], rtol=3e-4, atol=3e-4)
+    # ... and the oracle's own merge (the form the build's frozen reference adapter takes) is the same function
+    Wm, rest = LR.merge_llm_lora(W, lora, d)
+    logits_m = LR.lm_logits(LR.llama_decoder(x, mask, Wm, rest, d), Wm, d).numpy()
+    np.testing.assert_allclose(logits_m[valid], g["logits"][valid], rtol=3e-4, atol=3e-4)
+
+
+def test_vision_lora_path_against_hf_clip_with_merged_weights(golden_dir):
+    g = load(golden_dir, "hf_clip_lora.npz")
+    d, W, lora = _lora_pin(g)
+    feats = LR.vision_tower(t(g["pixels"]), W, lora, d).numpy()
+    plain = LR.vision_tower(t(g["pixels"]), W, None, d).numpy()
+    assert np.abs(feats - plain).mean() > 0.02
+    np.testing.assert_allclose(feats, g["feats"], rtol=3e-4, atol=3e-4)
+
+
+def test_projector_against_nn_sequential(golden_dir):
+    """mlp2x_gelu = nn.Sequential(Linear, GELU(erf), Linear) as upstream LLaVA builds it, plain and with the LoRA pairs merged."""
+    g = load(golden_dir, "nn_projector.npz")
+    d, W, lora = _lora_pin(g)
+    np.testing.assert_allclose(LR.projector(t(g["x"]), W, None, d).numpy(), g["plain"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(LR.projector(t(g["x"]), W, lora, d).numpy(), g["lora"], rtol=1e-4, atol=1e-4)
+    assert np.abs(g["lora"] - g["plain"]).mean() > 0.02
+
+
 def test_accum_arith_and_schedule():
     # opadpo_train.py:383-433 with the shipped script values at WORLD_SIZE=4 (SURVEY.md §8c G9)
     assert D.grad_accum_arith(64, 32, 2, 2, 4) == (8, 4)
