@@ -288,7 +288,7 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest);
  * bit 8 = the 16-rows-per-wave attention forward and dQ kernels (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
- * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked from 2 GiB of fp32 logits);
+ * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked when the fp32 logits of the batch shape S*K*T reach 4 GiB);
  * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */

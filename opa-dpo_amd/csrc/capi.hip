@@ -137,7 +137,8 @@ int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
                     float* lse, const uint8_t* key_mask, int S_, int L, int nh, int hd, int causal, float scale,
                     int seg_prefix, int seg_len, void* stream) {
   if (hd != 64 && hd != 128) return bad("opadpo_attn_fwd", "head_dim must be 64 or 128");
-  if (!q || !k || !v || !o || ld % 8 || ldo % 4) return bad("opadpo_attn_fwd", "null operand or misaligned leading dimension");
+  // head_dim 128 runs the 32-rows-per-wave kernel, which writes O (also the zeros of an all-padding tile) as 16-byte pieces: ldo % 8
+  if (!q || !k || !v || !o || ld % 8 || ldo % (hd == 128 ? 8 : 4)) return bad("opadpo_attn_fwd", "null operand or misaligned leading dimension (ld % 8, ldo % 8 at head_dim 128, ldo % 4 at 64)");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.key_mask = key_mask;

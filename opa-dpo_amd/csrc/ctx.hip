@@ -489,7 +489,10 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
     with_rope(g2);
     if ((e = run_gemm(c, g2, st)) != hipSuccess) return e;
   }
-  if (!fuse_rope && (e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st, rg ? rg->row_pos : nullptr)) != hipSuccess) return e;
+  // ragged passes that are too small (or too odd) for the fused epilogue rotate with the SAME table-free angles and arithmetic: the bits of a
+  // row's q / k do not depend on the size of the batch around it, and the backward (always table-free on ragged rows) is the exact transpose
+  if (!fuse_rope && (e = launch_rope(b.qkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 0, nullptr, seg0, seg1, st, rg ? rg->row_pos : nullptr,
+                                     rg ? log2f(d.rope_theta) : 0.f)) != hipSuccess) return e;
   if (kc) {                                        // rollout prefill: post-RoPE k, v -> head-major KV cache
     hipLaunchKernelGGL(kv_fill_kernel, dim3(std::min<size_t>(4096, ((size_t)M * nh * (hd / 8) + 255) / 256)), dim3(256), 0, st, b.qkv, kc, vc, S, Lp, nh, hd, max_ctx);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -823,13 +826,16 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   } else {
     sv->Rc = sv->R;
   }
-  // chunked head: automatically from 2 GiB of fp32 logits (K = 3 responses at T = 896, large rollout batches: the buffer and its bf16
-  // gradient scale with every valid token); context flag (use_tr) bit 9 forces it for any size, bit 10 switches it off.  Same-box A/B at
-  // the benchmark's 22 pairs (1.27 GB of logits): chunked 977.2 ms / 217.9 GB, un-chunked 972.9 ms / 220.2 GB per step - below the
-  // threshold the one-buffer form is kept (the recomputed lm_head GEMM and 8 short launches cost 0.4 %)
+  // chunked head: automatically when the fp32 logits of the batch SHAPE (S * K * T head rows, padding included) reach 4 GiB (K = 3 responses at
+  // T = 896, large rollout batches); context flag (use_tr) bit 9 forces it for any size, bit 10 switches it off.  The decision is a function
+  // of the shape of the pass, not of how many of its cells are padding (round 3 compared the ragged row count Rc with 2 GiB: batches of one
+  // shape whose valid-token counts straddled the threshold alternated between two numerically different heads from step to step, and the
+  // reference and policy passes of one step could differ).  Same-box A/B at the benchmark's 22 pairs (2.16 GB in this measure, 1.27 GB of
+  // valid rows): chunked 977.2 ms / 217.9 GB, un-chunked 972.9 ms / 220.2 GB per step - below the threshold the one-buffer form is kept (the
+  // recomputed lm_head GEMM and 8 short launches cost 0.4 %)
   {
     const int ut = c->use_tr >= 0 ? c->use_tr : 0;
-    const bool want = (ut & 512) || (!(ut & 1024) && (size_t)std::max(sv->Rc, 1) * d.vocab * sizeof(float) >= ((size_t)2 << 30));
+    const bool want = (ut & 512) || (!(ut & 1024) && (size_t)std::max(S * K * T, 1) * d.vocab * sizeof(float) >= ((size_t)4 << 30));
     sv->head_chunk = (want && d.vocab > 4096) ? 4096 : 0;
   }
   sv->bytes = saved_layout(d, sv, nullptr);
@@ -1080,7 +1086,8 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     const bool fuse_rope_bwd = sv->ragged && !(c->use_tr >= 0 && (c->use_tr & 2048));
     if (fuse_rope_bwd) { a.rope_pos = sv->row_pos; a.rope_l2theta = log2f(d.rope_theta); }
     CK(launch_attn_bwd(a, st));
-    if (!fuse_rope_bwd) CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr));
+    if (!fuse_rope_bwd) CK(launch_rope(dqkv, 3 * H, c->cosb, c->sinb, M, Lp, 2 * nh, hd, 1, nullptr, sv->seg_prefix, sv->seg_len, st, sv->ragged ? sv->row_pos : nullptr,
+                                       sv->ragged ? log2f(d.rope_theta) : 0.f));
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r, M));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0, M));

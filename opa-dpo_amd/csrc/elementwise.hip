@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
 // forward: x' = x*cos + rot(x)*sin ; inverse (gradient): g' = g*cos - rot(g)*sin  with rot(x) = [-x2, x1]
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const float* cosb, const float* sinb,
                                                     size_t total, int L, int n_heads, int hd, int inverse, const int32_t* pos_base,
-                                                    int seg_prefix, int seg_len, const int32_t* row_pos) {
+                                                    int seg_prefix, int seg_len, const int32_t* row_pos, float l2theta) {
   const int half = hd / 2;
   const int pos0 = pos_base ? pos_base[0] : 0;     // device-resident position offset (graph-replayed decode step)
   const int per_row = n_heads * (half / 8);     // 8 (x1,x2) pairs per thread
@@ -171,14 +171,31 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* qk, int ld, const flo
     float x1[8], x2[8];
     unpack8(*(const uint4*)(base + i0), x1);
     unpack8(*(const uint4*)(base + half + i0), x2);
-    const float* cp = cosb + (size_t)pos * half + i0;
-    const float* sp = sinb + (size_t)pos * half + i0;
     float o1[8], o2[8];
+    if (l2theta > 0.f) {
+      // TABLE-FREE angles (ragged context passes): the hardware sin / cos of the fractional revolution pos * theta^(-2i/hd) / 2pi - the angle
+      // definition of the q|k|v projection's rotary epilogue (gemm_nt_w4_kernel) and of the attention backward's inverse rotation, in the
+      // SAME arithmetic form as that epilogue (product, sign, fused multiply-add), so a pass that is too small for the fused epilogue
+      // rotates q / k to the same bits and the backward of every ragged pass is the transpose of its forward whatever its size
+      const float posf = (float)pos;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float c = cp[j], s = inverse ? -sp[j] : sp[j];
-      o1[j] = x1[j] * c - x2[j] * s;
-      o2[j] = x2[j] * c + x1[j] * s;
+      for (int j = 0; j < 8; ++j) {
+        const float frev = __builtin_amdgcn_exp2f(-(float)(2 * (i0 + j)) * (1.0f / (float)hd) * l2theta) * 0.15915494309189535f;
+        const float x = __builtin_amdgcn_fractf(posf * frev);
+        const float c = __builtin_amdgcn_cosf(x), s = inverse ? -__builtin_amdgcn_sinf(x) : __builtin_amdgcn_sinf(x);
+        const float t1 = x2[j] * s, t2 = x1[j] * s;
+        o1[j] = __builtin_fmaf(x1[j], c, -t1);
+        o2[j] = __builtin_fmaf(x2[j], c, t2);
+      }
+    } else {
+      const float* cp = cosb + (size_t)pos * half + i0;
+      const float* sp = sinb + (size_t)pos * half + i0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = cp[j], s = inverse ? -sp[j] : sp[j];
+        o1[j] = x1[j] * c - x2[j] * s;
+        o2[j] = x2[j] * c + x1[j] * s;
+      }
     }
     *(uint4*)(base + i0) = pack8(o1);
     *(uint4*)(base + half + i0) = pack8(o2);
@@ -601,11 +618,12 @@ hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_
   return hipGetLastError();
 }
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos) {
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos, float l2theta) {
   if (rows <= 0) return hipSuccess;
   if (hd % 16) return hipErrorInvalidValue;
+  if (l2theta > 0.f && !row_pos) return hipErrorInvalidValue;      // table-free angles need the per-row positions
   const size_t total = (size_t)rows * n_heads * (hd / 16);
-  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len, row_pos);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total)), dim3(256), 0, st, qk, ld, cosb, sinb, total, L, n_heads, hd, inverse, pos_base, seg_prefix, seg_len, row_pos, l2theta);
   return hipGetLastError();
 }
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {

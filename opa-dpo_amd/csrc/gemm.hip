@@ -896,7 +896,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 }
 
 template <bool ORDER_B, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_tiles) {
+__global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_tiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1044,8 +1044,14 @@ __global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_ti
     });
     W4_PIN();
     if constexpr (has_next) {
-      if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (decltype(FIRST)::value) {
+        // behind the previous tile's stores: only the 3 pieces issued BEFORE them must have landed (in-order retirement)
+        if (dbg & 2) { if constexpr (OUT_F32) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      } else {
+        if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       W4_PIN(); mfma_run(IC(1), IC(35), IC(1), FIRST); W4_PIN();
       __builtin_amdgcn_s_barrier();            // the next K-tile of the stream has landed for everyone
     } else {
@@ -1130,7 +1136,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_ti
     for (int t = 1; t < nt; ++t) { tile_body(par, T_{}, T_{}, F_{}); par ^= 1; }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> accumulator reads
     W4_PIN();
-    store_tile(c_m0, c_n0);
+    if (!(dbg & 1)) store_tile(c_m0, c_n0);
     W4_PIN();
     // the DMA side opened the next tile two K-tiles ago and cannot leave it before that tile's K-tile nt-3: its origin is the next compute tile
     c_m0 = d_m0; c_n0 = d_n0;
@@ -2083,7 +2089,8 @@ static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B fir
 // persistent form (gemm_nt_w4p_kernel) for direct-epilogue problems of more than one round of tiles: 256 workgroups walk the tile list.
 // OPADPO_W4P=0 keeps one tile per workgroup (A/B); variant 31 (the tests' bit-for-bit cross-check) never takes it.
 static int g_w4p = -1;
-#define W4P_GO(OB_, F32_) hipLaunchKernelGGL((gemm_nt_w4p_kernel<OB_, F32_>), dim3(256), dim3(256), 2 * P_STAGE, st, a, (int)tiles_)
+static int g_w4p_dbg = -1;
+#define W4P_GO(OB_, F32_) hipLaunchKernelGGL((gemm_nt_w4p_kernel<OB_, F32_>), dim3(256), dim3(256), 2 * P_STAGE, st, a, (int)tiles_, g_w4p_dbg)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
     const int tiles_ = (int)(GRID_);                                                                                         \
@@ -2104,6 +2111,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   GemmNTArgs a = a_in;
   if (g_w4_order == -1) { const char* v = getenv("OPADPO_W4_ORDER"); g_w4_order = v ? atoi(v) : -2; }
   if (g_w4p == -1) { const char* v = getenv("OPADPO_W4P"); g_w4p = v ? atoi(v) : 1; }
+  if (g_w4p_dbg == -1) { const char* v = getenv("OPADPO_W4P_DBG"); g_w4p_dbg = v ? atoi(v) : 0; }
   // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
   // (N <= 4096: o / down and three of the four dgrads) - measured at M = 32362: down 1.363 -> 1.397 PF/s, o 1.394 -> 1.401,
   // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).

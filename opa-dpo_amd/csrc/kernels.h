@@ -26,7 +26,8 @@ struct GemmNTArgs {
   const float* rope_sin = nullptr;
   int rope_L = 0, rope_cols = 0, rope_seg_prefix = 0, rope_seg_len = 0;
   // table-free form (round 3): per-row positions (int32 [M], e.g. the ragged pass's row_pos) and log2(theta); the epilogue computes the
-  // angles itself (hardware sin / cos of the fractional revolution at the first row, angle-addition recurrence along position runs)
+  // angles itself: hardware sin / cos of the fractional revolution pos * theta^(-2i/128) / 2pi, evaluated per (row, frequency) - a function of
+  // those two numbers only (an angle-addition recurrence along the rows was tried and dropped: it made a row depend on its tile offset)
   const int32_t* rope_pos = nullptr;
   float rope_l2theta = 0.f;
   int group_m = 8;                      // row tiles per group of the grouped tile order (256x256 4-wave kernel)
@@ -111,7 +112,8 @@ hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t*
 hipError_t launch_act_fwd(const bf16_t* z, bf16_t* out, size_t n, int act, hipStream_t st);
 hipError_t launch_act_bwd(const bf16_t* dout, const bf16_t* z, bf16_t* dz, size_t n, int act, hipStream_t st);
 hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb, int rows, int L, int n_heads, int hd,
-                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos = nullptr);
+                       int inverse, const int32_t* pos_base, int seg_prefix, int seg_len, hipStream_t st, const int32_t* row_pos = nullptr,
+                       float l2theta = 0.f);      // l2theta > 0 (with row_pos): table-free angles, the fused rotary epilogue's definition
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st);
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st);
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,

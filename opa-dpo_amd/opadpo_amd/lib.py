@@ -109,7 +109,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python opa-dpo_amd/build.py` (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            # OPADPO_LIB_PATH may point at an OLDER build of the library (same-box A/B of two kernel versions): entry points added since
+            # are simply absent there - calling one raises at the call site; the shipped library must export everything
+            if os.environ.get("OPADPO_LIB_PATH"):
+                continue
+            raise OpadpoError(f"{LIB_PATH} does not export {name}: stale build? run `python opa-dpo_amd/build.py`")
         fn.argtypes = argtypes
         fn.restype = _i
     lib.opadpo_abi_version.restype = _i

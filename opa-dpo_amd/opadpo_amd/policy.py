@@ -92,7 +92,12 @@ class AutoregressivePolicy(torch.nn.Module):
         keys = response_keys(responses)
         if not keys:
             raise ValueError("no *response* tensors passed to the policy")
-        ck = (self.pack_responses, self.response_len) + tuple(
+        if (row_lead is None) != (row_lens is None):      # a plan is a (lead, lens) PAIR: half a plan is dropped, the other half derived with it
+            row_lead = row_lens = None
+        # the caller's row plan is part of the key (a SeqBatch built from one plan must not be handed out for another, or for none)
+        _tl = lambda x: tuple(x.tolist()) if hasattr(x, "tolist") else tuple(int(v) for v in x)      # host tensors / lists of S ints
+        plan_key = None if row_lead is None else (_tl(row_lead), tuple(_tl(row_lens[k]) for k in keys))
+        ck = (self.pack_responses, self.response_len, plan_key) + tuple(
             (t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in [queries, queries_attn_masks] + [responses[k] for k in keys])
         cache = self.engine.__dict__.setdefault("_batch_cache", {})
         hit = cache.get(ck)

@@ -185,7 +185,7 @@ def test_wide_7b_forward_is_bit_identical():
     torch.cuda.synchronize()
     assert torch.equal(out["chosen_response_logprobs"].detach(), res[1][0])
     assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-5
-    # CHUNKED head (default from 2 GiB of logits; bit 9 forces it): lm_head + online log-sum-exp + label gather + entropy over 4096
+    # CHUNKED head (default when the logits of the batch shape reach 4 GiB; bit 9 forces it): lm_head + online log-sum-exp + label gather + entropy over 4096
     # vocabulary columns at a time, logits recomputed chunk by chunk in the backward - no [rows, vocab] buffer.  Same function in another
     # fp32 association: log-probs / entropies to fp32 rounding, gradients to the bf16 rounding of d_hn (accumulated over the chunks in fp32)
     peak0 = cx._lib.opadpo_ctx_bytes_peak(cx.ctx)

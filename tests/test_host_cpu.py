@@ -140,8 +140,15 @@ def test_host_row_plan_and_ragged_batches():
         assert torch.equal(b2.row_plan[:, 0], fake[0] if pack else fake[0].repeat(2))
         # cache: same tensors under other names -> the caller's names, the cached batch
         other = {"mask_standard_response": resp["chosen_response"], "mask_AI_pseudo_response": resp["rejected_response"]}
-        keys3, b3 = pol.build_batch(q, qm, other)
+        fake_other = {"mask_standard_response": fake[1]["chosen_response"], "mask_AI_pseudo_response": fake[1]["rejected_response"]}
+        keys3, b3 = pol.build_batch(q, qm, other, fake[0], fake_other)
         assert keys3 == list(other) and b3 is b2
+        # ... but the row plan is part of the key: the same tensors WITHOUT a plan (or with another one) get their own batch
+        _, b4 = pol.build_batch(q, qm, other)
+        assert b4 is not b2 and torch.equal(b4.row_plan, want)
+        # half a plan is no plan: lead without lens falls back to the derived plan instead of failing on None
+        _, b5 = pol.build_batch(q, qm, other, fake[0], None)
+        assert b5 is b4
         eng.__dict__.pop("_batch_cache", None)
 
 
