@@ -248,6 +248,40 @@ def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
                         "one C++ launch loop per token inside the context (opadpo_decode_run)", "bound": "hbm", "peak_GBps": 8000.0, **out}
 
 
+def extra_config(which):
+    """Sub-records of the default line for the BASELINE.json configurations the headline does not cover (measured AFTER the timed region,
+    in a child process on the same GPU; never part of `value`):
+      thirteen_b : configs[3]'s model at 1 GPU - LLaVA-1.5-13B LoRA DPO, 12 packed pairs per step, 3 timed steps (this file, --model 13b);
+      recipe     : the reference's NATIVE unit at the shipped recipe's lengths (run/train_opa_dpo.sh:39-50: query 128, response 896, 3 responses
+                   per sample + 2 on the CoPO-masked image, AncPO; DPOTrainer.step() of the product, tools/sample_bench.py) - samples/s."""
+    import subprocess
+    env = dict(os.environ)
+    try:
+        if which == "thirteen_b":
+            cmd = [sys.executable, os.path.abspath(__file__), "--model", "13b", "--steps", "3", "--warmup", "1", "--batch-pool", "3",
+                   "--no-cpu-baseline", "--no-rollout", "--no-side-legs", "--no-exchange-probe", "--no-extra-configs"]
+        else:
+            cmd = [sys.executable, os.path.join(REPO, "tools", "sample_bench.py")]
+            env.update(SB_T="896", SB_BATCH=env.get("OPADPO_BENCH_RECIPE_BATCH", "4"), SB_STEPS="3")
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc={r.returncode}", "stderr_tail": r.stderr[-400:]}
+        j = json.loads(lines[-1])
+        if which == "thirteen_b":
+            return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                    "pairs_per_step": j["config"]["global_pairs_per_step"], "roofline_frac": j["roofline"]["frac"] if j.get("roofline") else None,
+                    "gemm_nt_TFLOPs": j["roofline"]["achieved"] if j.get("roofline") else None,
+                    "executed_flops_per_pair_TF": j["executed_flops_per_pair_TF"], "mfma_roofline_frac_end_to_end": j["mfma_roofline_frac_end_to_end"],
+                    "hbm_peak_allocated_GB": j["hbm_peak_allocated_GB"], "child_wall_s": time.time() - t0}
+        return {"workload": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j.get("steps"),
+                "samples_per_step": j["samples_per_step"], "response_layout": j["response_layout"], "sequence_forwards_per_sample": j["sequence_forwards_per_sample"],
+                "hbm_peak_allocated_GB": j["hbm_peak_allocated_GB"], "child_wall_s": time.time() - t0}
+    except Exception as e:  # a side record never costs the headline
+        return {"error": repr(e)}
+
+
 def exchange_probe(numel, dev, layer_numel, n_layers):
     """1-rank timing of the data-parallel exchange path of one optimizer step on THIS GPU (no multi-GPU node is
     visible to this run): the fp32 -> bf16 staging casts, the per-bucket reduce-scatter and the per-bucket all-gather of FlatAdamW
@@ -442,6 +476,7 @@ def main():
     ap.add_argument("--no-side-legs", action="store_true", help="skip the dense-batch and exchange-overlap sub-records (measured after the timed region)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `thirteen_b` (BASELINE.json configs[3] at 1 GPU) and `recipe` (the reference's native unit: 3 responses, response_len 896, CoPO) sub-records (each runs in a child process after the 7B state is released)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / exchange self-check without kernels (gloo on a box with fewer GPUs than ranks)")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"], help="force the process-group backend (gloo: --dry-run on CPU, or the one-device test of the N > 1 path)")
     args = ap.parse_args()
@@ -752,6 +787,11 @@ def main():
                     t_with = timed(2, n_ab, opt=opt2, hook=make_hook(opt2))
                     step_no[0] = 0
                     t_without = timed(2, n_ab)
+                    if out.get("roofline"):      # what the in-step HIP-event profiling of the timed region costs: same pool, events off
+                        out["roofline"]["event_profiling"] = {"events_in_timed_region_per_step": 2 * out["roofline"]["launches"] // max(1, args.steps),
+                                                             "ms_per_step_same_pool_without_events": t_without * 1e3,
+                                                             "note": "the timed region (ms_per_step, value) brackets every gemm_nt launch with two HIP events; "
+                                                                     "the same pool timed without them afterwards"}
                     out["exchange_overlap"] = {"world": 1, "buckets": len(opt2.buckets), "steps": n_ab,
                                                "ms_per_step_with_inline_collectives": t_with * 1e3, "ms_per_step_without": t_without * 1e3,
                                                "overlapped_step_delta_ms": (t_with - t_without) * 1e3,
@@ -793,6 +833,15 @@ def main():
                     out["rollout"] = rollout_leg(eng, d, dev)
                 except Exception as e:
                     out["rollout"] = {"error": repr(e)}
+            if not args.no_extra_configs:
+                # the other BASELINE.json configurations, in the driver's line: each in a CHILD process on the same GPU after this
+                # process has given its memory back (a 13B model next to the 7B state does not fit; the child pays its own import + init)
+                del eng, base
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                out["thirteen_b"] = extra_config("thirteen_b")
+                out["recipe"] = extra_config("recipe")
     else:
         out = None
     if dist.is_initialized():

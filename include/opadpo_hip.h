@@ -112,6 +112,15 @@ int opadpo_gemm_tn(const uint16_t* P, int ldp, const uint16_t* Q, int ldq, float
  * (N1, N2, q_group_n1 % 256) make the call fall back to n single launches. */
 int opadpo_gemm_tn_group(int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C, const int* ldc,
                          int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha, void* stream);
+/* DETERMINISTIC form (round 4; what opadpo_seq_logprobs_bwd uses): a workgroup's partial tiles go to `workspace` as plain stores and a
+ * second launch adds the partial tiles of every output tile in a fixed order - no fp32 atomics, C bit-reproducible run to run (accelerate /
+ * PEFT gradients of the reference are deterministic too unless cuBLAS split-K is in play; dpo_trainer.py:847-849 accumulates them in place).
+ * The problems must all run on the 256x256 kernel (N1, N2, q_group_n1 % 256 == 0); `_workspace_bytes` returns 0 otherwise.  The workspace
+ * is scratch: free again when the call's kernels have run (stream order). */
+size_t opadpo_gemm_tn_group_workspace_bytes(int n, int M, const int* N1, const int* N2, const int* q_group_n1);
+int opadpo_gemm_tn_group_det(int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C, const int* ldc,
+                             int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention (flash-attn 2.5.3 LlamaFlashAttention2 / CLIP eager attention) -------------------
  * q,k,v: element (s,pos,head,d) at ptr[(s*L+pos)*ld + head*hd + d]; o/dout with ldo.
@@ -137,6 +146,9 @@ int opadpo_rmsnorm_fwd(const void* x, int x_f32, const uint16_t* w, uint16_t* y,
 int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint16_t* w, const float* rstd,
                        const void* dres, int dres_f32, float* dx_f32, uint16_t* dx_bf16, int rows, int H, void* stream);
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream);
+/* fp32 input (the CLIP tower's residual stream is fp32 in the DPO path, round 4); y bf16 (y_f32 = 0: the operand of the next GEMM) or fp32
+ * (y_f32 = 1: the pre-LayerNorm, whose output IS the residual stream) */
+int opadpo_layernorm_fwd_f32(const float* x, const uint16_t* w, const uint16_t* b, void* y, int y_f32, int rows, int H, float eps, void* stream);
 /* CLIP / projector training path (OPA LoRA-SFT stage, opadpo/opa_train.py: the vision tower and mm_projector carry trainable
  * LoRA there): LayerNorm backward w.r.t. x (affine parameters frozen; mean / rstd recomputed; dres nullable = residual-path
  * gradient, added), and the activation applied / differentiated on a stored PRE-activation tensor (act = OPADPO_ACT_*). */
@@ -164,6 +176,7 @@ int opadpo_embed_splice(const int32_t* ids, const uint8_t* text_mask, const uint
 /* ---- CLIP patch embedding (Conv2d k=s=patch as im2col + gemm_nt) ---------------------------------- */
 int opadpo_im2col(const uint16_t* pixels, uint16_t* out, int B, int image_size, int patch, int kpad, void* stream);
 int opadpo_vision_embed(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* x, int B, int P, int h, void* stream);
+int opadpo_vision_embed_f32(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, float* x, int B, int P, int h, void* stream);   /* fp32 x */
 
 /* ---- data movement helpers ---------------------------------------------------------------------- */
 int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx, uint16_t* dst, int n, int H, void* stream);
@@ -289,7 +302,8 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * bit 8 = the 16-rows-per-wave attention forward and dQ kernels (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
  * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked when the fp32 logits of the batch shape S*K*T reach 4 GiB);
- * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos) */
+ * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos);
+ * bit 12 = LoRA wgrads flushed with fp32 atomics (default: partial tiles to a workspace + ordered reduce, bit-reproducible gradients) */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);

@@ -133,6 +133,39 @@ int opadpo_gemm_tn_group(int n, const uint16_t* const* P, const int* ldp, const 
   return done(launch_gemm_tn_group(list, n, S(stream)), "opadpo_gemm_tn_group");
 }
 
+static int tn_group_list(const char* fn, GemmTNArgs* list, int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C,
+                         const int* ldc, int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha, bool shapes_only) {
+  if (n < 0 || n > 8 || (n && (!N1 || !N2 || (!shapes_only && (!P || !ldp || !Q || !ldq || !C || !ldc))))) return bad(fn, "0..8 problems, non-null arrays");
+  for (int i = 0; i < n; ++i) {
+    if (N1[i] <= 0 || N2[i] <= 0 || N1[i] % 128 || N2[i] % 128) return bad(fn, "N1/N2 must be positive multiples of 128");
+    GemmTNArgs& a = list[i];
+    a.M = M; a.N1 = N1[i]; a.N2 = N2[i];
+    a.q_group_n1 = q_group_n1 ? q_group_n1[i] : 0; a.q_group_stride = q_group_stride ? q_group_stride[i] : 0; a.alpha = alpha; a.splits = 0;
+    if (a.q_group_n1 && a.q_group_n1 % 128) return bad(fn, "q_group_n1 must be a multiple of 128");
+    if (shapes_only) { a.P = a.Q = nullptr; a.C = nullptr; a.ldp = N1[i]; a.ldq = N2[i] * (a.q_group_n1 ? N1[i] / a.q_group_n1 : 1); a.ldc = N2[i]; continue; }
+    if (!P[i] || !Q[i] || !C[i] || ldp[i] % 8 || ldq[i] % 8) return bad(fn, "null operand or misaligned leading dimension");
+    a.P = P[i]; a.Q = Q[i]; a.C = C[i]; a.ldp = ldp[i]; a.ldq = ldq[i]; a.ldc = ldc[i];
+  }
+  return 0;
+}
+
+size_t opadpo_gemm_tn_group_workspace_bytes(int n, int M, const int* N1, const int* N2, const int* q_group_n1) {
+  GemmTNArgs list[8];
+  if (M <= 0 || tn_group_list("opadpo_gemm_tn_group_workspace_bytes", list, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, N1, N2, q_group_n1, nullptr, 1.f, true)) return 0;
+  return gemm_tn_group_workspace_bytes(list, n);
+}
+
+int opadpo_gemm_tn_group_det(int n, const uint16_t* const* P, const int* ldp, const uint16_t* const* Q, const int* ldq, float* const* C, const int* ldc,
+                             int M, const int* N1, const int* N2, const int* q_group_n1, const int* q_group_stride, float alpha,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  GemmTNArgs list[8];
+  if (const int rc = tn_group_list("opadpo_gemm_tn_group_det", list, n, P, ldp, Q, ldq, C, ldc, M, N1, N2, q_group_n1, q_group_stride, alpha, false)) return rc;
+  const size_t need = gemm_tn_group_workspace_bytes(list, n);
+  if (need == 0) return bad("opadpo_gemm_tn_group_det", "these problems do not run on the 256x256 kernel (N1, N2, q_group_n1 % 256): no deterministic form");
+  if (!workspace || workspace_bytes < need) return bad("opadpo_gemm_tn_group_det", "workspace smaller than opadpo_gemm_tn_group_workspace_bytes");
+  return done(launch_gemm_tn_group(list, n, S(stream), workspace, workspace_bytes), "opadpo_gemm_tn_group_det");
+}
+
 int opadpo_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int ld, uint16_t* o, int ldo,
                     float* lse, const uint8_t* key_mask, int S_, int L, int nh, int hd, int causal, float scale,
                     int seg_prefix, int seg_len, void* stream) {
@@ -176,6 +209,10 @@ int opadpo_rmsnorm_bwd(const uint16_t* dy, const void* x, int x_f32, const uint1
 int opadpo_layernorm_fwd(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* y, int rows, int H, float eps, void* stream) {
   return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream)), "opadpo_layernorm_fwd");
 }
+int opadpo_layernorm_fwd_f32(const float* x, const uint16_t* w, const uint16_t* b, void* y, int y_f32, int rows, int H, float eps, void* stream) {
+  if (!x || !w || !b || !y) return bad("opadpo_layernorm_fwd_f32", "null operand");
+  return done(launch_layernorm_fwd(x, w, b, y, rows, H, eps, S(stream), 1, y_f32 ? 1 : 0), "opadpo_layernorm_fwd_f32");
+}
 int opadpo_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* w, const uint16_t* dres, uint16_t* dx, int rows, int H,
                          float eps, void* stream) {
   return done(launch_layernorm_bwd(dy, x, w, dres, dx, rows, H, eps, S(stream)), "opadpo_layernorm_bwd");
@@ -210,6 +247,9 @@ int opadpo_im2col(const uint16_t* pixels, uint16_t* out, int B, int image_size, 
 }
 int opadpo_vision_embed(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* x, int B, int P, int h, void* stream) {
   return done(launch_vision_embed(patches, cls, pos, x, B, P, h, S(stream)), "opadpo_vision_embed");
+}
+int opadpo_vision_embed_f32(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, float* x, int B, int P, int h, void* stream) {
+  return done(launch_vision_embed(patches, cls, pos, x, B, P, h, S(stream), 1), "opadpo_vision_embed_f32");
 }
 int opadpo_gather_rows(const uint16_t* src, int ld_src, const int32_t* rows_idx, uint16_t* dst, int n, int H, void* stream) {
   if (ld_src % 8) return bad("opadpo_gather_rows", "misaligned leading dimension");

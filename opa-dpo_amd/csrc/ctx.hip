@@ -731,37 +731,40 @@ int opadpo_vision_encode(opadpo_ctx* c, const uint16_t* pixels, int B, uint16_t*
   const int side = d.image_size / d.patch, P = side * side, vh = d.v_hidden, vf = d.v_ffn, T = P + 1, M = B * T;
   const int kpad = (3 * d.patch * d.patch + 63) / 64 * 64, hd = vh / d.v_heads, H = d.hidden;
   size_t need = 0;
-  { Carve cv(nullptr); cv.take<bf16_t>((size_t)B * P * kpad); cv.take<bf16_t>((size_t)B * P * vh); cv.take<bf16_t>((size_t)M * vh); cv.take<bf16_t>((size_t)M * vh);
+  { Carve cv(nullptr); cv.take<bf16_t>((size_t)B * P * kpad); cv.take<bf16_t>((size_t)B * P * vh); cv.take<float>((size_t)M * vh); cv.take<float>((size_t)M * vh);
     cv.take<bf16_t>((size_t)M * vh); cv.take<bf16_t>((size_t)M * 3 * vh); cv.take<bf16_t>((size_t)M * vh); cv.take<bf16_t>((size_t)M * vf);
     cv.take<int32_t>((size_t)B * P); cv.take<bf16_t>((size_t)B * P * vh); cv.take<bf16_t>((size_t)B * P * H); need = cv.off; }
   void* base = ctx_ws(c, need, st);
   if (!base) return cfail(c, hipErrorOutOfMemory, __func__);
   Carve cv(base);
   bf16_t* cols = cv.take<bf16_t>((size_t)B * P * kpad); bf16_t* patches = cv.take<bf16_t>((size_t)B * P * vh);
-  bf16_t* x = cv.take<bf16_t>((size_t)M * vh); bf16_t* x2 = cv.take<bf16_t>((size_t)M * vh); bf16_t* n = cv.take<bf16_t>((size_t)M * vh);
+  // the tower's residual stream x is fp32 (round 4): every block adds two bf16-rounded branch outputs to it, and rounding x itself to
+  // bf16 at each of the 46 adds carried a quarter of the 8-layer log-prob error (profiles/r03_bf16_ablation.json) for 0.5 % of the FLOPs
+  float* x = cv.take<float>((size_t)M * vh); float* x2 = cv.take<float>((size_t)M * vh); bf16_t* n = cv.take<bf16_t>((size_t)M * vh);
   bf16_t* qkv = cv.take<bf16_t>((size_t)M * 3 * vh); bf16_t* att = cv.take<bf16_t>((size_t)M * vh); bf16_t* f1 = cv.take<bf16_t>((size_t)M * vf);
   int32_t* idx = cv.take<int32_t>((size_t)B * P); bf16_t* tok = cv.take<bf16_t>((size_t)B * P * vh); bf16_t* h0 = cv.take<bf16_t>((size_t)B * P * H);
   CK(launch_im2col(pixels, cols, B, d.image_size, d.patch, kpad, st));
   { GemmNTArgs g = gemm(c, cols, kpad, c->vis.patch_w, kpad, kpad, patches, vh, 0, B * P, vh); CK(run_gemm(c, g, st)); }
-  CK(launch_vision_embed(patches, c->vis.cls, c->vis.pos, x, B, P, vh, st));
-  CK(launch_layernorm_fwd(x, c->vis.pre_ln_w, c->vis.pre_ln_b, x2, M, vh, d.v_eps, st));
+  CK(launch_vision_embed(patches, c->vis.cls, c->vis.pos, x, B, P, vh, st, 1));
+  CK(launch_layernorm_fwd(x, c->vis.pre_ln_w, c->vis.pre_ln_b, x2, M, vh, d.v_eps, st, 1, 1));
   std::swap(x, x2);
   for (const opadpo_vision_layer_weights& w : c->vlayers) {
-    CK(launch_layernorm_fwd(x, w.ln1_w, w.ln1_b, n, M, vh, d.v_eps, st));
+    CK(launch_layernorm_fwd(x, w.ln1_w, w.ln1_b, n, M, vh, d.v_eps, st, 1, 0));
     { GemmNTArgs g = gemm(c, n, vh, w.wqkv, vh, vh, qkv, 3 * vh, 0, M, 3 * vh); g.bias = w.bqkv; CK(run_gemm(c, g, st)); }
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = qkv; a.k = qkv + vh; a.v = qkv + 2 * vh; a.o = att; a.S = B; a.L = T; a.nh = d.v_heads; a.hd = hd; a.ld = 3 * vh; a.ldo = vh;
     a.causal = 0; a.scale = 1.0f / sqrtf((float)hd); a.use_tr = c->use_tr;
     CK(launch_attn_fwd(a, st));
-    { GemmNTArgs g = gemm(c, att, vh, w.wo, vh, vh, x2, vh, 0, M, vh); g.bias = w.bo; resid(g, x, vh, 0); CK(run_gemm(c, g, st)); }
-    CK(launch_layernorm_fwd(x2, w.ln2_w, w.ln2_b, n, M, vh, d.v_eps, st));
+    { GemmNTArgs g = gemm(c, att, vh, w.wo, vh, vh, x2, vh, 1, M, vh); g.bias = w.bo; resid(g, x, vh, 1); CK(run_gemm(c, g, st)); }
+    CK(launch_layernorm_fwd(x2, w.ln2_w, w.ln2_b, n, M, vh, d.v_eps, st, 1, 0));
     { GemmNTArgs g = gemm(c, n, vh, w.fc1, vh, vh, f1, vf, 0, M, vf); g.bias = w.b1; g.act = OPADPO_ACT_QUICK_GELU; CK(run_gemm(c, g, st)); }
-    { GemmNTArgs g = gemm(c, f1, vf, w.fc2, vf, vf, x, vh, 0, M, vh); g.bias = w.b2; resid(g, x2, vh, 0); CK(run_gemm(c, g, st)); }
+    { GemmNTArgs g = gemm(c, f1, vf, w.fc2, vf, vf, x, vh, 1, M, vh); g.bias = w.b2; resid(g, x2, vh, 1); CK(run_gemm(c, g, st)); }
   }
   hipLaunchKernelGGL(drop_cls_index_kernel, g1((size_t)B * P), dim3(256), 0, st, idx, B, P);
   CK(hipGetLastError());
-  CK(launch_gather_rows(x, vh, idx, tok, B * P, vh, st));
+  CK(launch_f32_to_bf16(x, n, (size_t)M * vh, st));          // one rounding of hidden_states[-2]: the bf16 operand of the projector
+  CK(launch_gather_rows(n, vh, idx, tok, B * P, vh, st));
   { GemmNTArgs g = gemm(c, tok, vh, c->vis.proj0, vh, vh, h0, H, 0, B * P, H); g.bias = c->vis.proj0_b; g.act = OPADPO_ACT_GELU; CK(run_gemm(c, g, st)); }
   { GemmNTArgs g = gemm(c, h0, H, c->vis.proj2, H, H, feats, H, 0, B * P, H); g.bias = c->vis.proj2_b; CK(run_gemm(c, g, st)); }
   return 0;
@@ -971,6 +974,22 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   const int S = sv->S, Lp = sv->L, M = sv->M, R = sv->Rc, H = d.hidden, F = d.ffn, r = d.lora_r, nh = d.n_heads, hd = d.head_dim, V = d.vocab;
   const float s = d.lora_alpha / d.lora_r;
   const size_t MH = (size_t)M * H;
+  // workspace of the LoRA wgrads' deterministic flush (gemm_tn_w4_kernel writes a run's partial tiles there, gemm_tn_reduce_kernel adds them in a
+  // fixed order: no fp32 atomics, gradients bit-reproducible run to run): the worst case over the layer's 8 problems as one group, or one
+  // by one (compact top layer: two row counts); context flag (use_tr) bit 12 keeps the atomic flush (A/B)
+  size_t tn_ws_floats = 1;
+  if (!(c->use_tr >= 0 && (c->use_tr & 4096))) {
+    GemmTNArgs shp[8];
+    const int n1s[8] = {H, r, 2 * F, 2 * r, H, r, 3 * H, 3 * r}, n2s[8] = {r, F, r, H, r, H, r, H}, qg[8] = {0, 0, F, 0, 0, 0, H, 0};
+    for (int rows_case = 0; rows_case < 2; ++rows_case) {
+      for (int q = 0; q < 8; ++q) {
+        memset(&shp[q], 0, sizeof(GemmTNArgs));
+        shp[q].M = (rows_case == 1 && sv->Uc > 0 && q < 6) ? sv->Uc : M;
+        shp[q].N1 = n1s[q]; shp[q].N2 = n2s[q]; shp[q].ldp = n1s[q]; shp[q].ldq = n2s[q] * (qg[q] ? n1s[q] / qg[q] : 1); shp[q].q_group_n1 = qg[q]; shp[q].use_tr = c->use_tr;
+      }
+      tn_ws_floats = std::max(tn_ws_floats, gemm_tn_group_workspace_bytes(shp, 8) / sizeof(float));
+    }
+  }
   // workspace (persists between the ranged calls of one backward)
   size_t need = 0;
   const int VC = sv->head_chunk;                      // chunked head: dz and the recomputed logits exist for one vocabulary chunk at a time
@@ -978,7 +997,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   { Carve cv(nullptr); cv.take<bf16_t>((size_t)R * dz_cols); cv.take<float>(VC > 0 ? (size_t)R * H : 1); cv.take<bf16_t>((size_t)R * H); cv.take<float>((size_t)R * H); cv.take<float>(MH); cv.take<bf16_t>(MH);
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
-    cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); need = cv.off; }
+    cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); cv.take<float>(tn_ws_floats); need = cv.off; }
   if (R == 0) return 0;                               // no valid response token: every gradient of this pass is exactly zero
   const bool first = layer_hi == d.n_layers - 1;
   if (!first && (c->ws_bytes < need || !c->ws)) return cbad(c, __func__, "ranged backward must start at the top layer");
@@ -993,6 +1012,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   bf16_t* dt_r = cv.take<bf16_t>((size_t)M * r); bf16_t* dt_2r = cv.take<bf16_t>((size_t)M * 2 * r); bf16_t* dt_3r = cv.take<bf16_t>((size_t)M * 3 * r);
   bf16_t* dt_ra = cv.take<bf16_t>((size_t)M * r);        // dT of the o projection (dt_r keeps the down projection's until the grouped wgrad)
   float* d_full = cv.take<float>(sv->Uc > 0 ? MH : 1);   // compact top layer: its residual gradient scattered back to every row
+  float* tn_ws = cv.take<float>(tn_ws_floats);
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");
@@ -1091,7 +1111,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r, M));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0, M));
-    CK(launch_gemm_tn_group(wg, nwg, st));
+    CK(launch_gemm_tn_group(wg, nwg, st, tn_ws_floats > 1 ? tn_ws : nullptr, tn_ws_floats > 1 ? tn_ws_floats * sizeof(float) : 0));
     if (i > 0 || d_feats) {          // layer-0 input is the frozen embedding / image features: no further dgrad in the DPO stage
       { GemmNTArgs g = gemm(c, dqkv, 3 * H, w.wqkv_t, 3 * H, 3 * H, d_n, H, 0, M, H); tail(g, dt_3r, 3 * r, wt + o.a_qkv, 3 * r, 3 * r); CK(run_gemm(c, g, st)); }
       const float* dres = d_h;

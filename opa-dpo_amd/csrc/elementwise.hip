@@ -1,8 +1,26 @@
 // HBM-bound row / elementwise kernels (bf16 storage, fp32 math, 16-byte vector accesses).
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace {
+// 16-byte accesses of tensors that are streamed exactly once by these HBM-bound kernels; `nt` (launch_* : OPADPO_EW_NT) marks them
+// non-temporal so that they do not push the next GEMM's operand panels out of the 4-MiB L2s
+typedef __attribute__((ext_vector_type(4))) unsigned ew_u4_t;
+typedef __attribute__((ext_vector_type(4))) float ew_f4_t;
+__device__ __forceinline__ uint4 ew_ld16(const void* p, int nt) {
+  const ew_u4_t v = nt ? __builtin_nontemporal_load((const ew_u4_t*)p) : *(const ew_u4_t*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ew_st16(void* p, const uint4& v, int nt) {
+  const ew_u4_t w = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_nontemporal_store(w, (ew_u4_t*)p); else *(ew_u4_t*)p = w;
+}
+__device__ __forceinline__ void ew_st16f(float* p, float a, float b, float c, float d, int nt) {
+  const ew_f4_t w = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(w, (ew_f4_t*)p); else *(ew_f4_t*)p = w;
+}
+
 
 // ---- RMSNorm ------------------------------------------------------------------------------
 // one block (256 threads) per row; H % 8 == 0.  y = x * rsqrt(mean(x^2) + eps) * w.  The residual
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* x, const b
 template <bool XF, bool RF>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, const void* x, const bf16_t* w,
                                                            const float* rstd, const void* dres, float* dx_f32,
-                                                           bf16_t* dx_bf16, int H) {
+                                                           bf16_t* dx_bf16, int H, int nt) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   const float r = rstd[row];
@@ -105,23 +123,34 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* dy, cons
       for (int j = 0; j < 8; ++j) o[j] += d[j];
     }
     if (dx_f32) {
-      *(float4*)(dx_f32 + row * H + i) = make_float4(o[0], o[1], o[2], o[3]);
-      *(float4*)(dx_f32 + row * H + i + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      ew_st16f(dx_f32 + row * H + i, o[0], o[1], o[2], o[3], nt);
+      ew_st16f(dx_f32 + row * H + i + 4, o[4], o[5], o[6], o[7], nt);
     }
-    if (dx_bf16) *(uint4*)(dx_bf16 + row * H + i) = pack8(o);
+    if (dx_bf16) ew_st16(dx_bf16 + row * H + i, pack8(o), nt);
   }
 }
 
 // ---- LayerNorm (CLIP) ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, const bf16_t* w, const bf16_t* b,
-                                                             bf16_t* y, int H, float eps) {
+// XF32 / YF32: the CLIP tower's residual stream is fp32 in the DPO path (round 4: 46 bf16 roundings of x per image removed - the
+// ablation of round 3 put a quarter of the 8-layer log-prob error on the tower); the pre-LayerNorm reads and writes that stream, the
+// two LayerNorms of a block read it and write the bf16 operand of the next GEMM.  (bf16 in / out: the OPA-SFT stage's trainable tower.)
+template <bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* x_, const bf16_t* w, const bf16_t* b,
+                                                             void* y_, int H, float eps) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
-  const bf16_t* xr = x + row * H;
+  auto load8 = [&](int i, float* f) {
+    if constexpr (XF32) {
+      const float4 a = *(const float4*)((const float*)x_ + row * H + i), c = *(const float4*)((const float*)x_ + row * H + i + 4);
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+    } else {
+      unpack8(*(const uint4*)((const bf16_t*)x_ + row * H + i), f);
+    }
+  };
   float s = 0.f;
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8];
-    unpack8(*(const uint4*)(xr + i), f);
+    load8(i, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += f[j];
   }
@@ -129,19 +158,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* x, con
   float v = 0.f;
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8];
-    unpack8(*(const uint4*)(xr + i), f);
+    load8(i, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; v += d * d; }
   }
   const float r = rsqrtf(block_sum_256(v, red) / H + eps);
   for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
     float f[8], g[8], c[8];
-    unpack8(*(const uint4*)(xr + i), f);
+    load8(i, f);
     unpack8(*(const uint4*)(w + i), g);
     unpack8(*(const uint4*)(b + i), c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * r * g[j] + c[j];
-    *(uint4*)(y + row * H + i) = pack8(f);
+    if constexpr (YF32) {
+      *(float4*)((float*)y_ + row * H + i) = make_float4(f[0], f[1], f[2], f[3]);
+      *(float4*)((float*)y_ + row * H + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+      *(uint4*)((bf16_t*)y_ + row * H + i) = pack8(f);
+    }
   }
 }
 
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* dout, const 
 }
 
 // ---- SwiGLU ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* gu, bf16_t* act, size_t rows, int F) {
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* gu, bf16_t* act, size_t rows, int F, int nt) {
   const int per_row = F / 8;
   const size_t total = rows * per_row;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -299,21 +333,21 @@ __global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16_t* gu, bf1
     unpack8(*(const uint4*)(gu + row * 2 * F + F + i), u);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = g[j] / (1.0f + __expf(-g[j])) * u[j];
-    *(uint4*)(act + row * F + i) = pack8(o);
+    ew_st16(act + row * F + i, pack8(o), nt);
   }
 }
 
 __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu,
-                                                            size_t rows, int F) {
+                                                            size_t rows, int F, int nt) {
   const int per_row = F / 8;
   const size_t total = rows * per_row;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const size_t row = idx / per_row;
     const int i = (int)(idx % per_row) * 8;
     float g[8], u[8], d[8], dg[8], du[8];
-    unpack8(*(const uint4*)(gu + row * 2 * F + i), g);
-    unpack8(*(const uint4*)(gu + row * 2 * F + F + i), u);
-    unpack8(*(const uint4*)(dact + row * F + i), d);
+    unpack8(ew_ld16(gu + row * 2 * F + i, nt), g);
+    unpack8(ew_ld16(gu + row * 2 * F + F + i, nt), u);
+    unpack8(ew_ld16(dact + row * F + i, nt), d);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float sg = 1.0f / (1.0f + __expf(-g[j]));
@@ -321,8 +355,8 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* dact, c
       du[j] = d[j] * silu;
       dg[j] = d[j] * u[j] * sg * (1.0f + g[j] * (1.0f - sg));
     }
-    *(uint4*)(dgu + row * 2 * F + i) = pack8(dg);
-    *(uint4*)(dgu + row * 2 * F + F + i) = pack8(du);
+    ew_st16(dgu + row * 2 * F + i, pack8(dg), nt);
+    ew_st16(dgu + row * 2 * F + F + i, pack8(du), nt);
   }
 }
 
@@ -396,8 +430,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* pixels, bf16_
 }
 
 // x[b, 0] = cls + pos[0] ; x[b, 1+p] = patches[b*P+p] + pos[1+p]
+template <bool XF32>
 __global__ __launch_bounds__(256) void vision_embed_kernel(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos,
-                                                            bf16_t* x, int P, int h) {
+                                                            void* x, int P, int h) {
   const int b = blockIdx.y, t = blockIdx.x;   // t in [0, P]
   const bf16_t* src = (t == 0) ? cls : patches + ((size_t)b * P + t - 1) * h;
   for (int i = threadIdx.x * 8; i < h; i += 256 * 8) {
@@ -406,7 +441,13 @@ __global__ __launch_bounds__(256) void vision_embed_kernel(const bf16_t* patches
     unpack8(*(const uint4*)(pos + (size_t)t * h + i), c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] += c[j];
-    *(uint4*)(x + ((size_t)b * (P + 1) + t) * h + i) = pack8(a);
+    if constexpr (XF32) {
+      float* xo = (float*)x + ((size_t)b * (P + 1) + t) * h + i;
+      *(float4*)xo = make_float4(a[0], a[1], a[2], a[3]);
+      *(float4*)(xo + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    } else {
+      *(uint4*)((bf16_t*)x + ((size_t)b * (P + 1) + t) * h + i) = pack8(a);
+    }
   }
 }
 
@@ -518,7 +559,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_strided_kernel(const float* i
 // deterministic, no atomics - and costs no launch).  One block per row, row held in registers between the two passes.
 template <bool RF>
 __global__ __launch_bounds__(256) void rmsnorm_sum_fwd_kernel(const void* resid, const float* partials, int n_partials, size_t partial_stride,
-                                                               const bf16_t* w, float* x_out, bf16_t* y, float* rstd, int H, float eps) {
+                                                               const bf16_t* w, float* x_out, bf16_t* y, float* rstd, int H, float eps, int nt) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   float f[3][8], g[3][8];
@@ -535,8 +576,8 @@ __global__ __launch_bounds__(256) void rmsnorm_sum_fwd_kernel(const void* resid,
         f[it][0] += a.x; f[it][1] += a.y; f[it][2] += a.z; f[it][3] += a.w;
         f[it][4] += b.x; f[it][5] += b.y; f[it][6] += b.z; f[it][7] += b.w;
       }
-      *(float4*)(x_out + row * H + i) = make_float4(f[it][0], f[it][1], f[it][2], f[it][3]);
-      *(float4*)(x_out + row * H + i + 4) = make_float4(f[it][4], f[it][5], f[it][6], f[it][7]);
+      ew_st16f(x_out + row * H + i, f[it][0], f[it][1], f[it][2], f[it][3], nt);
+      ew_st16f(x_out + row * H + i + 4, f[it][4], f[it][5], f[it][6], f[it][7], nt);
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += f[it][j] * f[it][j];
     }
@@ -551,7 +592,7 @@ __global__ __launch_bounds__(256) void rmsnorm_sum_fwd_kernel(const void* resid,
     if (i < H) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[it][j] = f[it][j] * r * g[it][j];
-      *(uint4*)(y + row * H + i) = pack8(f[it]);
+      ew_st16(y + row * H + i, pack8(f[it]), nt);
     }
   }
 }
@@ -572,19 +613,23 @@ hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t*
   else hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, x, w, y, rstd, H, eps);
   return hipGetLastError();
 }
+// OPADPO_EW_NT=1: non-temporal stores (and streamed-once loads) in the four HBM-bound passes between the GEMMs (A/B switch, see ew_st16)
+static int ew_nt() { static const int v = getenv("OPADPO_EW_NT") ? atoi(getenv("OPADPO_EW_NT")) : 0; return v; }
 hipError_t launch_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partials, int n_partials, size_t partial_stride, const bf16_t* w,
                                   float* x_out, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (H % 8 || H > 256 * 8 * 3 || n_partials < 0 || (n_partials > 0 && !partials) || !x_out) return hipErrorInvalidValue;
-  if (resid_f32) hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<true>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps);
-  else hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps);
+  const int nt = rows >= 4096 ? ew_nt() : 0;       // decode-sized calls keep their rows in cache
+  if (resid_f32) hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<true>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps, nt);
+  else hipLaunchKernelGGL(rmsnorm_sum_fwd_kernel<false>, dim3(rows), dim3(256), 0, st, resid, partials, n_partials, partial_stride, w, x_out, y, rstd, H, eps, nt);
   return hipGetLastError();
 }
 hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (H % 8) return hipErrorInvalidValue;
-#define RB(XF, RF) hipLaunchKernelGGL((rmsnorm_bwd_kernel<XF, RF>), dim3(rows), dim3(256), 0, st, dy, x, w, rstd, dres, dx_f32, dx_bf16, H)
+  const int nt = rows >= 4096 ? ew_nt() : 0;
+#define RB(XF, RF) hipLaunchKernelGGL((rmsnorm_bwd_kernel<XF, RF>), dim3(rows), dim3(256), 0, st, dy, x, w, rstd, dres, dx_f32, dx_bf16, H, nt)
   if (x_f32 && dres_f32) RB(true, true);
   else if (x_f32) RB(true, false);
   else if (dres_f32) RB(false, true);
@@ -592,10 +637,12 @@ hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const 
 #undef RB
   return hipGetLastError();
 }
-hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st) {
+hipError_t launch_layernorm_fwd(const void* x, const bf16_t* w, const bf16_t* b, void* y, int rows, int H, float eps, hipStream_t st, int x_f32, int y_f32) {
   if (rows <= 0) return hipSuccess;
-  if (H % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+  if (H % 8 || (y_f32 && !x_f32)) return hipErrorInvalidValue;
+  if (x_f32 && y_f32) hipLaunchKernelGGL((layernorm_fwd_kernel<true, true>), dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+  else if (x_f32) hipLaunchKernelGGL((layernorm_fwd_kernel<true, false>), dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
+  else hipLaunchKernelGGL((layernorm_fwd_kernel<false, false>), dim3(rows), dim3(256), 0, st, x, w, b, y, H, eps);
   return hipGetLastError();
 }
 hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const bf16_t* dres, bf16_t* dx, int rows, int H,
@@ -629,13 +676,13 @@ hipError_t launch_rope(bf16_t* qk, int ld, const float* cosb, const float* sinb,
 hipError_t launch_silu_mul_fwd(const bf16_t* gu, bf16_t* act, int rows, int F, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (F % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, gu, act, (size_t)rows, F);
+  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, gu, act, (size_t)rows, F, rows >= 4096 ? ew_nt() : 0);
   return hipGetLastError();
 }
 hipError_t launch_silu_mul_bwd(const bf16_t* dact, const bf16_t* gu, bf16_t* dgu, int rows, int F, hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   if (F % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, dact, gu, dgu, (size_t)rows, F);
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((size_t)rows * (F / 8))), dim3(256), 0, st, dact, gu, dgu, (size_t)rows, F, rows >= 4096 ? ew_nt() : 0);
   return hipGetLastError();
 }
 hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, const bf16_t* embed, const bf16_t* feats,
@@ -653,10 +700,11 @@ hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_siz
   hipLaunchKernelGGL(im2col_kernel, dim3(B * G * G), dim3(256), 0, st, pixels, out, image_size, patch, kpad);
   return hipGetLastError();
 }
-hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st) {
+hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, void* x, int B, int P, int h, hipStream_t st, int x_f32) {
   if (B <= 0) return hipSuccess;
   if (h % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(vision_embed_kernel, dim3(P + 1, B), dim3(256), 0, st, patches, cls, pos, x, P, h);
+  if (x_f32) hipLaunchKernelGGL(vision_embed_kernel<true>, dim3(P + 1, B), dim3(256), 0, st, patches, cls, pos, x, P, h);
+  else hipLaunchKernelGGL(vision_embed_kernel<false>, dim3(P + 1, B), dim3(256), 0, st, patches, cls, pos, x, P, h);
   return hipGetLastError();
 }
 hipError_t launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* rows_idx, bf16_t* dst, int n, int H, hipStream_t st) {

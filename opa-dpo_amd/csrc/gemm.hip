@@ -69,6 +69,14 @@ __device__ __forceinline__ void acc_read4(const f32x4_t& a, float (&v)[4]) {
   asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[3]) : "a"(a[3]));
 }
 
+// 16-byte store of a result row piece that nothing in this kernel reads again: non-temporal (streaming) when `nt` - see launch_gemm_nt
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4n_t;
+__device__ __forceinline__ void store16(void* dst, const uint4& v, int nt) {
+  const u32x4n_t w = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_nontemporal_store(w, (u32x4n_t*)dst);
+  else *(u32x4n_t*)dst = w;
+}
+
 // the w4 kernels take only bias-free, activation-free problems (the launcher routes the others to the 8-wave kernel): two
 // epilogue instantiations instead of five keep the hot kernel's code small
 template <class F>
@@ -523,8 +531,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
               hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
               if (small) {
                 const unsigned vo = ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 0);
+                if (p.store_nt) { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 2); }
+                else { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 0); }
               } else if (m < p.M) {
                 *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col) = lo;
                 *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col + 4) = hi;
@@ -532,7 +540,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
             } else {
               u32x4s_t o;
               o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
-              if (small) __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 0);
+              if (small) {
+                if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 0);
+              }
               else if (m < p.M) *(u32x4s_t*)((bf16_t*)p.C + (size_t)m * p.ldc + col) = o;
             }
           }
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           unpack8(*(const uint4*)(rp + ((((g + 8) >> 1) ^ (row & 7)) << 5) + (g & 1) * 16), up);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = gt[e] / (1.0f + __expf(-gt[e])) * up[e];
-          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ocol) = pack8(o);
+          if (m < p.M) store16((bf16_t*)p.C + (size_t)m * p.ldc + ocol, pack8(o), p.store_nt);
         }
         return;
       }
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
             const float x = __builtin_amdgcn_fractf(posf * frev[e]);
             o[e] = xs[e] * __builtin_amdgcn_cosf(x) + sign * (xp[e] * __builtin_amdgcn_sinf(x));
           }
-          if (m < p.M) *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8) = pack8(o);
+          if (m < p.M) store16((bf16_t*)p.C + (size_t)m * p.ldc + ncol0 + g * 8, pack8(o), p.store_nt);
           pos = pn;
         }
         return;
@@ -766,7 +777,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 0);
+            if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(o[u], rC, vo, 0, 0);
             vo += step;
           }
         }
@@ -786,364 +798,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     });
   };
   staged_epi();
-}
-
-// ------------------------------------------------------------------------------------------
-// gemm_nt "w4p" kernel (round 4): gemm_nt_w4_kernel as a PERSISTENT tile loop for the direct-epilogue problems (plain products, alpha = 1,
-// bf16 or fp32 out, no residual, no fused SwiGLU / rotary epilogue - three quarters of the step's GEMM FLOPs).
-// One workgroup per CU walks the tiles b, b + G, b + 2G, ... of the SAME grouped, XCD-aware order the one-tile-per-block kernel uses
-// (virtual block id v = b + i*G lands on the XCD of b: G % 8 == 0), and the K-tiles of consecutive output tiles form ONE stream through the
-// two LDS stages: the long-lead DMA (K-tile g+2 issued during K-tile g) simply runs on into the next output tile, so its first two K-tiles
-// are in flight / landed while the current tile finishes and stores.  What disappears per output tile: the 2.4 us prologue (32 pieces
-// issued and waited for with nothing to compute), the dispatch gap of a new workgroup and the end-of-kernel wait for the stores'
-// acknowledgement - DESIGN.md section 8(0) priced them at 3-4 us of a ~100 us tile at K = 4096.  Accumulators are not zeroed between
-// tiles: the first k-half of a tile's first K-tile runs MFMAs with the literal 0 as C operand.
-// Every tile is still computed by ONE workgroup over the full K range in the same k order, so every element of C is bit-identical to
-// gemm_nt_w4_kernel's (tests/test_ops_gpu.py::test_gemm_nt_persistent_is_bit_identical): which block computes a tile cannot change a result.
-// The 64 accumulator tuples are pinned to a[0:255] by PHYSICAL register constraints ("+{a[4n:4n+3]}"): with plain "+a" operands the
-// register allocator rotated the accumulators through other registers across the tile loop's back edge and around the epilogue
-// (761 v_accvgpr_write + 251 v_accvgpr_mov + 620 bytes of scratch per lane in the first version of this kernel).
-// vmcnt bookkeeping across the boundary: the epilogue's buffer_stores count in vmcnt next to the DMA pieces; the first K-tile body of
-// the next tile waits vmcnt(13) = "at most the 13 pieces issued in this body are outstanding", which under in-order completion of loads
-// (stores may complete in any order relative to them) still implies that every older piece has landed.
-// ------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void w4p_mfma(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b);       // c += a . b^T, c pinned
-template <int N> __device__ __forceinline__ void w4p_mfma0(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b);      // c  = a . b^T
-template <int N> __device__ __forceinline__ void w4p_rd(const f32x4_t& c, float (&v)[4]);                          // accumulator -> 4 VGPRs
-#define W4P_ACC(N, R0, R1, R2, R3)                                                                                                       \
-  template <> __device__ __forceinline__ void w4p_mfma<N>(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {                             \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+{a[" #R0 ":" #R3 "]}"(c) : "v"(a), "v"(b));                                \
-  }                                                                                                                                      \
-  template <> __device__ __forceinline__ void w4p_mfma0<N>(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {                            \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "={a[" #R0 ":" #R3 "]}"(c) : "v"(a), "v"(b));                                 \
-  }                                                                                                                                      \
-  template <> __device__ __forceinline__ void w4p_rd<N>(const f32x4_t& c, float (&v)[4]) {                                                \
-    asm volatile("v_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2                     \
-                 "\n\tv_accvgpr_read_b32 %3, a" #R3 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "{a[" #R0 ":" #R3 "]}"(c));        \
-  }
-W4P_ACC(0, 0, 1, 2, 3)
-W4P_ACC(1, 4, 5, 6, 7)
-W4P_ACC(2, 8, 9, 10, 11)
-W4P_ACC(3, 12, 13, 14, 15)
-W4P_ACC(4, 16, 17, 18, 19)
-W4P_ACC(5, 20, 21, 22, 23)
-W4P_ACC(6, 24, 25, 26, 27)
-W4P_ACC(7, 28, 29, 30, 31)
-W4P_ACC(8, 32, 33, 34, 35)
-W4P_ACC(9, 36, 37, 38, 39)
-W4P_ACC(10, 40, 41, 42, 43)
-W4P_ACC(11, 44, 45, 46, 47)
-W4P_ACC(12, 48, 49, 50, 51)
-W4P_ACC(13, 52, 53, 54, 55)
-W4P_ACC(14, 56, 57, 58, 59)
-W4P_ACC(15, 60, 61, 62, 63)
-W4P_ACC(16, 64, 65, 66, 67)
-W4P_ACC(17, 68, 69, 70, 71)
-W4P_ACC(18, 72, 73, 74, 75)
-W4P_ACC(19, 76, 77, 78, 79)
-W4P_ACC(20, 80, 81, 82, 83)
-W4P_ACC(21, 84, 85, 86, 87)
-W4P_ACC(22, 88, 89, 90, 91)
-W4P_ACC(23, 92, 93, 94, 95)
-W4P_ACC(24, 96, 97, 98, 99)
-W4P_ACC(25, 100, 101, 102, 103)
-W4P_ACC(26, 104, 105, 106, 107)
-W4P_ACC(27, 108, 109, 110, 111)
-W4P_ACC(28, 112, 113, 114, 115)
-W4P_ACC(29, 116, 117, 118, 119)
-W4P_ACC(30, 120, 121, 122, 123)
-W4P_ACC(31, 124, 125, 126, 127)
-W4P_ACC(32, 128, 129, 130, 131)
-W4P_ACC(33, 132, 133, 134, 135)
-W4P_ACC(34, 136, 137, 138, 139)
-W4P_ACC(35, 140, 141, 142, 143)
-W4P_ACC(36, 144, 145, 146, 147)
-W4P_ACC(37, 148, 149, 150, 151)
-W4P_ACC(38, 152, 153, 154, 155)
-W4P_ACC(39, 156, 157, 158, 159)
-W4P_ACC(40, 160, 161, 162, 163)
-W4P_ACC(41, 164, 165, 166, 167)
-W4P_ACC(42, 168, 169, 170, 171)
-W4P_ACC(43, 172, 173, 174, 175)
-W4P_ACC(44, 176, 177, 178, 179)
-W4P_ACC(45, 180, 181, 182, 183)
-W4P_ACC(46, 184, 185, 186, 187)
-W4P_ACC(47, 188, 189, 190, 191)
-W4P_ACC(48, 192, 193, 194, 195)
-W4P_ACC(49, 196, 197, 198, 199)
-W4P_ACC(50, 200, 201, 202, 203)
-W4P_ACC(51, 204, 205, 206, 207)
-W4P_ACC(52, 208, 209, 210, 211)
-W4P_ACC(53, 212, 213, 214, 215)
-W4P_ACC(54, 216, 217, 218, 219)
-W4P_ACC(55, 220, 221, 222, 223)
-W4P_ACC(56, 224, 225, 226, 227)
-W4P_ACC(57, 228, 229, 230, 231)
-W4P_ACC(58, 232, 233, 234, 235)
-W4P_ACC(59, 236, 237, 238, 239)
-W4P_ACC(60, 240, 241, 242, 243)
-W4P_ACC(61, 244, 245, 246, 247)
-W4P_ACC(62, 248, 249, 250, 251)
-W4P_ACC(63, 252, 253, 254, 255)
-#undef W4P_ACC
-// compile-time loop: f(integral_constant<int, I0>) ... f(integral_constant<int, I0 + N - 1>)
-template <int I0, int N, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (N > 0) {
-    f(std::integral_constant<int, I0>{});
-    sfor<I0 + 1, N - 1>(f);
-  }
-}
-
-template <bool ORDER_B, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_tiles, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int width = p.group_m * tiles_n;
-  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-  const int my_tiles = (n_tiles - bid + G - 1) / G;          // tiles bid, bid + G, ... < n_tiles (the launcher guarantees >= 1)
-  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;   // nt >= 3 (launcher)
-  const int srow = lane >> 3, spos = lane & 7;
-  auto uni = [](const void* q) -> void* {
-    const unsigned long long v = (unsigned long long)q;
-    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-  };
-  auto tile_of = [&](int v, int& m0, int& n0) {
-    const int swz = xcd_remap(v, n_tiles);
-    const int group_id = swz / width;
-    const int first_m = group_id * p.group_m;
-    const int gsz = min(tiles_m - first_m, p.group_m);
-    const int tm = first_m + (swz % width) % gsz;
-    const int tn = (swz % width) / gsz;
-    m0 = __builtin_amdgcn_readfirstlane(tm * P_BM);
-    n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
-  };
-  const unsigned lrow = (unsigned)(wave * 64 + srow);
-  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
-  const unsigned lrowB_lo = (unsigned)((srow & 1) * 8 + (srow & 6));
-  const unsigned m_last = (unsigned)(p.M - 1);
-  // ---- DMA side: the tile whose K-tiles are being fetched (runs two K-tiles ahead of the compute side, across tile boundaries)
-  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-  auto mk_rsrc = [&](const void* base) {
-    const unsigned long long v = (unsigned long long)base;
-    i32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)v); r[1] = __builtin_amdgcn_readfirstlane((int)((v >> 32) & 0xffffu));
-    r[2] = -1; r[3] = 0x00020000;
-    return r;
-  };
-  int d_m0, d_n0, d_t = 0, d_it = 0;           // tile origin, K-tile index inside it, tile ordinal of this block
-  bool d_second = false;
-  i32x4_t qA1, qA2;
-  const i32x4_t qB1 = mk_rsrc(p.B1), qB2 = mk_rsrc(nt2 ? p.B2 : p.B1);
-  unsigned voff[16];
-  auto set_voff = [&](bool second) {
-    const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-#pragma unroll
-    for (int pi = 0; pi < 8; ++pi) {
-      voff[pi] = min((unsigned)d_m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
-      voff[8 + pi] = ((unsigned)d_n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb +
-                     (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
-    }
-  };
-  auto d_open_tile = [&](int v) {              // start fetching tile v
-    tile_of(v, d_m0, d_n0);
-    const bf16_t* a1 = p.A1;
-    if (p.a1_group_n > 0) a1 += (size_t)(d_n0 / p.a1_group_n) * p.a1_group_stride;
-    const bf16_t* a2 = p.A2;
-    if (p.a2_group_n > 0) a2 += (size_t)(d_n0 / p.a2_group_n) * p.a2_group_stride;
-    qA1 = mk_rsrc(a1);
-    qA2 = mk_rsrc(nt2 ? a2 : a1);
-    d_t = 0; d_second = false;
-    set_voff(false);
-  };
-  // called before the 16 pieces of K-tile d_t are issued: tile / operand switches of the stream
-  // Past the block's last tile the stream keeps running on a DUMMY tile (the last tile again: two K-tiles nobody reads): every K-tile of
-  // the stream then runs the SAME steady-state body - no drain variants of the 128-MFMA body (in a first version their two copies merged
-  // into one 256-MFMA basic block in which the register allocator spilled the pinned accumulators), 64 KiB of extra L2 reads per block.
-  auto d_advance = [&]() {
-    if (d_t == nt) {
-      ++d_it;
-      const int v = bid + d_it * G;
-      d_open_tile(v < n_tiles ? v : v - G);
-    }
-    else if (d_t == nt1) { d_second = true; set_voff(true); }
-  };
-  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
-  auto dma_m0 = [&](int par, int q) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + par * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-    asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory");
-  };
-  auto dma_go = [&](int q) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((d_second ? (d_t - nt1) : d_t) * P_BK * 2);
-    const i32x4_t r = q < 8 ? (d_second ? qA2 : qA1) : (d_second ? qB2 : qB1);
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff) : "memory");
-  };
-
-  f32x4_t acc[64];                             // acc[i*8 + j], pinned to a[4(i*8+j) : +3] by the w4p_* helpers; first written by w4p_mfma0
-  bf16x8_t fa[2][8], fb[2][8];
-  const int frow = lane & 15, fchk = lane >> 4;
-  const int fsw = (frow >> 1) & 7;
-  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128;
-  auto read_frag = [&](int par, int kk, int r) {
-    const char* st = smem + par * P_STAGE;
-    const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
-    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + ((r & 1) * 8 + (r & 6)) * 128 + cb);
-    else fa[kk][r - 8] = *(const bf16x8_t*)(st + offA + (r - 8) * 2048 + cb);
-  };
-#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // MFMAs IDX0 .. IDX0+N-1 of k-half KK (idx = i*8 + j); ZERO: C operand = 0 (the tile's first k-half)
-  auto mfma_run = [&](auto KK_, auto IDX0_, auto N_, auto ZERO_) {
-    constexpr int kk = decltype(KK_)::value, idx0 = decltype(IDX0_)::value, n = decltype(N_)::value;
-    constexpr bool zero = decltype(ZERO_)::value;
-    sfor<idx0, n>([&](auto I_) {
-      constexpr int idx = decltype(I_)::value;
-      if constexpr (zero && kk == 0) w4p_mfma0<idx>(acc[idx], fa[kk][idx >> 3], fb[kk][idx & 7]);
-      else w4p_mfma<idx>(acc[idx], fa[kk][idx >> 3], fb[kk][idx & 7]);
-    });
-  };
-#define IC(x) std::integral_constant<int, (x)>{}
-  // one K-tile of the stream; par = its LDS stage.  Same schedule as gemm_nt_w4_kernel::tile_body_ll (see there for the knobs)
-  auto tile_body = [&](int par, auto HAS_NEXT, auto HAS_NEXT2, auto FIRST) {
-    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    constexpr bool dma = has_next2;
-    constexpr int R1 = 32, B1 = 40, DSTEP = 4;
-    sfor<0, 16>([&](auto G_) {
-      constexpr int g = decltype(G_)::value;
-      mfma_run(IC(0), IC((g * R1) / 16), IC(((g + 1) * R1) / 16 - (g * R1) / 16), FIRST);
-      W4_PIN();
-      read_frag(par, 1, g);
-      W4_PIN();
-    });
-    mfma_run(IC(0), IC(R1), IC(B1 - R1 - 1), FIRST);
-    W4_PIN();
-    if constexpr (has_next2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_PIN(); mfma_run(IC(0), IC(B1 - 1), IC(1), FIRST); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // every read of this stage is done: it takes the K-tile two ahead
-      W4_PIN();
-      d_advance();
-      W4_PIN();
-    } else {
-      mfma_run(IC(0), IC(B1 - 1), IC(1), FIRST);
-      W4_PIN();
-    }
-    sfor<0, 100 - B1 - 1>([&](auto M_) {
-      constexpr int m = decltype(M_)::value, gi = B1 + m;
-      constexpr auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };
-      mfma_run(IC(gi >> 6), IC(gi & 63), IC(1), FIRST);
-      if constexpr (dma && (m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(par, piece_of((m + 2) / DSTEP - 1)); W4_PIN(); }
-      if constexpr ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
-        W4_PIN();
-        if constexpr (dma) dma_go(piece_of((m + 1) / DSTEP - 1));
-        W4_PIN();
-      }
-    });
-    W4_PIN();
-    if constexpr (has_next) {
-      if constexpr (decltype(FIRST)::value) {
-        // behind the previous tile's stores: only the 3 pieces issued BEFORE them must have landed (in-order retirement)
-        if (dbg & 2) { if constexpr (OUT_F32) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      } else {
-        if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      W4_PIN(); mfma_run(IC(1), IC(35), IC(1), FIRST); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // the next K-tile of the stream has landed for everyone
-    } else {
-      mfma_run(IC(1), IC(35), IC(1), FIRST);
-    }
-    W4_PIN();
-    sfor<0, 8>([&](auto G_) {
-      constexpr int g = decltype(G_)::value;
-      constexpr auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };
-      mfma_run(IC(1), IC(36 + g * 3), IC(2), FIRST);
-      W4_PIN();
-      if constexpr (has_next) read_frag(par ^ 1, 0, 2 * g);
-      if constexpr (dma && (g == 1 || g == 4 || g == 7)) dma_m0(par, piece_of(13 + (g - 1) / 3));
-      W4_PIN();
-      mfma_run(IC(1), IC(36 + g * 3 + 2), IC(1), FIRST);
-      W4_PIN();
-      if constexpr (has_next) read_frag(par ^ 1, 0, 2 * g + 1);
-      if constexpr (dma && (g == 1 || g == 4 || g == 7)) dma_go(piece_of(13 + (g - 1) / 3));
-      W4_PIN();
-    });
-    mfma_run(IC(1), IC(60), IC(4), FIRST);
-    W4_PIN();
-    if constexpr (dma) ++d_t;
-  };
-  using T_ = std::true_type; using F_ = std::false_type;
-
-  // ---- epilogue: 16-byte stores straight from the accumulators (gemm_nt_w4_kernel's direct form), rows >= M dropped by the descriptor
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(uni(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * (OUT_F32 ? 4u : 2u)), 0x00020000);
-  auto store_tile = [&](int m0, int n0) {
-    const unsigned esz = OUT_F32 ? 4u : 2u;
-    unsigned vo = ((unsigned)(m0 + wr * 128 + 4 * fchk) * (unsigned)p.ldc + (unsigned)(n0 + wc * 128 + 8 * frow)) * esz;
-    const unsigned rstep = (unsigned)p.ldc * esz;
-    sfor<0, 8>([&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      float v[8][4];
-      sfor<0, 8>([&](auto J_) { constexpr int j = decltype(J_)::value; w4p_rd<i * 8 + j>(acc[i * 8 + j], v[j]); });
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned vr = vo + (unsigned)(i * 16 + r) * rstep;
-        if constexpr (OUT_F32) {
-          u32x4s_t lo, hi;
-          lo[0] = __float_as_uint(v[0][r]); lo[1] = __float_as_uint(v[1][r]); lo[2] = __float_as_uint(v[2][r]); lo[3] = __float_as_uint(v[3][r]);
-          hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vr, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vr + 16u, 0, 0);
-        } else {
-          u32x4s_t o;
-          o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(o, rC, vr, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);        // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
-    });
-  };
-
-  // ---- prologue of the block's stream: K-tiles 0 and 1 of its first tile
-  d_open_tile(bid);
-  int c_m0 = d_m0, c_n0 = d_n0;                // compute side: the tile being accumulated
-  auto dma_piece = [&](int par, int q) {        // prologue form: M0 and the load in one asm block (one wait state between them)
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + par * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((d_second ? (d_t - nt1) : d_t) * P_BK * 2);
-    const i32x4_t r = q < 8 ? (d_second ? qA2 : qA1) : (d_second ? qB2 : qB1);
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff), "s"(dst) : "memory");
-  };
-#pragma unroll
-  for (int q = 0; q < 16; ++q) dma_piece(0, q);
-  ++d_t;
-  d_advance();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) dma_piece(1, q);
-  ++d_t;
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  W4_PIN();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
-  W4_PIN();
-  int par = 0;
-  for (int it = 0; it < my_tiles; ++it) {
-    tile_body(par, T_{}, T_{}, T_{}); par ^= 1;          // the tile's first K-tile: its first k-half starts the accumulators (C = 0)
-    for (int t = 1; t < nt; ++t) { tile_body(par, T_{}, T_{}, F_{}); par ^= 1; }
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> accumulator reads
-    W4_PIN();
-    if (!(dbg & 1)) store_tile(c_m0, c_n0);
-    W4_PIN();
-    // the DMA side opened the next tile two K-tiles ago and cannot leave it before that tile's K-tile nt-3: its origin is the next compute tile
-    c_m0 = d_m0; c_n0 = d_n0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy K-tiles' DMA writes into this block's LDS must not outlive it
-#undef IC
-#undef W4_PIN
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1909,7 +1563,9 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
   const int c = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
 
+  int seg_no = -1;                     // ordinal of the segment inside this run (empty segments count: the reduce kernel enumerates them the same way)
   while (run_s < run_e) {
+    ++seg_no;
     const long long cidx = run_s / chunk_len;
     const int kin = (int)(run_s % chunk_len), sidx = (int)(cidx / tiles), gtile = (int)(cidx % tiles);
     int pi = 0;
@@ -2054,19 +1710,83 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     W4_PIN();
 #undef W4_PIN
     // D[i = n1][j = n2]: lane holds col n2 = lane & 15, rows n1 = (lane >> 4)*4 + reg
+    if (G.ws) {
+      // deterministic flush: the raw partial tile of this (run, segment) as 64 one-KiB stores per wave, [wave][i][j][lane] float4 -
+      // gemm_tn_reduce_kernel adds a tile's segments in a fixed order (no atomics: LoRA gradients bit-reproducible run to run)
+      float4* slot = (float4*)(G.ws + ((size_t)lrun * G.smax + seg_no) * 65536) + (size_t)wave * 4096 + lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v[4];
-        acc_read4(acc[i][j], v);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          atomicAdd(p.C + (size_t)(n1_0 + wr * 128 + i * 16 + g * 4 + q) * p.ldc + n2_0 + wc * 128 + j * 16 + c, v[q] * p.alpha);
+        for (int j = 0; j < 8; ++j) {
+          float v[4];
+          acc_read4(acc[i][j], v);
+          slot[(i * 8 + j) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v[4];
+          acc_read4(acc[i][j], v);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            atomicAdd(p.C + (size_t)(n1_0 + wr * 128 + i * 16 + g * 4 + q) * p.ldc + n2_0 + wc * 128 + j * 16 + c, v[q] * p.alpha);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __builtin_amdgcn_s_barrier();      // the next run segment re-uses the stages
+  }
+}
+// Deterministic flush of gemm_tn_w4_kernel, part 2: C[tile] += alpha * (sum of the tile's segments, K-chunk by K-chunk and run by run in
+// ascending order).  The segment enumeration is recomputed from the launch geometry exactly as the kernel walks it (run = `per` consecutive
+// K-steps of the (K-chunk, tile, K-step) order; a run's segment s is the part of unit unit0 + s it covers).  Grid (tiles, 4): a block adds 4096
+// float4 (one wave's 128x128 quadrant) of one tile; every element of C is owned by one thread (plain read-modify-write, no atomics).
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTNGroup G, int n_runs) {
+  const int tiles = G.tile_end[G.n - 1];
+  const int ksteps = (G.g[0].M + 63) / 64;
+  const int chunk_len = (ksteps + G.splits - 1) / G.splits;
+  const long long total = (long long)G.splits * tiles * chunk_len;
+  const long long per = (total + n_runs - 1) / n_runs;
+  const int gtile = blockIdx.x;
+  int pi = 0;
+  while (pi + 1 < G.n && gtile >= G.tile_end[pi]) ++pi;
+  const GemmTNArgs& p = G.g[pi];
+  const int tile = gtile - (pi ? G.tile_end[pi - 1] : 0);
+  const int tiles_n2 = p.N2 / 256;
+  const int n1_0 = (tile / tiles_n2) * 256, n2_0 = (tile % tiles_n2) * 256;
+  float4 sum[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sidx = 0; sidx < G.splits; ++sidx) {
+    const long long u = (long long)sidx * tiles + gtile, lo = u * chunk_len, hi = lo + chunk_len;
+    for (long long r = lo / per; r <= (hi - 1) / per && r < n_runs; ++r) {
+      const long long start = max(lo, r * per), end = min(min(hi, (r + 1) * per), total);
+      const int kin = (int)(start - lo), seg = (int)(end - start);
+      const int nt = min(seg, ksteps - (sidx * chunk_len + kin));
+      if (nt <= 0) continue;                                      // the padded tail of the last K-chunk: the kernel wrote nothing
+      const int seg_no = (int)(u - (r * per) / chunk_len);
+      const float4* slot = (const float4*)(G.ws + ((size_t)r * G.smax + seg_no) * 65536) + (size_t)blockIdx.y * 4096 + threadIdx.x;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float4 v = slot[e * 256];
+        sum[e].x += v.x; sum[e].y += v.y; sum[e].z += v.z; sum[e].w += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = blockIdx.y * 4096 + e * 256 + threadIdx.x;      // ((wave*8 + i)*8 + j)*64 + lane
+    const int lane = idx & 63, j = (idx >> 6) & 7, i = (idx >> 9) & 7, wave = idx >> 12;
+    const int row = n1_0 + (wave >> 1) * 128 + i * 16 + (lane >> 4) * 4, col = n2_0 + (wave & 1) * 128 + j * 16 + (lane & 15);
+    float* cp = p.C + (size_t)row * p.ldc + col;
+    cp[0] += sum[e].x * p.alpha;
+    cp[(size_t)p.ldc] += sum[e].y * p.alpha;
+    cp[2 * (size_t)p.ldc] += sum[e].z * p.alpha;
+    cp[3 * (size_t)p.ldc] += sum[e].w * p.alpha;
   }
 }
 }  // namespace
@@ -2086,32 +1806,24 @@ bool opadpo_flag_tr() { return g_use_tr; }
 
 // piece order of the 4-wave 256x256 kernel by shape (see gemm_nt_w4_kernel): B half first for N <= 16 column tiles
 static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B first (experiments)
-// persistent form (gemm_nt_w4p_kernel) for direct-epilogue problems of more than one round of tiles: 256 workgroups walk the tile list.
-// OPADPO_W4P=0 keeps one tile per workgroup (A/B); variant 31 (the tests' bit-for-bit cross-check) never takes it.
-static int g_w4p = -1;
-static int g_w4p_dbg = -1;
-#define W4P_GO(OB_, F32_) hipLaunchKernelGGL((gemm_nt_w4p_kernel<OB_, F32_>), dim3(256), dim3(256), 2 * P_STAGE, st, a, (int)tiles_, g_w4p_dbg)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
-    const int tiles_ = (int)(GRID_);                                                                                         \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
-    const bool pers_ = g_w4p != 0 && g_gemm_variant != 31 && tiles_ > 256 && !a.R && !a.act && !a.rope_cos && !a.rope_pos &&  \
-                       !a.bias && a.alpha == 1.0f && (a.K1 + a.K2) / P_BK >= 3 &&                                             \
-                       ((unsigned long long)a.M + 256ull) * (unsigned)a.ldc * (a.out_f32 ? 4u : 2u) < 0xffffffffull;          \
-    if (pers_) {                                                                                                             \
-      if (ob_) { if (a.out_f32) W4P_GO(true, true); else W4P_GO(true, false); }                                              \
-      else     { if (a.out_f32) W4P_GO(false, true); else W4P_GO(false, false); }                                            \
-    }                                                                                                                        \
-    else if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(tiles_), dim3(256), 2 * P_STAGE, st, a);                   \
-    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(tiles_), dim3(256), 2 * P_STAGE, st, a);                           \
+    if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                         \
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                            \
   } while (0)
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
   GemmNTArgs a = a_in;
   if (g_w4_order == -1) { const char* v = getenv("OPADPO_W4_ORDER"); g_w4_order = v ? atoi(v) : -2; }
-  if (g_w4p == -1) { const char* v = getenv("OPADPO_W4P"); g_w4p = v ? atoi(v) : 1; }
-  if (g_w4p_dbg == -1) { const char* v = getenv("OPADPO_W4P_DBG"); g_w4p_dbg = v ? atoi(v) : 0; }
+  // C leaves the 4-wave 256x256 kernel's direct epilogue as NON-TEMPORAL stores (round 4): at the end of a round all 256 workgroups write
+  // their 128-256 KiB of results at once - a 32-64 MB burst that drains at the fabric's write rate (the no-store diagnostic of the
+  // persistent-loop experiment put it at 4-5 us of a ~100 us tile) while nothing computes; streaming stores do not fight the operand
+  // panels for the 4-MiB L2s.  Same-box sustained A/B at M = 24576 (tools/ab_env.sh, profiles/r04_ab_nt_stores.txt): q|k|v +0.9 %, o
+  // (fp32 out) +2.5 %, gate|up +0.6 %, down (fp32 out) +1.0 %, N = 768 +1.2 %.  OPADPO_W4_NT=0 keeps write-back stores (A/B).
+  static const int env_nt = getenv("OPADPO_W4_NT") ? atoi(getenv("OPADPO_W4_NT")) : 1;
+  a.store_nt = env_nt;
   // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
   // (N <= 4096: o / down and three of the four dgrads) - measured at M = 32362: down 1.363 -> 1.397 PF/s, o 1.394 -> 1.401,
   // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).
@@ -2126,10 +1838,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
@@ -2255,6 +1963,58 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   return hipGetLastError();
 }
 
+// grid + flush geometry of one launch of gemm_tn_w4_kernel over the group's tile list
+static void tn_w4_geometry(GemmTNGroup& G, int& n_runs, int& smax) {
+  const int tiles = G.tile_end[G.n - 1], ksteps = (G.g[0].M + 63) / 64;
+  G.splits = (256 + tiles - 1) / tiles;                          // K-chunks: about one run per CU and chunk-tile
+  if (G.splits > ksteps) G.splits = ksteps;
+  const int chunk_len = (ksteps + G.splits - 1) / G.splits;
+  const long long total = (long long)G.splits * tiles * chunk_len;
+  n_runs = (int)(total < 256 ? total : 256);
+  const long long per = (total + n_runs - 1) / n_runs;
+  smax = (int)((per - 1) / chunk_len) + 2;                       // units a run of `per` consecutive K-steps can touch
+}
+static hipError_t tn_w4_launch(GemmTNGroup& G, hipStream_t st, void* ws, size_t ws_bytes) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    attr = true;
+  }
+  int n_runs, smax;
+  tn_w4_geometry(G, n_runs, smax);
+  const size_t need = (size_t)n_runs * smax * 65536 * sizeof(float);
+  const bool det = ws && ws_bytes >= need;
+  G.ws = det ? (float*)ws : nullptr;
+  G.smax = det ? smax : 0;
+  hipLaunchKernelGGL(gemm_tn_w4_kernel, dim3(n_runs), dim3(256), 2 * P_STAGE, st, G);
+  if (det) hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(G.tile_end[G.n - 1], 4), dim3(256), 0, st, G, n_runs);      // 4 x 4096 float4 = one 256x256 tile
+  return hipGetLastError();
+}
+static bool tn_w4_ok(const GemmTNArgs& a, int M0) {
+  const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
+  return a.M == M0 && a.M > 0 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0) &&
+         (a.use_tr < 0 ? g_tn_w4 != 0 : (a.use_tr & 8) == 0);
+}
+size_t gemm_tn_group_workspace_bytes(const GemmTNArgs* list, int n) {
+  // worst case over the ways launch_gemm_tn_group may run the list: one grouped launch, or one launch per problem (problems of different M)
+  size_t need = 0;
+  auto one = [&](const GemmTNArgs* l, int k) {
+    GemmTNGroup G;
+    G.n = k;
+    int tiles = 0;
+    for (int i = 0; i < k; ++i) { G.g[i] = l[i]; tiles += (l[i].N1 / 256) * (l[i].N2 / 256); G.tile_end[i] = tiles; }
+    int n_runs, smax;
+    tn_w4_geometry(G, n_runs, smax);
+    need = std::max(need, (size_t)n_runs * smax * 65536 * sizeof(float));
+  };
+  if (n <= 0 || n > 8) return 0;
+  bool group = true;
+  for (int i = 0; i < n; ++i) group = group && tn_w4_ok(list[i], list[0].M);
+  if (group) one(list, n);
+  for (int i = 0; i < n; ++i) if (tn_w4_ok(list[i], list[i].M)) one(list + i, 1);
+  return need;
+}
+
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
   if (a.N1 % 128 || a.N2 % 128) return hipErrorInvalidValue;
@@ -2262,21 +2022,10 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
   const bool tn_w4 = a.use_tr >= 0 ? (a.use_tr & 8) == 0 : g_tn_w4 != 0;
   const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
   if (tn_w4 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0)) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-      attr = true;
-    }
     GemmTNGroup G;
     G.g[0] = a; G.n = 1;
-    const int tiles4 = (a.N1 / 256) * (a.N2 / 256), ksteps = (a.M + 63) / 64;
-    G.tile_end[0] = tiles4;
-    G.splits = (256 + tiles4 - 1) / tiles4;                      // K-chunks: about one run per CU and chunk-tile
-    if (G.splits > ksteps) G.splits = ksteps;
-    const long long total = (long long)G.splits * tiles4 * ((ksteps + G.splits - 1) / G.splits);
-    const dim3 gr((unsigned)(total < 256 ? total : 256));
-    hipLaunchKernelGGL(gemm_tn_w4_kernel, gr, dim3(256), 2 * P_STAGE, st, G);
-    return hipGetLastError();
+    G.tile_end[0] = (a.N1 / 256) * (a.N2 / 256);
+    return tn_w4_launch(G, st, nullptr, 0);
   }
   const int tiles = (a.N1 / 128) * (a.N2 / 128);
   int splits = a.splits;
@@ -2348,26 +2097,24 @@ int gemm_nt_dec64_splits(int N, int K, int splits) {
   return splits > nt ? nt : splits;
 }
 
-hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st) {
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace, size_t workspace_bytes) {
   if (n <= 0) return hipSuccess;
-  bool ok = n <= 8 && g_tn_w4;
-  for (int i = 0; i < n && ok; ++i) {
-    const GemmTNArgs& a = list[i];
-    const bool off32 = (double)a.M * a.ldp * 2 < 4.0e9 && (double)a.M * a.ldq * 2 < 4.0e9;
-    ok = a.M == list[0].M && a.M > 0 && a.splits <= 0 && off32 && a.N1 % 256 == 0 && a.N2 % 256 == 0 && (a.q_group_n1 <= 0 || a.q_group_n1 % 256 == 0) &&
-         (a.use_tr < 0 || (a.use_tr & 8) == 0);
-  }
-  if (!ok) {                                   // not groupable: one launch per problem
+  bool ok = n <= 8;
+  for (int i = 0; i < n && ok; ++i) ok = tn_w4_ok(list[i], list[0].M);
+  if (!ok) {                                   // not groupable (e.g. the compact top layer: two row counts): one launch per problem
     for (int i = 0; i < n; ++i) {
-      const hipError_t e = launch_gemm_tn(list[i], st);
+      hipError_t e;
+      if (list[i].M > 0 && tn_w4_ok(list[i], list[i].M)) {
+        GemmTNGroup G;
+        G.g[0] = list[i]; G.n = 1;
+        G.tile_end[0] = (list[i].N1 / 256) * (list[i].N2 / 256);
+        e = tn_w4_launch(G, st, workspace, workspace_bytes);      // launches of one stream run in order: the workspace is free again
+      } else {
+        e = launch_gemm_tn(list[i], st);
+      }
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
-  }
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    attr = true;
   }
   GemmTNGroup G;
   G.n = n;
@@ -2377,11 +2124,5 @@ hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st) {
     tiles += (list[i].N1 / 256) * (list[i].N2 / 256);
     G.tile_end[i] = tiles;
   }
-  const int ksteps = (list[0].M + 63) / 64;
-  G.splits = (256 + tiles - 1) / tiles;
-  if (G.splits > ksteps) G.splits = ksteps;
-  const long long total = (long long)G.splits * tiles * ((ksteps + G.splits - 1) / G.splits);
-  const dim3 gr((unsigned)(total < 256 ? total : 256));
-  hipLaunchKernelGGL(gemm_tn_w4_kernel, gr, dim3(256), 2 * P_STAGE, st, G);
-  return hipGetLastError();
+  return tn_w4_launch(G, st, workspace, workspace_bytes);
 }

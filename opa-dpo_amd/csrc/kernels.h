@@ -37,6 +37,7 @@ struct GemmNTArgs {
   // tile0 + (b >> 2) of the 4-wave kernel's grouped tile order - the full K range, so every output element keeps the summation order
   // it has inside a 256x256 tile (results do not depend on which tiles fall into the tail, i.e. on the row count of the batch)
   int quarter = 0;
+  int store_nt = 0;                     // direct epilogue of the 256x256 4-wave kernels: non-temporal C stores (set by launch_gemm_nt)
 };
 
 struct GemmTNArgs {
@@ -84,6 +85,10 @@ struct GemmTNGroup {
   int n;
   int splits;
   int tile_end[8];      // cumulative 256x256 tile counts
+  // deterministic flush (round 4): a run's partial tiles go to ws[(run * smax + segment) * 65536 floats] as plain stores and
+  // gemm_tn_reduce_kernel adds the segments of every tile in a fixed order; ws = nullptr keeps the fp32-atomic flush
+  float* ws = nullptr;
+  int smax = 0;
 };
 
 void opadpo_set_flags_impl(int use_glds, int use_tr);
@@ -94,7 +99,9 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
 // all problems must share M and be eligible for the 256x256 kernel (N1, N2 % 256 == 0, q_group_n1 % 256 == 0); otherwise the
 // problems are launched one by one
-hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st);
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0);
+// bytes of workspace that make a grouped launch of these problems deterministic (0: the problems do not run on the 256x256 kernel)
+size_t gemm_tn_group_workspace_bytes(const GemmTNArgs* list, int n);
 
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_bwd(const AttnArgs& a, hipStream_t st);
@@ -106,7 +113,7 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
 int gemm_nt_dec64_splits(int N, int K, int splits);
 hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
-hipError_t launch_layernorm_fwd(const bf16_t* x, const bf16_t* w, const bf16_t* b, bf16_t* y, int rows, int H, float eps, hipStream_t st);
+hipError_t launch_layernorm_fwd(const void* x, const bf16_t* w, const bf16_t* b, void* y, int rows, int H, float eps, hipStream_t st, int x_f32 = 0, int y_f32 = 0);
 hipError_t launch_layernorm_bwd(const bf16_t* dy, const bf16_t* x, const bf16_t* w, const bf16_t* dres, bf16_t* dx, int rows, int H,
                                 float eps, hipStream_t st);
 hipError_t launch_act_fwd(const bf16_t* z, bf16_t* out, size_t n, int act, hipStream_t st);
@@ -120,7 +127,7 @@ hipError_t launch_embed_splice(const int32_t* ids, const uint8_t* text_mask, con
                                const int32_t* feat_row, const uint8_t* image_mask, void* x, int x_f32, uint8_t* key_mask,
                                int S, int n_txt, int P, int H, int image_token, hipStream_t st);
 hipError_t launch_im2col(const bf16_t* pixels, bf16_t* out, int B, int image_size, int patch, int kpad, hipStream_t st);
-hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* x, int B, int P, int h, hipStream_t st);
+hipError_t launch_vision_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, void* x, int B, int P, int h, hipStream_t st, int x_f32 = 0);
 hipError_t launch_gather_rows(const bf16_t* src, int ld_src, const int32_t* rows_idx, bf16_t* dst, int n, int H, hipStream_t st);
 hipError_t launch_scatter_add_rows_f32(const float* src, const int32_t* rows_idx, float* dst, int ld_dst, int n, int H, hipStream_t st);
 hipError_t launch_scatter_rows(const bf16_t* src, const int32_t* rows_idx, bf16_t* dst, int ld_dst, int n, int H, hipStream_t st);

@@ -34,11 +34,13 @@ SIGNATURES = {
     "opadpo_rmsnorm_sum_fwd": [_p, _i, _p, _i, _sz, _p, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_gemm_tn": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "opadpo_gemm_tn_group": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p],
+    "opadpo_gemm_tn_group_det": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _p, _sz, _p],
     "opadpo_attn_fwd": [_p, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_attn_bwd": [_p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "opadpo_rmsnorm_fwd": [_p, _i, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_rmsnorm_bwd": [_p, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _p],
     "opadpo_layernorm_fwd": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "opadpo_layernorm_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "opadpo_layernorm_bwd": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
     "opadpo_act_fwd": [_p, _p, _sz, _i, _p],
     "opadpo_act_bwd": [_p, _p, _p, _sz, _i, _p],
@@ -48,6 +50,7 @@ SIGNATURES = {
     "opadpo_embed_splice": [_p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "opadpo_im2col": [_p, _p, _i, _i, _i, _i, _p],
     "opadpo_vision_embed": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "opadpo_vision_embed_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
     "opadpo_gather_rows": [_p, _i, _p, _p, _i, _i, _p],
     "opadpo_scatter_rows": [_p, _p, _p, _i, _i, _i, _p],
     "opadpo_scatter_add_rows_f32": [_p, _p, _p, _i, _i, _i, _p],
@@ -89,7 +92,7 @@ SIGNATURES.update({
     "opadpo_decode_all_finished": [_p, _p, _p],
     "opadpo_decode_end": [_p],
 })
-OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes",
+OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes", "opadpo_gemm_tn_group_workspace_bytes",
                  "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_ctx_bytes_peak"]
 
 _lib: Optional[C.CDLL] = None
@@ -124,6 +127,9 @@ def load() -> C.CDLL:
     lib.opadpo_set_flags.restype = None
     lib.opadpo_attn_decode_workspace_bytes.argtypes = [_i, _i, _i, _i]
     lib.opadpo_attn_decode_workspace_bytes.restype = _sz
+    if hasattr(lib, "opadpo_gemm_tn_group_workspace_bytes"):
+        lib.opadpo_gemm_tn_group_workspace_bytes.argtypes = [_i, _i, _p, _p, _p]
+        lib.opadpo_gemm_tn_group_workspace_bytes.restype = _sz
     lib.opadpo_ctx_destroy.argtypes = [_p]
     lib.opadpo_ctx_destroy.restype = None
     lib.opadpo_ctx_last_error.argtypes = [_p]

@@ -331,10 +331,11 @@ class LlavaEngine:
         L.gemm_nt(cols, b.patch_w, patches)
         T = P + 1
         M = B * T
-        x = self.buf("v_x", (M, vh))
-        L.call("opadpo_vision_embed", L.ptr(patches), L.ptr(b.cls), L.ptr(b.pos), L.ptr(x), B, P, vh, st)
-        x2 = self.buf("v_x2", (M, vh))
-        L.call("opadpo_layernorm_fwd", L.ptr(x), L.ptr(b.pre_ln_w), L.ptr(b.pre_ln_b), L.ptr(x2), M, vh, d.v_eps, st)
+        # fp32 residual stream through the tower (round 4; same sequence as opadpo_vision_encode, bit for bit)
+        x = self.buf("v_x32", (M, vh), torch.float32)
+        L.call("opadpo_vision_embed_f32", L.ptr(patches), L.ptr(b.cls), L.ptr(b.pos), L.ptr(x), B, P, vh, st)
+        x2 = self.buf("v_x2_32", (M, vh), torch.float32)
+        L.call("opadpo_layernorm_fwd_f32", L.ptr(x), L.ptr(b.pre_ln_w), L.ptr(b.pre_ln_b), L.ptr(x2), 1, M, vh, d.v_eps, st)
         x, x2 = x2, x
         n = self.buf("v_n", (M, vh))
         qkv = self.buf("v_qkv", (M, 3 * vh))
@@ -342,19 +343,20 @@ class LlavaEngine:
         f1 = self.buf("v_f1", (M, vf))
         hd = vh // d.v_heads
         for w in b.vlayers:
-            L.call("opadpo_layernorm_fwd", L.ptr(x), L.ptr(w["layer_norm1_w"]), L.ptr(w["layer_norm1_b"]), L.ptr(n), M, vh, d.v_eps, st)
+            L.call("opadpo_layernorm_fwd_f32", L.ptr(x), L.ptr(w["layer_norm1_w"]), L.ptr(w["layer_norm1_b"]), L.ptr(n), 0, M, vh, d.v_eps, st)
             L.gemm_nt(n, w["wqkv"], qkv, bias=w["bqkv"])
             L.call("opadpo_attn_fwd", L.ptr(qkv), qkv.data_ptr() + 2 * vh, qkv.data_ptr() + 4 * vh, 3 * vh, L.ptr(att), vh,
                    None, None, B, T, d.v_heads, hd, 0, hd ** -0.5, 0, 0, st)
             L.gemm_nt(att, w["wo"], x2, bias=w["bo"], residual=x)
-            L.call("opadpo_layernorm_fwd", L.ptr(x2), L.ptr(w["layer_norm2_w"]), L.ptr(w["layer_norm2_b"]), L.ptr(n), M, vh, d.v_eps, st)
+            L.call("opadpo_layernorm_fwd_f32", L.ptr(x2), L.ptr(w["layer_norm2_w"]), L.ptr(w["layer_norm2_b"]), L.ptr(n), 0, M, vh, d.v_eps, st)
             L.gemm_nt(n, w["fc1"], f1, bias=w["b1"], act=L.ACT_QUICK_GELU)
             L.gemm_nt(f1, w["fc2"], x, bias=w["b2"], residual=x2)
         # drop CLS
         idx = (torch.arange(B, device=self.dev, dtype=torch.int32)[:, None] * T
                + torch.arange(1, T, device=self.dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
         tok = self.buf("v_tok", (B * P, vh))
-        L.call("opadpo_gather_rows", L.ptr(x), vh, L.ptr(idx), L.ptr(tok), B * P, vh, st)
+        L.call("opadpo_f32_to_bf16", L.ptr(x), L.ptr(n), M * vh, st)
+        L.call("opadpo_gather_rows", L.ptr(n), vh, L.ptr(idx), L.ptr(tok), B * P, vh, st)
         h0 = self.buf("v_h0", (B * P, d.hidden))
         L.gemm_nt(tok, b.proj0, h0, bias=b.proj0_b, act=L.ACT_GELU)
         feats = torch.empty(B * P, d.hidden, dtype=BF, device=self.dev)

@@ -1001,59 +1001,6 @@ def test_gemm_nt_split_k_tail(L, R, K, r, mode):
     assert torch.equal(got[:M], small), "256x256 dispatch != 128x128 kernel"
 
 
-@pytest.mark.parametrize("N,R,K,r,grp,f32", [
-    (4096, 40, 512, 0, 0, False),      # 640 tiles: blocks walk 2 or 3 tiles each, B-first piece order, nt = 8
-    (4096, 40, 192, 0, 0, True),       # nt = 3 (odd: the LDS stage parity of a tile's first K-tile alternates), fp32 out
-    (8192, 20, 256, 64, 0, False),     # A-first piece order (N > 4096), K-concatenated tail, nt = 5
-    (4096, 33, 320, 128, 2048, True),  # 512 persistent tiles + a 16-tile quarter tail; tail operand grouped by output column
-    (8192, 11, 128, 64, 4096, False),  # 352 tiles (one block in three walks two), nt = 3 with the operand switch inside
-])
-def test_gemm_nt_persistent_is_bit_identical(L, N, R, K, r, grp, f32):
-    """Round 4: direct-epilogue problems of more than one round of 256x256 tiles run on the PERSISTENT kernel (gemm_nt_w4p_kernel: 256
-    workgroups walk the tile list, the K-tile stream of one tile runs on into the next).  Every tile is still computed by one workgroup
-    over the full K range in the same k order -> bit-identical to the one-tile-per-workgroup kernel on every tile (variant 31) and to
-    the 128x128 kernel (variant 4); rows >= M untouched; repeated launches identical (the cross-tile DMA / vmcnt bookkeeping is race-free)."""
-    L.set_flags(10, True)
-    M = R * 256 - 77
-    x, w = rnd(M, K, seed=11), rnd(N, K, scale=0.05, seed=12)
-    kw = {}
-    if r:
-        G = N // grp if grp else 1
-        kw = dict(a2=rnd(M, G * r, seed=13), b2=rnd(N, r, scale=0.05, seed=14))
-        if grp:
-            kw.update(a2_group_n=grp, a2_group_stride=r)
-    want = x.float() @ w.float().t()
-    if r:
-        a2f, b2f = kw["a2"].float(), kw["b2"].float()
-        if grp:
-            for gi in range(N // grp):
-                want[:, gi * grp:(gi + 1) * grp] += a2f[:, gi * r:(gi + 1) * r] @ b2f[gi * grp:(gi + 1) * grp].t()
-        else:
-            want += a2f @ b2f.t()
-    dt = torch.float32 if f32 else BF
-    got = torch.full((M + 3, N), 7.0, dtype=dt, device=dev())
-    L.gemm_nt(x, w, got[:M], **kw)
-    runs = []
-    for _ in range(3):
-        o = torch.empty(M, N, dtype=dt, device=dev())
-        L.gemm_nt(x, w, o, **kw)
-        runs.append(o)
-    L.set_flags(31, True)
-    whole = torch.empty(M, N, dtype=dt, device=dev())
-    L.gemm_nt(x, w, whole, **kw)
-    L.set_flags(4, True)
-    small = torch.empty(M, N, dtype=dt, device=dev())
-    L.gemm_nt(x, w, small, **kw)
-    L.set_flags(10, True)
-    torch.cuda.synchronize()
-    assert relerr(got[:M], want) < (3e-3 if not f32 else 2e-5 * ((K + r) ** 0.5))
-    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
-    for o in runs:
-        assert torch.equal(got[:M], o)
-    assert torch.equal(got[:M], whole), "persistent tile loop != one 256x256 tile per workgroup"
-    assert torch.equal(got[:M], small), "persistent tile loop != 128x128 kernel"
-
-
 @pytest.mark.parametrize("M,F,K,r", [(300, 256, 128, 64), (1000, 768, 256, 0), (257, 1536, 512, 256), (3, 256, 64, 64)])
 def test_gemm_nt_swiglu_bwd(L, M, F, K, r):
     """ACT_SWIGLU_BWD: dgrad of the down projection (+ K-concatenated LoRA tail) with opadpo_silu_mul_bwd in its epilogue ==
@@ -1299,6 +1246,71 @@ def test_gemm_tn_group_equals_single_launches(L):
            one(o2.data_ptr(), C.c_void_p), one(128, C.c_int), M, one(256, C.c_int), one(128, C.c_int), None, None, 1.0, L.stream())
     torch.cuda.synchronize()
     assert relerr(o2, o1) < 1e-5 and relerr(o1, P.float().t() @ Q.float()) < 1e-4
+
+
+@pytest.mark.parametrize("M", [3000, 24500, 130])
+def test_gemm_tn_group_deterministic_form(L, M):
+    """opadpo_gemm_tn_group_det (round 4; what the context's backward runs): partial tiles to a workspace + ordered reduce instead of fp32
+    atomics.  == torch fp32, == the atomic form up to summation order, ACCUMULATES into C (gradient accumulation), and repeated launches are
+    BIT-identical (the atomic form is not).  M = 24500: the bench's ragged row count (383 K-steps of 64 rows, one run per CU crossing tiles);
+    M = 130: fewer K-steps than K-chunks.  The same call on one problem at a time (the compact top layer's fallback) agrees bit for bit with
+    itself over repeats too; a too-small workspace and a problem the 256x256 kernel cannot take are refused."""
+    import ctypes as C
+    H, F, r = 1024, 2816, 256
+    g = torch.Generator().manual_seed(5)
+    mk = lambda n: (torch.randn(M, n, generator=g) * 0.3).to(BF).to(dev())
+    dY, t_d, dt_r, act, d_gu, t_gu, dt_2r, n2 = mk(H), mk(r), mk(r), mk(F), mk(2 * F), mk(2 * r), mk(2 * r), mk(H)
+    probs = [(dY, t_d, H, r, 0, 0), (dt_r, act, r, F, 0, 0), (d_gu, t_gu, 2 * F, r, F, r), (dt_2r, n2, 2 * r, H, 0, 0),
+             (dY, t_d, H, r, 0, 0), (dt_r, n2, r, H, 0, 0), (dt_2r, act, 2 * r, F, 0, 0)]
+    lib = L.load()
+
+    def arrs(ps, outs):
+        n = len(ps)
+        arr = lambda vals, T: (T * n)(*vals)
+        return (n, arr([p_[0].data_ptr() for p_ in ps], C.c_void_p), arr([p_[0].stride(0) for p_ in ps], C.c_int),
+                arr([p_[1].data_ptr() for p_ in ps], C.c_void_p), arr([p_[1].stride(0) for p_ in ps], C.c_int),
+                arr([o.data_ptr() for o in outs], C.c_void_p), arr([o.stride(0) for o in outs], C.c_int), M,
+                arr([p_[2] for p_ in ps], C.c_int), arr([p_[3] for p_ in ps], C.c_int), arr([p_[4] for p_ in ps], C.c_int), arr([p_[5] for p_ in ps], C.c_int), 1.0)
+
+    def need_of(ps):
+        n = len(ps)
+        arr = lambda vals: (C.c_int * n)(*vals)
+        return lib.opadpo_gemm_tn_group_workspace_bytes(n, M, arr([p_[2] for p_ in ps]), arr([p_[3] for p_ in ps]), arr([p_[4] for p_ in ps]))
+
+    need = need_of(probs)
+    assert 0 < need <= 256 * 3 * 65536 * 4
+    ws = torch.empty(need, dtype=torch.uint8, device=dev())
+
+    def run(det, base=0.0, ps=probs):
+        outs = [torch.full((n1, n2_), base, device=dev()) for _, _, n1, n2_, _, _ in ps]
+        a = arrs(ps, outs)
+        if det:
+            L.call("opadpo_gemm_tn_group_det", *a, ws.data_ptr(), need, L.stream())
+        else:
+            L.call("opadpo_gemm_tn_group", *a, L.stream())
+        torch.cuda.synchronize()
+        return outs
+
+    d1, d2, at = run(True), run(True), run(False)
+    for (P, Q, n1, n2_, qg, qs), a, b, c in zip(probs, d1, d2, at):
+        if qg:
+            want = torch.cat([P[:, i * qg:(i + 1) * qg].float().t() @ Q[:, i * qs:i * qs + n2_].float() for i in range(n1 // qg)], 0)
+        else:
+            want = P.float().t() @ Q[:, :n2_].float()
+        assert relerr(a, want) < 1e-4 and relerr(a, c) < 1e-5
+        assert torch.equal(a, b), "deterministic wgrad flush differs between two launches"
+    acc = run(True, base=1.5)                                       # C is accumulated into, not overwritten
+    for a, b in zip(d1, acc):
+        assert float((b - 1.5 - a).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-6
+    for k in (0, 2):                                                # one problem per call (how a list of mixed row counts is run)
+        s1, s2 = run(True, ps=probs[k:k + 1])[0], run(True, ps=probs[k:k + 1])[0]
+        assert torch.equal(s1, s2) and relerr(s1, d1[k]) < 1e-5
+    with pytest.raises(L.OpadpoError):
+        L.call("opadpo_gemm_tn_group_det", *arrs(probs, d1), ws.data_ptr(), need - 1, L.stream())
+    bad = [(mk(256), mk(128), 256, 128, 0, 0)]
+    assert need_of(bad) == 0
+    with pytest.raises(L.OpadpoError):
+        L.call("opadpo_gemm_tn_group_det", *arrs(bad, [torch.zeros(256, 128, device=dev())]), ws.data_ptr(), need, L.stream())
 
 
 @pytest.mark.parametrize("seg", [(0, 0), (200, 140)])

@@ -109,7 +109,7 @@ def test_logprobs_forward(setup, pack, merged):
     against the same oracle numbers; its bf16-emulating oracle rounds the merged weights once, like the HIP pipeline."""
     s = setup
     LR = s["LR"]
-    B, Q, T = 2, 12, 9
+    B, Q, T = 4, 12, 17       # round 4: 4 x 17 instead of 2 x 9 - a response key held ~10 valid tokens, and the ratio to the oracle's own floor was a coin toss
     images, queries, qmask, resp = make_inputs(s["d"], B, Q, T)
     pol = _policy(s, s["ref_merged"] if merged else s["ref"], T, pack)
     out = pol(images=images.to(s["dev"]), queries=queries, queries_attn_masks=qmask, temperature=0.9, **resp)
@@ -156,7 +156,7 @@ def test_logprobs_forward(setup, pack, merged):
         assert float((ge - want32[k + "_entropies"]).abs().max()) < 5e-2
     # north_star's 1e-3 on the mean against the bf16-emulating oracle where the oracle's own two realisations allow it, and never
     # further from the oracle than 1.35 x the distance between those realisations
-    # (54 tokens only at these tiny dims: the ratio to the floor is itself noisy -> 1.5 x here, 1.35 x in the 5 000-row tests)
+    # (~120 tokens only at these tiny dims: the ratio to the floor is itself noisy -> 1.5 x here, 1.35 x in the 5 000-row tests)
     assert worst16 < max(1e-3, 1.5 * floor) and worst16 < 1.6e-3, f"mean relative log-prob error vs bf16-emulating oracle {worst16} (oracle self-noise {floor})"
     assert worst32 < 5e-3, f"mean relative log-prob error vs fp32 oracle {worst32}"
 

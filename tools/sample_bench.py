@@ -28,7 +28,7 @@ def main():
     B = int(os.environ.get("SB_BATCH", 8))            # samples per micro-batch (the reference runs 2 on 80-GB parts)
     steps = int(os.environ.get("SB_STEPS", 3))
     pack = os.environ.get("SB_PACK", "1") == "1"
-    Q, T = 128, 384
+    Q, T = 128, int(os.environ.get("SB_T", 384))      # SB_T=896: the shipped recipe's response_len (run/train_opa_dpo.sh)
     d = LlavaDims.llava15_7b()
     base = BaseWeights(d, init_weights(d, seed=0, device=dev), dev, need_backward=True)
     eng = LlavaEngine(base) if os.environ.get("OPADPO_OP_LEVEL") == "1" else CtxEngine(base)      # default: the product path (opadpo_ctx, ragged rows)
@@ -51,8 +51,8 @@ def main():
         stats = tr.step(it, i + 1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    out = {"metric": "OPA-DPO samples/s (3 responses + CoPO masked image + AncPO), LLaVA-1.5-7B LoRA r256, seq512, 1x MI355X",
-           "value": B / dt, "unit": "samples/s", "samples_per_step": B, "ms_per_step": dt * 1e3,
+    out = {"metric": f"OPA-DPO samples/s (3 responses + CoPO masked image + AncPO), LLaVA-1.5-7B LoRA r256, query {Q} + response {T}, 1x MI355X",
+           "value": B / dt, "unit": "samples/s", "samples_per_step": B, "ms_per_step": dt * 1e3, "steps": steps, "query_len": Q, "response_len": T,
            "response_layout": "packed on the shared prefix" if pack else "stacked (reference layout)",
            "sequence_forwards_per_sample": {"reference_no_grad": 5, "policy_with_grad": 5,
                                             "note": "the reference additionally runs a discarded 3-sequence policy forward inside rollout() (Quirk Q2)"},
