@@ -21,6 +21,7 @@
 // access patterns (row fragments via ds_read_b128, transposed fragments via ds_read_b64_tr_b16):
 //   HD=128 (256-B rows): chunk ^= (row & 7) << 1      HD=64 (128-B rows): chunk ^= ((row >> 1) & 3) << 1
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -490,6 +491,7 @@ __device__ __forceinline__ int off32(int row, int c16) {
 // the dQ kernel's V tile: with the flip its row-read offsets differ from the K tile's (which cannot take it, above) and the second set of
 // eight address registers spills too (60 bytes of scratch per lane, measured slower) - both tiles keep ONE set of offsets, no flip
 constexpr bool DQ32_VFLIP = false;
+constexpr int DQ32_PF = 1;        // prefetch depth of the dQ kernel's K / V row fragments (k-steps ahead of their MFMAs)
 template <bool FLIP = false>
 __device__ __forceinline__ void tile_commit_v(char* dst, const TileRegs<128>& r, int tid) {
 #pragma unroll
@@ -571,11 +573,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
   const float scale2 = p.scale * 1.4426950408889634f;
   const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
-  TileRegs<HD> kreg, vreg;
+  // ONE 16-register staging image used twice per iteration (round 4): next K tile fetched at the top and written to the other ring buffer
+  // after the S^T phase, next V tile fetched there and written at the end (two images in flight held 32 registers across the iteration)
+  TileRegs<HD> kreg;
   tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
-  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
   tile_commit_k32(smem, kreg, tid);
-  tile_commit_v(smem + TILE, vreg, tid);
+  tile_fetch<HD>(kreg, vsrc, p.ld, sk.first() * 64);
+  tile_commit_v(smem + TILE, kreg, tid);
   stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   int cur = 0;
   const int krow_off = ql * 256;                          // K fragment: row kb*32 + ql, 16-byte chunk ks*2 + hi, swizzle kswz32(row) (bit 4 of the row = bit 4 of ql)
@@ -588,24 +592,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     const char* const Vs = Ks + TILE;
     const uint8_t* const Ms = ms_base + cur * 80;
     __syncthreads();                                      // tile kt is in LDS for everyone; everyone has left the other buffer
-    if (nxt < n_kt) {
-      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
-      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
-    }
+    char* const nb = smem + (cur ^ 1) * 2 * TILE;
+    if (nxt < n_kt) tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
     // tiles none of this wave's rows can see: beyond its causal diagonal, or wholly inside the responses its rows exclude
     const bool dead = !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first);
+    f32x16_t sc[2];
     if (!dead) {
-      f32x16_t sc[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+      {
+        // S^T = K . Q^T with the K fragments of BOTH 32-key blocks requested FWD32_PF k-steps ahead of the MFMAs that consume them and the
+        // two accumulator chains interleaved (round 4).  Left to itself the compiler issued read -> s_waitcnt -> MFMA eight times in a row
+        // for the first block (every MFMA behind the full LDS latency of the read in front of it) and then eight dependent MFMAs for the second.
+        constexpr int PF = 2;
+        bf16x8_t kfr[PF + 1][2];
+        auto kread = [&](int ks, int kb) {
+          return *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
+        };
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) { kfr[ks][0] = kread(ks, 0); kfr[ks][1] = kread(ks, 1); }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
-          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+          if (ks + PF < 8) { kfr[(ks + PF) % (PF + 1)][0] = kread(ks + PF, 0); kfr[(ks + PF) % (PF + 1)][1] = kread(ks + PF, 1); }
+          __builtin_amdgcn_sched_barrier(0);
+          sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks % (PF + 1)][0], qf[ks], sc[0], 0, 0, 0);
+          sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks % (PF + 1)][1], qf[ks], sc[1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+    }
+    if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
+      tile_commit_k32(nb, kreg, tid);
+      tile_fetch<HD>(kreg, vsrc, p.ld, nxt * 64);
+    }
+    if (!dead) {
       // sc[kb][r] = S^T[key = k0 + kb*32 + 8*(r >> 2) + 4*hi + (r & 3)][q = qpos], raw (unscaled) scores
       const bool clean = !Ms[64] && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
       float mx = -INFINITY;
@@ -685,10 +707,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           }
         }
     }
-    if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
-      char* const nb = smem + (cur ^ 1) * 2 * TILE;
-      tile_commit_k32(nb, kreg, tid);
-      tile_commit_v(nb + TILE, vreg, tid);
+    if (nxt < n_kt) {
+      tile_commit_v(nb + TILE, kreg, tid);
       stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
     }
     cur ^= 1;
@@ -1126,11 +1146,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
   const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;
   const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
   const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
-  TileRegs<HD> kreg, vreg;
+  // staging registers: ONE 16-register tile image, used twice per iteration (round 4) - the next K tile is fetched at the top of the
+  // iteration and written to the other ring buffer after the first 32-key block, the next V tile is fetched there and written at the
+  // end.  Two images in flight (round 3) held 32 registers across the whole iteration; the 16 freed ones let the K / V row fragments of
+  // the S / dP products be requested DQ32_PF k-steps ahead of their MFMAs without spilling.
+  TileRegs<HD> kreg;
   tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
-  tile_fetch<HD>(vreg, vsrc, p.ld, sk.first() * 64);
   tile_commit_v<false>(smem, kreg, tid);
-  tile_commit_v<DQ32_VFLIP>(smem + TILE, vreg, tid);
+  tile_fetch<HD>(kreg, vsrc, p.ld, sk.first() * 64);
+  tile_commit_v<DQ32_VFLIP>(smem + TILE, kreg, tid);
   stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   int cur = 0;
   const int a4 = lane & 15, vgrp = (lane >> 4) & 1;
@@ -1142,73 +1166,88 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
     const char* const Ks = smem + cur * 2 * TILE;
     const char* const Vs = Ks + TILE;
     const uint8_t* const Ms = ms_base + cur * 80;
+    char* const nb = smem + (cur ^ 1) * 2 * TILE;
     __syncthreads();
-    if (nxt < n_kt) {
-      tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
-      tile_fetch<HD>(vreg, vsrc, p.ld, nxt * 64);
-    }
+    if (nxt < n_kt) tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
     const bool dead = !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first);
-    if (!dead) {
-      const bool clean = !Ms[64] && qhi == qlo + 31 && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
-      uint32_t vw[2] = {~0u, ~0u};
-      if (!clean) {
-        uint64_t vis = *(const uint64_t*)(Ms + 72);
-        if (qpos >= L) vis = 0;
-        if (p.causal) {
-          const int lim = qpos - k0;
-          vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
-        }
-        {
-          const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi - k0, 0), 64);
-          if (hx > lo) {
-            const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
-            vis &= ~(below_hx & ~below_lo);
-          }
-        }
-        vis >>= 4 * hi;
-        vw[0] = (uint32_t)vis; vw[1] = (uint32_t)(vis >> 32);
+    const bool clean = !Ms[64] && qhi == qlo + 31 && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
+    uint32_t vw[2] = {~0u, ~0u};
+    if (!dead && !clean) {
+      uint64_t vis = *(const uint64_t*)(Ms + 72);
+      if (qpos >= L) vis = 0;
+      if (p.causal) {
+        const int lim = qpos - k0;
+        vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
       }
+      {
+        const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi - k0, 0), 64);
+        if (hx > lo) {
+          const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+          vis &= ~(below_hx & ~below_lo);
+        }
+      }
+      vis >>= 4 * hi;
+      vw[0] = (uint32_t)vis; vw[1] = (uint32_t)(vis >> 32);
+    }
+    auto kb_block = [&](auto KB_) {
+      constexpr int kb = decltype(KB_)::value;
+      f32x16_t sc, dp;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16_t sc, dp;
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+      const int krow = kb * 32 + ql;
+      {
+        // K / V row fragments requested DQ32_PF k-steps ahead of their MFMAs (the compiler's own order was read, read, wait, MFMA, wait,
+        // MFMA per k-step: every pair of MFMAs behind the full LDS latency)
+        constexpr int PF = DQ32_PF;
+        bf16x8_t kfr[PF + 1], vfr[PF + 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-        const int krow = kb * 32 + ql;
+        for (int ks = 0; ks < PF; ++ks) {
+          kfr[ks] = *(const bf16x8_t*)(Ks + row_off(krow, ks * 2 + hi));
+          vfr[ks] = *(const bf16x8_t*)(Vs + row_off_v(krow, ks * 2 + hi));
+        }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8_t kf = *(const bf16x8_t*)(Ks + row_off(krow, ks * 2 + hi));
-          const bf16x8_t vf = *(const bf16x8_t*)(Vs + row_off_v(krow, ks * 2 + hi));
-          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float arg = __builtin_fmaf(sc[r], scale2, -lse2);
-          const bool ok = clean || (vw[kb] & (1u << (8 * (r >> 2) + (r & 3))));
-          const float pv = fast_exp2(ok ? arg : -INFINITY);
-          dp[r] = pv * (dp[r] - dlt) * p.scale;
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          union { bf16x8_t v; uint32_t u[4]; } df;
-          df.u[0] = pack_bf2(dp[8 * s2 + 0], dp[8 * s2 + 1]); df.u[1] = pack_bf2(dp[8 * s2 + 2], dp[8 * s2 + 3]);
-          df.u[2] = pack_bf2(dp[8 * s2 + 4], dp[8 * s2 + 5]); df.u[3] = pack_bf2(dp[8 * s2 + 6], dp[8 * s2 + 7]);
-          const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;
-            union { bf16x8_t v; s16x4_t hh[2]; } kf2;
-            kf2.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r0, c16) + sub));
-            kf2.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r1, c16) + sub));
-            dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf2.v, df.v, dq[db], 0, 0, 0);
+          if (ks + PF < 8) {
+            kfr[(ks + PF) % (PF + 1)] = *(const bf16x8_t*)(Ks + row_off(krow, (ks + PF) * 2 + hi));
+            vfr[(ks + PF) % (PF + 1)] = *(const bf16x8_t*)(Vs + row_off_v(krow, (ks + PF) * 2 + hi));
           }
+          if (PF > 0) __builtin_amdgcn_sched_barrier(0);
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks % (PF + 1)], qf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks % (PF + 1)], dof[ks], dp, 0, 0, 0);
+          if (PF > 0) __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
-    if (nxt < n_kt) {
-      char* const nb = smem + (cur ^ 1) * 2 * TILE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float arg = __builtin_fmaf(sc[r], scale2, -lse2);
+        const bool ok = clean || (vw[kb] & (1u << (8 * (r >> 2) + (r & 3))));
+        const float pv = fast_exp2(ok ? arg : -INFINITY);
+        dp[r] = pv * (dp[r] - dlt) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        union { bf16x8_t v; uint32_t u[4]; } df;
+        df.u[0] = pack_bf2(dp[8 * s2 + 0], dp[8 * s2 + 1]); df.u[1] = pack_bf2(dp[8 * s2 + 2], dp[8 * s2 + 3]);
+        df.u[2] = pack_bf2(dp[8 * s2 + 4], dp[8 * s2 + 5]); df.u[3] = pack_bf2(dp[8 * s2 + 6], dp[8 * s2 + 7]);
+        const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;
+          union { bf16x8_t v; s16x4_t hh[2]; } kf2;
+          kf2.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r0, c16) + sub));
+          kf2.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Ks + row_off(r1, c16) + sub));
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf2.v, df.v, dq[db], 0, 0, 0);
+        }
+      }
+    };
+    if (!dead) kb_block(std::integral_constant<int, 0>{});
+    if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
       tile_commit_v<false>(nb, kreg, tid);
-      tile_commit_v<DQ32_VFLIP>(nb + TILE, vreg, tid);
+      tile_fetch<HD>(kreg, vsrc, p.ld, nxt * 64);
+    }
+    if (!dead) kb_block(std::integral_constant<int, 1>{});
+    if (nxt < n_kt) {
+      tile_commit_v<DQ32_VFLIP>(nb + TILE, kreg, tid);
       stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
     }
     cur ^= 1;
