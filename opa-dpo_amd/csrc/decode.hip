@@ -1,6 +1,7 @@
 // On-policy rollout kernels: single-token attention over a KV cache and the on-device
 // temperature -> top-k -> top-p -> multinomial sampler (HF logits-processor order; the reference
 // calls policy.generate(do_sample=True, top_k=30, top_p=0.95): online_generator.py:292-309).
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 #include <algorithm>
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
                                                                bf16_t* o, const uint8_t* key_mask, int nh, int ctx_arg,
                                                                const int32_t* ctx_ptr, int max_ctx, float scale_log2e, float* ws_part,
                                                                const float* cosb = nullptr, const float* sinb = nullptr,
-                                                               bf16_t* kc_w = nullptr, bf16_t* vc_w = nullptr) {
+                                                               bf16_t* kc_w = nullptr, bf16_t* vc_w = nullptr, int kv_nt = 0) {
   constexpr int LPK = HD / 8;            // lanes per key
   constexpr int KPW = 64 / LPK;          // keys per wave step
   constexpr int NG = NW * KPW;           // lane groups (= keys per block step)
@@ -81,8 +82,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* q, i
       kk[u] = make_uint4(0, 0, 0, 0);
       vv[u] = make_uint4(0, 0, 0, 0);
       if (j < s1 && j != pos) {          // slots >= ctx are never read (uninitialised memory may hold NaN bit patterns)
-        kk[u] = *(const uint4*)(kb + (size_t)j * HD);
-        vv[u] = *(const uint4*)(vb + (size_t)j * HD);
+        // the KV cache is read exactly once per decode step: kv_nt streams it past the L2s (OPADPO_DEC_NT, A/B switch)
+        typedef __attribute__((ext_vector_type(4))) unsigned u4n_t;
+        if (kv_nt) {
+          const u4n_t a = __builtin_nontemporal_load((const u4n_t*)(kb + (size_t)j * HD)), c = __builtin_nontemporal_load((const u4n_t*)(vb + (size_t)j * HD));
+          kk[u] = make_uint4(a.x, a.y, a.z, a.w); vv[u] = make_uint4(c.x, c.y, c.z, c.w);
+        } else {
+          kk[u] = *(const uint4*)(kb + (size_t)j * HD);
+          vv[u] = *(const uint4*)(vb + (size_t)j * HD);
+        }
       }
     }
     float sc[U];
@@ -552,6 +560,7 @@ static int attn_decode_splits(int B, int nh, int max_ctx) {
   splits = std::min(splits, std::max(1, max_ctx / 256));
   return std::max(1, std::min(splits, 16));
 }
+static int dec_nt() { static const int v = getenv("OPADPO_DEC_NT") ? atoi(getenv("OPADPO_DEC_NT")) : 0; return v; }
 size_t attn_decode_workspace_bytes(int B, int nh, int hd, int max_ctx) {
   const int splits = attn_decode_splits(B, nh, max_ctx);
   return splits == 1 ? 0 : (size_t)B * nh * splits * (hd + 2) * 4;
@@ -568,7 +577,7 @@ hipError_t launch_attn_decode_fused(const bf16_t* qkv, int ld, const float* cosb
   const float sl2 = scale * 1.4426950408889634f;
   const bool fat = B * nh * splits < 1024;
   const dim3 gr(nh, B, splits);
-#define ADF(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, true>), gr, dim3(NW_ * 64), 0, st, qkv, ld, kc, vc, o, key_mask, nh, 0, pos_ptr, max_ctx, sl2, part, cosb, sinb, kc, vc)
+#define ADF(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, true>), gr, dim3(NW_ * 64), 0, st, qkv, ld, kc, vc, o, key_mask, nh, 0, pos_ptr, max_ctx, sl2, part, cosb, sinb, kc, vc, dec_nt())
   if (hd == 128) { if (fat) ADF(128, 16); else ADF(128, 4); }
   else           { if (fat) ADF(64, 16); else ADF(64, 4); }
 #undef ADF
@@ -587,7 +596,7 @@ hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* v
   const float sl2 = scale * 1.4426950408889634f;
   const bool fat = B * nh * splits < 1024;       // few blocks: 16 waves each
   const dim3 gr(nh, B, splits);
-#define AD(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), gr, dim3(NW_ * 64), 0, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, sl2, part)
+#define AD(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), gr, dim3(NW_ * 64), 0, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, sl2, part, nullptr, nullptr, nullptr, nullptr, dec_nt())
   if (hd == 128) { if (fat) AD(128, 16); else AD(128, 4); }
   else           { if (fat) AD(64, 16); else AD(64, 4); }
 #undef AD
