@@ -289,13 +289,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  if (p.stagger_mode && blockIdx.x < 256) {      // experiment: de-synchronise the rounds' store bursts (see GemmNTArgs::stagger_mode)
-    const unsigned b = blockIdx.x;
-    const unsigned slots = p.stagger_mode == 1 ? (b & 7u) * 8u : p.stagger_mode == 2 ? ((b >> 3) & 31u) * 8u : (b & 255u);
-    const unsigned long long wait = (unsigned long long)slots * (unsigned)p.stagger_cycles / 8ull;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int width = p.group_m * tiles_n;
@@ -1831,9 +1824,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // (fp32 out) +2.5 %, gate|up +0.6 %, down (fp32 out) +1.0 %, N = 768 +1.2 %.  OPADPO_W4_NT=0 keeps write-back stores (A/B).
   static const int env_nt = getenv("OPADPO_W4_NT") ? atoi(getenv("OPADPO_W4_NT")) : 1;
   a.store_nt = env_nt;
-  static int st_mode = -1, st_cyc = 0;
-  if (st_mode < 0) { st_mode = 0; if (const char* v = getenv("OPADPO_W4_STAGGER")) { if (sscanf(v, "%d,%d", &st_mode, &st_cyc) != 2) st_mode = 0; } }
-  a.stagger_mode = st_mode; a.stagger_cycles = st_cyc;
   // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
   // (N <= 4096: o / down and three of the four dgrads) - measured at M = 32362: down 1.363 -> 1.397 PF/s, o 1.394 -> 1.401,
   // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).

@@ -38,10 +38,6 @@ struct GemmNTArgs {
   // it has inside a 256x256 tile (results do not depend on which tiles fall into the tail, i.e. on the row count of the batch)
   int quarter = 0;
   int store_nt = 0;                     // direct epilogue of the 256x256 4-wave kernels: non-temporal C stores (set by launch_gemm_nt)
-  // start stagger of the FIRST round of workgroups of the 256x256 4-wave kernel (experiment, launch_gemm_nt / OPADPO_W4_STAGGER="mode,cycles"):
-  // mode 1: workgroup b waits (b % 8) * cycles (one slot per XCD); mode 2: ((b / 8) % 32) * cycles (per CU slot inside every XCD);
-  // mode 3: (b % 256) * cycles / 8.  All rounds after the first inherit the skew (a CU takes its next tile when it finishes the last)
-  int stagger_mode = 0, stagger_cycles = 0;
 };
 
 struct GemmTNArgs {
