@@ -801,421 +801,6 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// gemm_nt "w4p" kernel (round 4): gemm_nt_w4_kernel as a PERSISTENT tile loop WITH THE EPILOGUE OF A TILE PIPELINED INTO THE NEXT TILE, for the
-// direct-epilogue problems (plain products, alpha = 1, bf16 or fp32 out, no residual, no fused SwiGLU / rotary epilogue).
-// One workgroup per CU walks the tiles b, b + G, b + 2G, ... of the SAME grouped, XCD-aware order the one-tile-per-block kernel uses
-// (virtual block id v = b + i*G lands on the XCD of b: G % 8 == 0); the K-tiles of consecutive output tiles form ONE stream through the
-// two LDS stages (the long-lead DMA runs on into the next output tile; past the block's last tile it runs on a dummy tile so that every
-// K-tile of the stream executes the same steady-state body).  The first k-half of a tile's first K-tile runs its 64 MFMAs with the literal 0
-// as C operand - and that is where the PREVIOUS tile's results leave: row block by row block, the four accumulator reads of acc[idx] sit
-// right in front of the C = 0 MFMA that overwrites acc[idx], and the conversions + 16-byte stores of a row block are spread over the MFMAs
-// of the next row block (8 slots: 4 x {convert a row, store a row}).  The matrix pipe keeps running through what was a 4-us epilogue with
-// nothing to multiply (the no-epilogue diagnostic of the first persistent version: +3.5 ... +4.2 % at K ~ 4096); the first k-half becomes
-// VALU-issue bound instead (~6.5 single-issue instructions per 16-cycle MFMA).  The block's LAST tile stores the plain way.
-// vmcnt bookkeeping: the pipelined stores count in vmcnt next to the DMA pieces.  The first body's "next K-tile has landed" wait only needs
-// the 3 pieces issued BEFORE any of those stores: vmcnt(13 pieces + 32 stores) = 45 for bf16 results, capped at 63 for fp32 results
-// (64 stores: the oldest 11 must retire with the 3 pieces).  The second body's vmcnt(13) retires every store (issued >= 150 MFMAs earlier).
-// Every tile is still computed by ONE workgroup over the full K range in the same k order -> bit-identical to gemm_nt_w4_kernel
-// (tests/test_ops_gpu.py::test_gemm_nt_persistent_is_bit_identical).  Accumulators are pinned to a[0:255] by PHYSICAL register constraints
-// ("+{a[4n:4n+3]}"): with plain "+a" operands the allocator rotated them across the tile loop's back edge (761 v_accvgpr_write + 251 v_accvgpr_mov +
-// 620 bytes of scratch per lane in the first version).
-// ------------------------------------------------------------------------------------------
-template <int N> __device__ __forceinline__ void w4p_mfma(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b);       // c += a . b^T, c pinned
-template <int N> __device__ __forceinline__ void w4p_mfma0(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b);      // c  = a . b^T
-template <int N> __device__ __forceinline__ void w4p_rd(const f32x4_t& c, float (&v)[4]);                          // accumulator -> 4 VGPRs
-#define W4P_ACC(N, R0, R1, R2, R3)                                                                                                       \
-  template <> __device__ __forceinline__ void w4p_mfma<N>(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {                             \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+{a[" #R0 ":" #R3 "]}"(c) : "v"(a), "v"(b));                                \
-  }                                                                                                                                      \
-  template <> __device__ __forceinline__ void w4p_mfma0<N>(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {                            \
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "={a[" #R0 ":" #R3 "]}"(c) : "v"(a), "v"(b));                                 \
-  }                                                                                                                                      \
-  template <> __device__ __forceinline__ void w4p_rd<N>(const f32x4_t& c, float (&v)[4]) {                                                \
-    asm volatile("v_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2                     \
-                 "\n\tv_accvgpr_read_b32 %3, a" #R3 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "{a[" #R0 ":" #R3 "]}"(c));        \
-  }
-W4P_ACC(0, 0, 1, 2, 3)
-W4P_ACC(1, 4, 5, 6, 7)
-W4P_ACC(2, 8, 9, 10, 11)
-W4P_ACC(3, 12, 13, 14, 15)
-W4P_ACC(4, 16, 17, 18, 19)
-W4P_ACC(5, 20, 21, 22, 23)
-W4P_ACC(6, 24, 25, 26, 27)
-W4P_ACC(7, 28, 29, 30, 31)
-W4P_ACC(8, 32, 33, 34, 35)
-W4P_ACC(9, 36, 37, 38, 39)
-W4P_ACC(10, 40, 41, 42, 43)
-W4P_ACC(11, 44, 45, 46, 47)
-W4P_ACC(12, 48, 49, 50, 51)
-W4P_ACC(13, 52, 53, 54, 55)
-W4P_ACC(14, 56, 57, 58, 59)
-W4P_ACC(15, 60, 61, 62, 63)
-W4P_ACC(16, 64, 65, 66, 67)
-W4P_ACC(17, 68, 69, 70, 71)
-W4P_ACC(18, 72, 73, 74, 75)
-W4P_ACC(19, 76, 77, 78, 79)
-W4P_ACC(20, 80, 81, 82, 83)
-W4P_ACC(21, 84, 85, 86, 87)
-W4P_ACC(22, 88, 89, 90, 91)
-W4P_ACC(23, 92, 93, 94, 95)
-W4P_ACC(24, 96, 97, 98, 99)
-W4P_ACC(25, 100, 101, 102, 103)
-W4P_ACC(26, 104, 105, 106, 107)
-W4P_ACC(27, 108, 109, 110, 111)
-W4P_ACC(28, 112, 113, 114, 115)
-W4P_ACC(29, 116, 117, 118, 119)
-W4P_ACC(30, 120, 121, 122, 123)
-W4P_ACC(31, 124, 125, 126, 127)
-W4P_ACC(32, 128, 129, 130, 131)
-W4P_ACC(33, 132, 133, 134, 135)
-W4P_ACC(34, 136, 137, 138, 139)
-W4P_ACC(35, 140, 141, 142, 143)
-W4P_ACC(36, 144, 145, 146, 147)
-W4P_ACC(37, 148, 149, 150, 151)
-W4P_ACC(38, 152, 153, 154, 155)
-W4P_ACC(39, 156, 157, 158, 159)
-W4P_ACC(40, 160, 161, 162, 163)
-W4P_ACC(41, 164, 165, 166, 167)
-W4P_ACC(42, 168, 169, 170, 171)
-W4P_ACC(43, 172, 173, 174, 175)
-W4P_ACC(44, 176, 177, 178, 179)
-W4P_ACC(45, 180, 181, 182, 183)
-W4P_ACC(46, 184, 185, 186, 187)
-W4P_ACC(47, 188, 189, 190, 191)
-W4P_ACC(48, 192, 193, 194, 195)
-W4P_ACC(49, 196, 197, 198, 199)
-W4P_ACC(50, 200, 201, 202, 203)
-W4P_ACC(51, 204, 205, 206, 207)
-W4P_ACC(52, 208, 209, 210, 211)
-W4P_ACC(53, 212, 213, 214, 215)
-W4P_ACC(54, 216, 217, 218, 219)
-W4P_ACC(55, 220, 221, 222, 223)
-W4P_ACC(56, 224, 225, 226, 227)
-W4P_ACC(57, 228, 229, 230, 231)
-W4P_ACC(58, 232, 233, 234, 235)
-W4P_ACC(59, 236, 237, 238, 239)
-W4P_ACC(60, 240, 241, 242, 243)
-W4P_ACC(61, 244, 245, 246, 247)
-W4P_ACC(62, 248, 249, 250, 251)
-W4P_ACC(63, 252, 253, 254, 255)
-#undef W4P_ACC
-// compile-time loop: f(integral_constant<int, I0>) ... f(integral_constant<int, I0 + N - 1>)
-template <int I0, int N, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (N > 0) {
-    f(std::integral_constant<int, I0>{});
-    sfor<I0 + 1, N - 1>(f);
-  }
-}
-
-template <bool ORDER_B, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_nt_w4p_kernel(GemmNTArgs p, int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int width = p.group_m * tiles_n;
-  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-  const int my_tiles = (n_tiles - bid + G - 1) / G;          // tiles bid, bid + G, ... < n_tiles (the launcher guarantees >= 1)
-  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;   // nt >= 3 (launcher)
-  const int srow = lane >> 3, spos = lane & 7;
-  auto uni = [](const void* q) -> void* {
-    const unsigned long long v = (unsigned long long)q;
-    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-  };
-  auto tile_of = [&](int v, int& m0, int& n0) {
-    const int swz = xcd_remap(v, n_tiles);
-    const int group_id = swz / width;
-    const int first_m = group_id * p.group_m;
-    const int gsz = min(tiles_m - first_m, p.group_m);
-    const int tm = first_m + (swz % width) % gsz;
-    const int tn = (swz % width) / gsz;
-    m0 = __builtin_amdgcn_readfirstlane(tm * P_BM);
-    n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
-  };
-  const unsigned lrow = (unsigned)(wave * 64 + srow);
-  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
-  const unsigned lrowB_lo = (unsigned)((srow & 1) * 8 + (srow & 6));
-  const unsigned m_last = (unsigned)(p.M - 1);
-  // ---- DMA side: the tile whose K-tiles are being fetched (runs two K-tiles ahead of the compute side, across tile boundaries)
-  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-  auto mk_rsrc = [&](const void* base) {
-    const unsigned long long v = (unsigned long long)base;
-    i32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)v); r[1] = __builtin_amdgcn_readfirstlane((int)((v >> 32) & 0xffffu));
-    r[2] = -1; r[3] = 0x00020000;
-    return r;
-  };
-  int d_m0, d_n0, d_t = 0, d_it = 0;           // tile origin, K-tile index inside it, tile ordinal of this block
-  bool d_second = false;
-  i32x4_t qA1, qA2;
-  const i32x4_t qB1 = mk_rsrc(p.B1), qB2 = mk_rsrc(nt2 ? p.B2 : p.B1);
-  unsigned voff[16];
-  auto set_voff = [&](bool second) {
-    const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
-#pragma unroll
-    for (int pi = 0; pi < 8; ++pi) {
-      voff[pi] = min((unsigned)d_m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
-      voff[8 + pi] = ((unsigned)d_n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb +
-                     (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
-    }
-  };
-  auto d_open_tile = [&](int v) {              // start fetching tile v
-    tile_of(v, d_m0, d_n0);
-    const bf16_t* a1 = p.A1;
-    if (p.a1_group_n > 0) a1 += (size_t)(d_n0 / p.a1_group_n) * p.a1_group_stride;
-    const bf16_t* a2 = p.A2;
-    if (p.a2_group_n > 0) a2 += (size_t)(d_n0 / p.a2_group_n) * p.a2_group_stride;
-    qA1 = mk_rsrc(a1);
-    qA2 = mk_rsrc(nt2 ? a2 : a1);
-    d_t = 0; d_second = false;
-    set_voff(false);
-  };
-  // called before the 16 pieces of K-tile d_t are issued: tile / operand switches of the stream
-  // Past the block's last tile the stream keeps running on a DUMMY tile (the last tile again: two K-tiles nobody reads): every K-tile of
-  // the stream then runs the SAME steady-state body - no drain variants of the 128-MFMA body (in a first version their two copies merged
-  // into one 256-MFMA basic block in which the register allocator spilled the pinned accumulators), 64 KiB of extra L2 reads per block.
-  auto d_advance = [&]() {
-    if (d_t == nt) {
-      ++d_it;
-      const int v = bid + d_it * G;
-      d_open_tile(v < n_tiles ? v : v - G);
-    }
-    else if (d_t == nt1) { d_second = true; set_voff(true); }
-  };
-  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
-  auto dma_m0 = [&](int par, int q) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + par * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-    asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory");
-  };
-  auto dma_go = [&](int q) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((d_second ? (d_t - nt1) : d_t) * P_BK * 2);
-    const i32x4_t r = q < 8 ? (d_second ? qA2 : qA1) : (d_second ? qB2 : qB1);
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff) : "memory");
-  };
-
-  f32x4_t acc[64];                             // acc[i*8 + j], pinned to a[4(i*8+j) : +3] by the w4p_* helpers; first written by w4p_mfma0
-  bf16x8_t fa[2][8], fb[2][8];
-  const int frow = lane & 15, fchk = lane >> 4;
-  const int fsw = (frow >> 1) & 7;
-  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128;
-  auto read_frag = [&](int par, int kk, int r) {
-    const char* st = smem + par * P_STAGE;
-    const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
-    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + ((r & 1) * 8 + (r & 6)) * 128 + cb);
-    else fa[kk][r - 8] = *(const bf16x8_t*)(st + offA + (r - 8) * 2048 + cb);
-  };
-#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // MFMAs IDX0 .. IDX0+N-1 of k-half KK (idx = i*8 + j); ZERO: C operand = 0 (the tile's first k-half)
-  auto mfma_run = [&](auto KK_, auto IDX0_, auto N_, auto ZERO_) {
-    constexpr int kk = decltype(KK_)::value, idx0 = decltype(IDX0_)::value, n = decltype(N_)::value;
-    constexpr bool zero = decltype(ZERO_)::value;
-    sfor<idx0, n>([&](auto I_) {
-      constexpr int idx = decltype(I_)::value;
-      if constexpr (zero && kk == 0) w4p_mfma0<idx>(acc[idx], fa[kk][idx >> 3], fb[kk][idx & 7]);
-      else w4p_mfma<idx>(acc[idx], fa[kk][idx >> 3], fb[kk][idx & 7]);
-    });
-  };
-#define IC(x) std::integral_constant<int, (x)>{}
-  // one K-tile of the stream; par = its LDS stage.  Same schedule as gemm_nt_w4_kernel::tile_body_ll (see there for the knobs)
-  // ---- pipelined epilogue of the PREVIOUS tile (EPI bodies): two 32-register read-out buffers (row blocks alternate), the packed row in
-  // flight, and the byte offset of this lane's first element of the previous tile
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(uni(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * (OUT_F32 ? 4u : 2u)), 0x00020000);
-  const unsigned rstep = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)p.ldc * (OUT_F32 ? 4u : 2u)));
-  float raw[2][8][4];
-  u32x4s_t pk = {0u, 0u, 0u, 0u};
-  unsigned e_vo = 0;
-  auto epi_pre = [&](auto IDX_) {                // the four reads of acc[idx], in front of the C = 0 MFMA that overwrites it
-    constexpr int idx = decltype(IDX_)::value;
-    w4p_rd<idx>(acc[idx], raw[(idx >> 3) & 1][idx & 7]);
-  };
-  auto epi_post = [&](auto SLOT_) {              // slot 0..63: row block slot >> 3, step slot & 7 = {convert, store} x 4 rows (fp32: {store lo, store hi})
-    constexpr int slot = decltype(SLOT_)::value, rb = slot >> 3, j = slot & 7, r = j >> 1;
-    float (&v)[8][4] = raw[rb & 1];
-    const unsigned vr = e_vo + (unsigned)(rb * 16 + r) * rstep;
-    if constexpr (OUT_F32) {
-      u32x4s_t o;
-      constexpr int c0 = (j & 1) * 4;
-      o[0] = __float_as_uint(v[c0][r]); o[1] = __float_as_uint(v[c0 + 1][r]); o[2] = __float_as_uint(v[c0 + 2][r]); o[3] = __float_as_uint(v[c0 + 3][r]);
-      __builtin_amdgcn_raw_buffer_store_b128(o, rC, vr + (unsigned)(j & 1) * 16u, 0, 2);
-    } else if constexpr ((j & 1) == 0) {
-      pk[0] = pack_bf2(v[0][r], v[1][r]); pk[1] = pack_bf2(v[2][r], v[3][r]); pk[2] = pack_bf2(v[4][r], v[5][r]); pk[3] = pack_bf2(v[6][r], v[7][r]);
-    } else {
-      __builtin_amdgcn_raw_buffer_store_b128(pk, rC, vr, 0, 2);
-    }
-  };
-  // one MFMA of the tile's first k-half in an EPI body: read-out of its accumulator, the MFMA, one step of the previous row block's stores
-  auto mfma_epi = [&](auto GI_) {                // gi = 0..71: MFMA index inside the K-tile (64..71: k-half 1, only the tail of the stores)
-    constexpr int gi = decltype(GI_)::value;
-    if constexpr (gi < 64) {
-      epi_pre(IC(gi));
-      w4p_mfma0<gi>(acc[gi], fa[0][gi >> 3], fb[0][gi & 7]);
-    } else {
-      w4p_mfma<gi - 64>(acc[gi - 64], fa[1][(gi - 64) >> 3], fb[1][(gi - 64) & 7]);
-    }
-    if constexpr (gi >= 8) epi_post(IC(gi - 8));
-  };
-  // one K-tile of the stream; par = its LDS stage.  Same schedule as gemm_nt_w4_kernel::tile_body_ll (see there for the knobs).
-  // FIRST: the tile's first K-tile (C = 0 in k-half 0); EPI: ... that also carries the previous tile's epilogue
-  auto tile_body = [&](int par, auto HAS_NEXT, auto HAS_NEXT2, auto FIRST, auto EPI) {
-    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    constexpr bool dma = has_next2, epi = decltype(EPI)::value;
-    constexpr int R1 = 32, B1 = 40, DSTEP = 4;
-    // MFMAs gi0 .. gi0+n-1 of the K-tile (gi = kk*64 + idx), with the pipelined epilogue steps in an EPI body
-    auto run = [&](auto GI0_, auto N_) {
-      constexpr int gi0 = decltype(GI0_)::value, n = decltype(N_)::value;
-      if constexpr (epi && gi0 < 72) {
-        sfor<gi0, n>([&](auto I_) {
-          constexpr int gi = decltype(I_)::value;
-          if constexpr (gi < 72) mfma_epi(IC(gi));
-          else w4p_mfma<gi - 64>(acc[gi - 64], fa[1][(gi - 64) >> 3], fb[1][(gi - 64) & 7]);
-        });
-      } else {
-        mfma_run(IC(gi0 >> 6), IC(gi0 & 63), IC(n), FIRST);
-      }
-    };
-    sfor<0, 16>([&](auto G_) {
-      constexpr int g = decltype(G_)::value;
-      run(IC((g * R1) / 16), IC(((g + 1) * R1) / 16 - (g * R1) / 16));
-      W4_PIN();
-      read_frag(par, 1, g);
-      W4_PIN();
-    });
-    run(IC(R1), IC(B1 - R1 - 1));
-    W4_PIN();
-    if constexpr (has_next2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_PIN(); run(IC(B1 - 1), IC(1)); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // every read of this stage is done: it takes the K-tile two ahead
-      W4_PIN();
-      d_advance();
-      W4_PIN();
-    } else {
-      run(IC(B1 - 1), IC(1));
-      W4_PIN();
-    }
-    sfor<0, 100 - B1 - 1>([&](auto M_) {
-      constexpr int m = decltype(M_)::value, gi = B1 + m;
-      constexpr auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };
-      run(IC(gi), IC(1));
-      if constexpr (dma && (m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(par, piece_of((m + 2) / DSTEP - 1)); W4_PIN(); }
-      if constexpr ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
-        W4_PIN();
-        if constexpr (dma) dma_go(piece_of((m + 1) / DSTEP - 1));
-        W4_PIN();
-      }
-    });
-    W4_PIN();
-    if constexpr (has_next) {
-      if constexpr (epi) {
-        // behind the previous tile's pipelined stores: only the 3 pieces issued BEFORE them must have landed (in-order retirement)
-        if constexpr (OUT_F32) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
-      } else {
-        if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      W4_PIN(); mfma_run(IC(1), IC(35), IC(1), FIRST); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // the next K-tile of the stream has landed for everyone
-    } else {
-      mfma_run(IC(1), IC(35), IC(1), FIRST);
-    }
-    W4_PIN();
-    sfor<0, 8>([&](auto G_) {
-      constexpr int g = decltype(G_)::value;
-      constexpr auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };
-      mfma_run(IC(1), IC(36 + g * 3), IC(2), FIRST);
-      W4_PIN();
-      if constexpr (has_next) read_frag(par ^ 1, 0, 2 * g);
-      if constexpr (dma && (g == 1 || g == 4 || g == 7)) dma_m0(par, piece_of(13 + (g - 1) / 3));
-      W4_PIN();
-      mfma_run(IC(1), IC(36 + g * 3 + 2), IC(1), FIRST);
-      W4_PIN();
-      if constexpr (has_next) read_frag(par ^ 1, 0, 2 * g + 1);
-      if constexpr (dma && (g == 1 || g == 4 || g == 7)) dma_go(piece_of(13 + (g - 1) / 3));
-      W4_PIN();
-    });
-    mfma_run(IC(1), IC(60), IC(4), FIRST);
-    W4_PIN();
-    if constexpr (dma) ++d_t;
-  };
-  using T_ = std::true_type; using F_ = std::false_type;
-
-  // ---- epilogue: 16-byte stores straight from the accumulators (gemm_nt_w4_kernel's direct form), rows >= M dropped by the descriptor
-  auto lane_off = [&](int m0, int n0) {
-    return ((unsigned)(m0 + wr * 128 + 4 * fchk) * (unsigned)p.ldc + (unsigned)(n0 + wc * 128 + 8 * frow)) * (OUT_F32 ? 4u : 2u);
-  };
-  auto store_tile = [&](int m0, int n0) {
-    const unsigned esz = OUT_F32 ? 4u : 2u;
-    unsigned vo = ((unsigned)(m0 + wr * 128 + 4 * fchk) * (unsigned)p.ldc + (unsigned)(n0 + wc * 128 + 8 * frow)) * esz;
-    const unsigned rstep = (unsigned)p.ldc * esz;
-    sfor<0, 8>([&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      float v[8][4];
-      sfor<0, 8>([&](auto J_) { constexpr int j = decltype(J_)::value; w4p_rd<i * 8 + j>(acc[i * 8 + j], v[j]); });
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned vr = vo + (unsigned)(i * 16 + r) * rstep;
-        if constexpr (OUT_F32) {
-          u32x4s_t lo, hi;
-          lo[0] = __float_as_uint(v[0][r]); lo[1] = __float_as_uint(v[1][r]); lo[2] = __float_as_uint(v[2][r]); lo[3] = __float_as_uint(v[3][r]);
-          hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vr, 0, 2);
-          __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vr + 16u, 0, 2);
-        } else {
-          u32x4s_t o;
-          o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(o, rC, vr, 0, 2);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);        // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
-    });
-  };
-
-  // ---- prologue of the block's stream: K-tiles 0 and 1 of its first tile
-  d_open_tile(bid);
-  int c_m0 = d_m0, c_n0 = d_n0;                // compute side: the tile being accumulated
-  auto dma_piece = [&](int par, int q) {        // prologue form: M0 and the load in one asm block (one wait state between them)
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + par * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((d_second ? (d_t - nt1) : d_t) * P_BK * 2);
-    const i32x4_t r = q < 8 ? (d_second ? qA2 : qA1) : (d_second ? qB2 : qB1);
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff), "s"(dst) : "memory");
-  };
-#pragma unroll
-  for (int q = 0; q < 16; ++q) dma_piece(0, q);
-  ++d_t;
-  d_advance();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) dma_piece(1, q);
-  ++d_t;
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  W4_PIN();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
-  W4_PIN();
-  int par = 0;
-  tile_body(par, T_{}, T_{}, T_{}, F_{}); par ^= 1;          // the block's first tile: C = 0 in the first k-half, nothing to store yet
-  for (int t = 1; t < nt; ++t) { tile_body(par, T_{}, T_{}, F_{}, F_{}); par ^= 1; }
-  for (int it = 1; it < my_tiles; ++it) {
-    // the DMA side opened tile `it` two K-tiles ago and cannot leave it before that tile's K-tile nt-3: its origin is the next compute tile
-    e_vo = lane_off(c_m0, c_n0);
-    c_m0 = d_m0; c_n0 = d_n0;
-    tile_body(par, T_{}, T_{}, T_{}, T_{}); par ^= 1;        // first K-tile of tile `it` + the stores of tile `it - 1`
-    for (int t = 1; t < nt; ++t) { tile_body(par, T_{}, T_{}, F_{}, F_{}); par ^= 1; }
-  }
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> accumulator reads
-  W4_PIN();
-  store_tile(c_m0, c_n0);                                    // the block's last tile: nothing left to hide it behind
-  W4_PIN();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy K-tiles' DMA writes into this block's LDS must not outlive it
-#undef IC
-#undef W4_PIN
-}
-
-// ------------------------------------------------------------------------------------------
 // gemm_nt "p8" kernel: the 256x256 / BK 64 / 8-wave (2x4, 128x64 per wave) geometry of the ping-pong kernel with FOUR
 // phases per K-tile instead of one.  A phase = read block (the ds_read_b128 of one 64x32 quadrant of the wave's C block,
 // TWO LDS-DMA pieces, a counted s_waitcnt vmcnt) | barrier | 16 MFMAs under s_setprio 1 | barrier.  The wave groups
@@ -2221,24 +1806,11 @@ bool opadpo_flag_tr() { return g_use_tr; }
 
 // piece order of the 4-wave 256x256 kernel by shape (see gemm_nt_w4_kernel): B half first for N <= 16 column tiles
 static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B first (experiments)
-// persistent form with the pipelined epilogue (gemm_nt_w4p_kernel) for direct-epilogue problems of more than one round of tiles: 256
-// workgroups walk the tile list.  OPADPO_W4P=0/1 switches it, variant 32 forces it where eligible (otherwise = auto); variant 31 (the tests'
-// bit-for-bit cross-check: one 256x256 tile per workgroup on every tile) never takes it.
-static int g_w4p = -1;
-#define W4P_GO(OB_, F32_) hipLaunchKernelGGL((gemm_nt_w4p_kernel<OB_, F32_>), dim3(256), dim3(256), 2 * P_STAGE, st, a, (int)tiles_)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
-    const int tiles_ = (int)(GRID_);                                                                                         \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
-    const bool pers_ = (g_w4p != 0 || g_gemm_variant == 32) && g_gemm_variant != 31 && tiles_ > 256 && !a.R && !a.act && !a.rope_cos && !a.rope_pos &&  \
-                       !a.bias && a.alpha == 1.0f && (a.K1 + a.K2) / P_BK >= 3 &&                                             \
-                       ((unsigned long long)a.M + 256ull) * (unsigned)a.ldc * (a.out_f32 ? 4u : 2u) < 0xffffffffull;          \
-    if (pers_) {                                                                                                             \
-      if (ob_) { if (a.out_f32) W4P_GO(true, true); else W4P_GO(true, false); }                                              \
-      else     { if (a.out_f32) W4P_GO(false, true); else W4P_GO(false, false); }                                            \
-    }                                                                                                                        \
-    else if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(tiles_), dim3(256), 2 * P_STAGE, st, a);                   \
-    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(tiles_), dim3(256), 2 * P_STAGE, st, a);                           \
+    if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                         \
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                            \
   } while (0)
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
@@ -2250,7 +1822,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // persistent-loop experiment put it at 4-5 us of a ~100 us tile) while nothing computes; streaming stores do not fight the operand
   // panels for the 4-MiB L2s.  Same-box sustained A/B at M = 24576 (tools/ab_env.sh, profiles/r04_ab_nt_stores.txt): q|k|v +0.9 %, o
   // (fp32 out) +2.5 %, gate|up +0.6 %, down (fp32 out) +1.0 %, N = 768 +1.2 %.  OPADPO_W4_NT=0 keeps write-back stores (A/B).
-  if (g_w4p == -1) { const char* v = getenv("OPADPO_W4P"); g_w4p = v ? atoi(v) : 0; }
   static const int env_nt = getenv("OPADPO_W4_NT") ? atoi(getenv("OPADPO_W4_NT")) : 1;
   a.store_nt = env_nt;
   // grouped tile order of the 256x256 4-wave kernel: 8 row tiles per group; 4 when the problem is at most 16 column tiles wide
@@ -2267,10 +1838,6 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_w4p_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }

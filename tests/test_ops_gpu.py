@@ -1001,60 +1001,6 @@ def test_gemm_nt_split_k_tail(L, R, K, r, mode):
     assert torch.equal(got[:M], small), "256x256 dispatch != 128x128 kernel"
 
 
-@pytest.mark.parametrize("N,R,K,r,grp,f32", [
-    (4096, 40, 512, 0, 0, False),      # 640 tiles: blocks walk 2 or 3 tiles each, B-first piece order, nt = 8
-    (4096, 40, 192, 0, 0, True),       # nt = 3 (odd: the LDS stage parity of a tile's first K-tile alternates), fp32 out
-    (8192, 20, 256, 64, 0, False),     # A-first piece order (N > 4096), K-concatenated tail, nt = 5
-    (4096, 33, 320, 128, 2048, True),  # 512 persistent tiles + a 16-tile quarter tail; tail operand grouped by output column
-    (8192, 11, 128, 64, 4096, False),  # 352 tiles (one block in three walks two), nt = 3 with the operand switch inside
-])
-def test_gemm_nt_persistent_is_bit_identical(L, N, R, K, r, grp, f32):
-    """Round 4: the PERSISTENT kernel with the pipelined epilogue (gemm_nt_w4p_kernel, variant 32 / OPADPO_W4P=1: 256 workgroups walk the tile
-    list, the K-tile stream of one tile runs on into the next, a tile's results leave inside the first k-half of the next tile).  Every tile is
-    still computed by one workgroup over the full K range in the same k order -> bit-identical to the one-tile-per-workgroup kernel on every tile
-    (variant 31) and to the 128x128 kernel (variant 4); rows >= M untouched; repeated launches identical (the cross-tile DMA / store / vmcnt
-    bookkeeping is race-free)."""
-    L.set_flags(32, True)
-    M = R * 256 - 77
-    x, w = rnd(M, K, seed=11), rnd(N, K, scale=0.05, seed=12)
-    kw = {}
-    if r:
-        G = N // grp if grp else 1
-        kw = dict(a2=rnd(M, G * r, seed=13), b2=rnd(N, r, scale=0.05, seed=14))
-        if grp:
-            kw.update(a2_group_n=grp, a2_group_stride=r)
-    want = x.float() @ w.float().t()
-    if r:
-        a2f, b2f = kw["a2"].float(), kw["b2"].float()
-        if grp:
-            for gi in range(N // grp):
-                want[:, gi * grp:(gi + 1) * grp] += a2f[:, gi * r:(gi + 1) * r] @ b2f[gi * grp:(gi + 1) * grp].t()
-        else:
-            want += a2f @ b2f.t()
-    dt = torch.float32 if f32 else BF
-    got = torch.full((M + 3, N), 7.0, dtype=dt, device=dev())
-    L.gemm_nt(x, w, got[:M], **kw)
-    runs = []
-    for _ in range(3):
-        o = torch.empty(M, N, dtype=dt, device=dev())
-        L.gemm_nt(x, w, o, **kw)
-        runs.append(o)
-    L.set_flags(31, True)
-    whole = torch.empty(M, N, dtype=dt, device=dev())
-    L.gemm_nt(x, w, whole, **kw)
-    L.set_flags(4, True)
-    small = torch.empty(M, N, dtype=dt, device=dev())
-    L.gemm_nt(x, w, small, **kw)
-    L.set_flags(10, True)
-    torch.cuda.synchronize()
-    assert relerr(got[:M], want) < (3e-3 if not f32 else 2e-5 * ((K + r) ** 0.5))
-    assert float((got[M:].float() - 7.0).abs().max()) == 0.0
-    for o in runs:
-        assert torch.equal(got[:M], o)
-    assert torch.equal(got[:M], whole), "persistent tile loop != one 256x256 tile per workgroup"
-    assert torch.equal(got[:M], small), "persistent tile loop != 128x128 kernel"
-
-
 @pytest.mark.parametrize("M,F,K,r", [(300, 256, 128, 64), (1000, 768, 256, 0), (257, 1536, 512, 256), (3, 256, 64, 64)])
 def test_gemm_nt_swiglu_bwd(L, M, F, K, r):
     """ACT_SWIGLU_BWD: dgrad of the down projection (+ K-concatenated LoRA tail) with opadpo_silu_mul_bwd in its epilogue ==

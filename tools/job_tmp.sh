@@ -1,4 +1,2 @@
-cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -8
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 900 python bench.py > gpurun_out/r04b_bench_default.json 2> gpurun_out/r04b_bench_default.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/r04b_bench_default.json; tail -3 gpurun_out/r04b_bench_default.err
+python -m pytest tests/test_ops_gpu.py -x -q -k "persistent or split_k_tail" 2>&1 | tail -4
+W4P_CONFIGS="0:0 1:0" GB_ITERS=150 bash tools/ab_w4p.sh 2>&1 | tee gpurun_out/r04_ab_w4p_v2.txt
