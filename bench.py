@@ -66,6 +66,20 @@ def _parity_record():
     return None
 
 
+def _cpu_full_record():
+    """The oracle timed DIRECTLY at full depth on the GPU box's host cores (tools/cpu_baseline_full.py: one whole pair, 32 layers, nothing
+    extrapolated; minutes of CPU work, so it is a committed record - newest profiles/r*_cpu_baseline_full.json - not part of this run)."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_cpu_baseline_full.json")))):
+        try:
+            r = json.load(open(f))
+            return {"value": r["value"], "unit": r["unit"], "seconds_per_pair": r["seconds_per_pair"], "cores": r["cores"], "extrapolated": False,
+                    "sample": r["sample"], "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline_config_p(dims_kw, n_layers=1):
     """SURVEY.md §8(d) config (1) timed DIRECTLY on the host cores: 8 pairs, query 32 + response 96 (L = 703), fp32, world 1, the whole
     path of a pair - CLIP tower + projector once per image, frozen-reference forward (no grad) and policy forward on chosen + rejected,
@@ -807,6 +821,9 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(dict(hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim,
                                                         ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
+                full = _cpu_full_record()
+                if full is not None:
+                    out["cpu_baseline"]["full_depth_measured"] = full
                 try:
                     out["cpu_baseline"]["config_p_direct"] = cpu_baseline_config_p(dict(
                         hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim, ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r,
