@@ -243,6 +243,105 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel_x(GemmNTArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_nt tail kernel (round 4): SIXTEENTH tiles.  A partly filled last round of the 256x256 kernel (<= 64 tiles) used to run as quarter tiles
+// on the 128x128 kernel - 4 blocks per tile, i.e. 64-256 blocks for a chip of 256 CUs: a 16-tile tail (6 % of a round's work) cost half a round.
+// Here block b computes the 64x64 piece (b & 15) of tile tile0 + (b >> 4) of the 4-wave kernel's grouped order over the FULL K range, in the
+// same k order (K-tiles in order, two 32-deep MFMA steps per K-tile): every element of C is bit-identical to what the 256x256 kernel and the
+// quarter tiles write (tests/test_ops_gpu.py::test_gemm_nt_split_k_tail), so which tiles are tail tiles still cannot change a bit of the output.
+// 16 blocks per tile fill the chip from a 16-tile tail on; 4 waves x (16 rows x 64 columns), a ring of NS 16-KiB LDS stages filled by
+// global_load_lds with NS - 1 K-tiles in flight (counted vmcnt + raw barrier: a 16-tile tail is one block per CU, nothing else hides the latency), the
+// 128x128 kernel's LDS image / B-row permutation (a lane owns 4 consecutive output columns).  Arithmetic intensity is low by construction
+// (64 FLOP per operand byte from L2): the point is latency, not rate.
+// ------------------------------------------------------------------------------------------
+template <int NS>                                   // ring depth: NS - 1 K-tiles in flight per block.  8 (128 KiB: one block per CU) for tails that give every CU at most
+                                                    // one block - nothing else hides the L2 / HBM latency there -, 4 (64 KiB, two blocks per CU) for longer tails
+__global__ __launch_bounds__(256) void gemm_nt_tail64_kernel(GemmNTArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = 128, TB = 64 * ROWB, SB = 2 * TB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int m0, n0;
+  {
+    const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
+    const int swz = p.tile0 + (blockIdx.x >> 4), q = blockIdx.x & 15;
+    const int width = p.group_m * tiles_n;
+    const int first_m = (swz / width) * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
+    m0 = (first_m + (swz % width) % gsz) * 256 + (q >> 2) * 64;
+    n0 = ((swz % width) / gsz) * 256 + (q & 3) * 64;
+    if (m0 >= p.M) return;                       // block-uniform: the lower part of a ragged last row tile may be empty
+  }
+  const int nt1 = p.K1 / 64, nt2 = p.K2 / 64, nt = nt1 + nt2;
+  const bf16_t* a2 = p.A2;
+  if (p.a2_group_n > 0) a2 += (size_t)(n0 / p.a2_group_n) * p.a2_group_stride;
+  if (p.a1_group_n > 0) p.A1 += (size_t)(n0 / p.a1_group_n) * p.a1_group_stride;
+  const int srow = lane >> 3, spos = lane & 7;
+  auto fsw = [](int r) { return (r >> 1) & 7; };
+  auto issue = [&](int buf, int t) {
+    const bf16_t *Ab, *Bb;
+    int lda, ldb, k0;
+    if (t < nt1) { Ab = p.A1; lda = p.lda1; Bb = p.B1; ldb = p.ldb1; k0 = t * 64; }
+    else { Ab = a2; lda = p.lda2; Bb = p.B2; ldb = p.ldb2; k0 = (t - nt1) * 64; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;              // 8 pieces of 8 rows x 128 bytes per operand
+      const int r = piece * 8 + srow;
+      const int c = spos ^ fsw(r);
+      const int gr = min(m0 + r, p.M - 1);
+      char* dA = smem + buf * SB + piece * 1024;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Ab + (size_t)gr * lda + k0 + c * 8), LDS_PTR(void, dA), 16, 0, 0);
+      const int rb = 4 * (r & 15) + ((r >> 4) & 3);   // column slot s of B fragment j is row 4s + j of the 64 (gemm_nt_kernel_x)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(Bb + (size_t)(n0 + rb) * ldb + k0 + c * 8), LDS_PTR(void, dA + TB), 16, 0, 0);
+    }
+  };
+  f32x4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nt) issue(t, t);
+  const int frow = lane & 15, fchk = lane >> 4;
+  for (int t = 0; t < nt; ++t) {
+    // K-tile t has landed for this wave's pieces when at most the pieces of the K-tiles behind it are outstanding (4 per K-tile and wave)
+    const int behind = min(nt - 1 - t, NS - 2);
+    if (NS > 4 && behind >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (NS > 4 && behind == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (NS > 4 && behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NS > 4 && behind == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // ... for every wave's pieces; and everyone has finished reading the stage of K-tile t - 1
+    if (t + NS - 1 < nt) issue((t + NS - 1) % NS, t + NS - 1);
+    const char* As = smem + (t % NS) * SB;
+    const char* Bs = As + TB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + fchk;
+      const int arow = wave * 16 + frow;
+      const bf16x8_t af = *(const bf16x8_t*)(As + arow * ROWB + ((c ^ fsw(arow)) << 4));
+      bf16x8_t bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = j * 16 + frow;
+        bfr[j] = *(const bf16x8_t*)(Bs + row * ROWB + ((c ^ fsw(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[j], 0, 0, 0);
+    }
+  }
+  // acc[j][r] of lane (frow, fchk): row wave*16 + 4*fchk + r, column 4*frow + j of the block's 64x64 piece
+  epi_dispatch(p, [&](auto MD_) {
+    constexpr int md = decltype(MD_)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wave * 16 + 4 * fchk + r;
+      if (m < p.M) epilogue4<md>(p, m, n0 + 4 * frow, acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_nt "ping-pong" kernel: 256x256 block tile, 8 waves (2 x 4, each 128x64), BK = 64, two 64-KiB
 // LDS stages (128 KiB, one block per CU).  The two wave groups G0 = waves 0-3 and G1 = waves 4-7
 // (wave w and w+4 share a SIMD) run the SAME per-K-tile program
@@ -1838,6 +1937,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_tail64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_tail64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
@@ -1949,7 +2050,16 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
         t.quarter = 1; t.tile0 = full;
         // (a four-stage ring for these blocks - three K-tiles in flight, one block per CU - measured 973.1 vs 969.9 ms per step: no gain,
         // a lone 4-wave 128x128 block runs at ~0.6 PF/s per CU whatever its prefetch depth; removed)
-        hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
+        // (round 4) tails of a multi-round launch run as SIXTEENTH tiles (16 blocks of 64x64 per tile: a 16-tile tail already fills the chip);
+        // the deep-K one-round problem keeps its quarter tiles (every tile of it is a "tail" tile: rate matters there).  OPADPO_TAIL16=0: quarter tiles
+        // Measured (GB_ONLY=tail, N = 4096; quarter tiles -> sixteenth tiles): 16-tile tail +38 -> +24 us (K = 4096), +115 -> +44 us (K = 11008);
+        // 32 tiles +51 -> +34, +115 -> +82; 48 tiles: a tie; 64 tiles (1024 blocks, four per CU): +50 -> +65, i.e. quarter tiles from 48 tiles on.
+        static const int tail16 = getenv("OPADPO_TAIL16") ? atoi(getenv("OPADPO_TAIL16")) : 1;
+        if (full > 0 && tail16 && rem <= 40) {
+          if (rem <= 16) hipLaunchKernelGGL(gemm_nt_tail64_kernel<8>, dim3(rem * 16), dim3(256), 8 * 16384, st, t);
+          else hipLaunchKernelGGL(gemm_nt_tail64_kernel<4>, dim3(rem * 16), dim3(256), 4 * 16384, st, t);
+        }
+        else hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
         return hipGetLastError();
       }
       W4_LAUNCH(pp_tiles);

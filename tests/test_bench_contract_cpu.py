@@ -28,6 +28,17 @@ def test_bench_line_fields():
     assert abs(d["value"] - d["config"]["global_pairs_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
     base = json.load(open(os.path.join(REPO, "BASELINE.json")))
     assert "pairs" in base["metric"] and "pairs" in d["metric"]
+    # round-4 sub-records (never part of `value`): the other BASELINE.json configurations and the directly timed CPU baseline
+    for k, unit in (("thirteen_b", "pairs/s"), ("recipe", "samples/s")):
+        if k in d:
+            assert "error" not in d[k], d[k]
+            assert d[k]["unit"] == unit and d[k]["value"] > 0 and d[k]["ms_per_step"] > 0
+    full = c.get("full_depth_measured")
+    if full is not None:
+        assert full["extrapolated"] is False and full["value"] > 0 and full["cores"] >= 1 and full["source"].endswith("_cpu_baseline_full.json")
+    ev = r.get("event_profiling")
+    if ev is not None:
+        assert ev["ms_per_step_same_pool_without_events"] > 0
 
 
 def test_bench_defaults():
