@@ -48,7 +48,8 @@ const char* opadpo_last_error(void);
  * 15 = M <= 64 weight-streaming kernel); use_tr bit 0 = ds_read_b64_tr_b16 transposed LDS reads in attention / gemm_tn, bit 1 =
  * attention forward through a direct-to-LDS double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks
  * per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
- * M <= 16 (default there: the whole-cache-line 8-row form). */
+ * M <= 16 (default there: the whole-cache-line 8-row form), bits 5-6 = kernel behind opadpo_gemm_nt_decode (0 = the library's choice,
+ * 1 = the LDS-ring kernel for every mode, 2 = the register-streaming kernel for every mode; A/B runs and tests). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
@@ -88,7 +89,8 @@ int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, in
 
 /* Decode projection for up to 64 tokens (rollout at 33..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
  * no bias / residual / LoRA tail (adapter-free or merged adapter).  Both operands are streamed through a 4-stage LDS ring by
- * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup.  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
+ * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup; the bf16-output projection of at most 256 column tiles
+ * (q|k|v) takes the register-streaming kernel instead (every wave its own weight stream, no LDS in the K-loop; round 4).  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
  * C[splits][M,N] (ldc = row stride of one slice) - K is split over `splits` workgroups (<= 0: chosen by the library, query it with
  * opadpo_gemm_nt_decode_splits) and the consumer adds the slices (opadpo_rmsnorm_sum_fwd); mode 2: OPADPO_ACT_SWIGLU_PAIR weight
  * layout -> bf16 C[M, N/2] = silu(gate) * up.  M <= 64, N % 128 == 0, K % 64 == 0. */

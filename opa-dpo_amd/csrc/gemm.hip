@@ -1402,10 +1402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
   for (int t = t0; t < t1; ++t) {
     // stage t landed: this wave's pieces of stages t+1 .. t+NS-2 may stay in flight (2 + WP pieces each)
     if (t1 - t - 1 >= D_NS - 2) {
-      if constexpr (D_NS == 8 && KW == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if constexpr (D_NS == 8) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-      else if constexpr (KW == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D_NS - 2) * (2 + WP)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1476,6 +1473,156 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
       stv.x = pack_bf2(acc[f][0], acc[f][1]);
       stv.y = pack_bf2(acc[f][2], acc[f][3]);
       *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = stv;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_nt "dec64r" kernel (round 4): the same job as gemm_nt_dec64_kernel - <= 64 tokens against 16*NF weight rows per workgroup,
+// same MODEs, same K-split over gridDim.y - with NO LDS in the K-loop: every WAVE is its own stream.  The K range of the workgroup is
+// dealt to its 4 waves by 64-deep k-tile (wave w takes tiles t0 + w, t0 + w + 4, ...); a wave loads its NF weight fragments (16 rows x
+// 2 x 64 B each, nt) and its MF token fragments (L2-resident) straight into MFMA operand registers, PF tiles per batch, and multiplies
+// NF x MF x 2 MFMAs per tile; no barrier until the four partial accumulators meet in LDS once, at the end (summed in wave order:
+// deterministic).  Activation traffic from L2: 4 / NF bytes per weight byte - and that is what bounds it: time falls with the token count
+// (q|k|v 36.6 / 33.2 / 29.9 us at 64 / 48 / 32 tokens) where the ring kernel's does not.  Measured against the ring kernel at 64 tokens
+// (profiles/r04_dec64r_bench.txt): q|k|v 36.6 vs 45.2 us (the ring kernel's weak case: 192 tiles, run as 384 32-row workgroups whose
+// stages are two thirds activations), gate|up 69.6 vs 53.2, down 29.6 vs 23.4, o 13.3 vs 10.5, lm_head 75.5 vs 63.0 - so the launcher
+// takes it for the q|k|v projection only (mode 0, <= 256 tiles).  32-row workgroups (NF = 2) lost everywhere (q|k|v 49 us) and are not
+// instantiated; a 5-stage ring for the other kernel (80 KiB, still two workgroups per CU) changed nothing (53.5 vs 54.1 us on gate|up):
+// that kernel is not short of bytes in flight.
+// ---------------------------------------------------------------------------------------------------
+template <int MF, int MODE, int NF, int PF>
+__global__ __launch_bounds__(256, NF == 4 ? 2 : 3) void gemm_nt_dec64r_kernel(GemmNTArgs p) {
+  static_assert(NF == 2 || NF == 4, "32 or 64 weight rows per workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [4 waves][NF][MF][64 lanes] f32x4 = NF*MF*4 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bt = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
+  const int nt = p.K1 / D_BK;
+  const int per = (nt + splits - 1) / splits;
+  const int t0 = split * per, t1 = min(nt, t0 + per);
+  constexpr int ROWS = NF * 16, GPB = 128 / ROWS;
+  // weight rows of this workgroup: ROWS consecutive rows, or (MODE 2) ROWS/2 gate rows + the ROWS/2 up rows 64 further
+  const int n0 = MODE == 2 ? (bt / GPB) * 128 + (bt % GPB) * (ROWS / 2) : bt * ROWS;
+  auto wrow = [&](int r) { return MODE == 2 ? n0 + (r < ROWS / 2 ? r : 64 - ROWS / 2 + r) : n0 + r; };
+  const int fr = lane & 15, fc = lane >> 4;
+  unsigned voffW[NF], voffA[MF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) voffW[i] = (unsigned)wrow(i * 16 + fr) * (unsigned)p.ldb1 * 2u + fc * 16u;
+#pragma unroll
+  for (int f = 0; f < MF; ++f) voffA[f] = (unsigned)min(f * 16 + fr, p.M - 1) * (unsigned)p.lda1 * 2u + fc * 16u;
+  auto uni = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uni(p.A1), 0, (int)0xffffffffu, 0x00020000);
+  struct Tile { u32x4_t w[NF][2], x[MF][2]; };
+  Tile buf[PF];
+  auto load = [&](Tile& b, int t) {
+    const int k2 = t * (D_BK * 2);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      b.w[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], k2, 2);            // aux 2 = nt: streamed once
+      b.w[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], k2 + 64, 2);       // the other half of the same 128-byte lines
+    }
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+      b.x[f][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[f], k2, 0);
+      b.x[f][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[f], k2 + 64, 0);
+    }
+  };
+  f32x4_t acc[NF][MF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const Tile& b) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+          acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&b.w[i][kk], *(const bf16x8_t*)&b.x[f][kk], acc[i][f], 0, 0, 0);
+  };
+  const int tw = t0 + wave;
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (tw + 4 * s < t1) load(buf[s], tw + 4 * s);
+  int t = tw;
+  // steady state: every slot holds a tile and has a successor - no branches, so the compiler's vmcnt waits stay COUNTED (a conditional
+  // load makes it wait for everything at the loop head); the last PF..2*PF-1 tiles of the wave drain through the guarded loop
+  for (; t + 4 * (2 * PF - 1) < t1; t += 4 * PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      compute(buf[s]);
+      __builtin_amdgcn_sched_barrier(0);         // keep the issue order: the scheduler otherwise sinks every load below the last MFMA (wait-all / compute-all)
+      load(buf[s], t + 4 * s + 4 * PF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (; t < t1; t += 4 * PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int tt = t + 4 * s;
+      if (tt < t1) {
+        compute(buf[s]);
+        if (tt + 4 * PF < t1) load(buf[s], tt + 4 * PF);
+      }
+    }
+  }
+  // the four k-partials of the workgroup meet in LDS; lane holds C[token f*16 + fr][columns fc*4 .. +3 of fragment i's 16 weight rows]
+  float* red = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int f = 0; f < MF; ++f) *(f32x4_t*)(red + ((((wave * NF + i) * MF + f) * 64 + lane) << 2)) = acc[i][f];
+  __syncthreads();
+  auto total = [&](int i, int f) {
+    f32x4_t v = *(const f32x4_t*)(red + ((((0 * NF + i) * MF + f) * 64 + lane) << 2));
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) v += *(const f32x4_t*)(red + ((((w2 * NF + i) * MF + f) * 64 + lane) << 2));
+    return v;
+  };
+  if constexpr (MODE == 2) {
+    // fragments 0 .. NF/2-1 = gate rows, NF/2 .. NF-1 = the up rows of the same output columns; wave w < NF/2 finishes pair w
+    if (wave >= NF / 2) return;
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+      const int m = f * 16 + fr;
+      if (m >= p.M) continue;
+      const f32x4_t g = total(wave, f), u = total(NF / 2 + wave, f);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gt = bf2f(f2bf(g[e])), up = bf2f(f2bf(u[e]));
+        o[e] = gt / (1.0f + __expf(-gt)) * up;
+      }
+      uint2 stv;
+      stv.x = pack_bf2(o[0], o[1]);
+      stv.y = pack_bf2(o[2], o[3]);
+      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + (bt / GPB) * 64 + (bt % GPB) * (ROWS / 2) + wave * 16 + fc * 4) = stv;
+    }
+    return;
+  }
+  for (int i = wave; i < NF; i += 4) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+      const int m = f * 16 + fr;
+      if (m >= p.M) continue;
+      const f32x4_t v = total(i, f);
+      const int n = n0 + i * 16 + fc * 4;
+      if constexpr (MODE == 1) {
+        *(float4*)((float*)p.C + ((size_t)split * p.M + m) * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 stv;
+        stv.x = pack_bf2(v[0], v[1]);
+        stv.y = pack_bf2(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = stv;
+      }
     }
   }
 }
@@ -1891,6 +2038,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTNGroup G, int 
 }  // namespace
 
 static bool g_skinny8 = true;       // M <= 16 decode GEMMs: whole-cache-line form of the streaming kernel
+static int g_dec64_variant = getenv("OPADPO_DEC64_V") ? atoi(getenv("OPADPO_DEC64_V")) : 0;      // 0 auto, 1 LDS-ring kernel everywhere, 2 register-streaming kernel everywhere; use_tr bits 5-6
 static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 8-wave 256x256 kernel (p8); 31: 4-wave 256x256 kernel (w4) forced; 15: M <= 64 streaming
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
@@ -1900,6 +2048,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   opadpo_set_attn_dma((use_tr & 2) != 0);
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
+  if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
@@ -2163,6 +2312,24 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
   if (mode != 1) splits = 1;
   splits = gemm_nt_dec64_splits(a.N, a.K1, splits);
   const int mf = (a.M + 15) / 16;
+  // register-streaming kernel (dec64r) for the bf16-output projection that does not fill the chip with 64-row workgroups (q|k|v: 192): measured at
+  // 64 / 48 / 32 tokens 36.6 / 33.2 / 29.9 us against 45.2 / 45.0 / 44.3 for the ring kernel's 32-row form; every other decode GEMM stays on the
+  // ring kernel (gate|up 53 vs 70 us, down 23 vs 30, lm_head 63 vs 76: dec64r is bound by its activation reads from L2).  g_dec64_variant
+  // 1 / 2 force the ring / the register kernel (experiments).
+  if (g_dec64_variant == 2 || (g_dec64_variant == 0 && mode == 0 && tiles <= 256)) {
+#define DR_GO(MF_, MD_)                                                                                                               \
+  do {                                                                                                                                \
+    static bool at_ = false;                                                                                                          \
+    constexpr int lds_ = 4 * MF_ * 4096;                                                                                              \
+    if (!at_) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64r_kernel<MF_, MD_, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); at_ = true; } \
+    hipLaunchKernelGGL((gemm_nt_dec64r_kernel<MF_, MD_, 4, 2>), dim3(a.N / 64, splits), dim3(256), lds_, st, a);                      \
+  } while (0)
+#define DR_MODE(MD_) do { if (mf == 1) DR_GO(1, MD_); else if (mf == 2) DR_GO(2, MD_); else if (mf == 3) DR_GO(3, MD_); else DR_GO(4, MD_); } while (0)
+    if (mode == 0) DR_MODE(0); else if (mode == 1) DR_MODE(1); else DR_MODE(2);
+#undef DR_MODE
+#undef DR_GO
+    return hipGetLastError();
+  }
   static const int kw2_max = getenv("OPADPO_DEC64_KW2") ? atoi(getenv("OPADPO_DEC64_KW2")) : 256;      // diagnostics
   if (mode == 0 && tiles <= kw2_max) {      // 32-row workgroups: twice the blocks for a projection that does not fill the chip
     static bool at[5] = {false, false, false, false, false};

@@ -153,7 +153,8 @@ def set_flags(use_glds=10, use_tr: bool = True) -> None:
     17 the 8-wave 4-phase 256x256 kernel (p8), 31 the 4-wave kernel forced, 15 force the M <= 64 streaming kernel.  True -> default.
     use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V
     ring (default: register-staged single buffer, 3 blocks per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256
-    gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel)."""
+    gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel), bits 5-6 = kernel of
+    opadpo_gemm_nt_decode: 0 the library's choice, 1 the LDS-ring kernel everywhere, 2 the register-streaming kernel everywhere."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 

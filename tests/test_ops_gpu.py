@@ -1139,12 +1139,16 @@ def test_gemm_nt_rope_pos(L, lora):
 
 @pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
 @pytest.mark.parametrize("shape", [(4096, 4096), (4096, 11008), (12288, 4096), (1024, 512)])
-def test_gemm_nt_decode_modes(L, M, shape):
-    """opadpo_gemm_nt_decode (LDS-ring decode GEMM, 64 weight rows x <= 64 tokens x one K-slice per workgroup): bf16 output, fp32
-    K-split partial tiles (their sum in slice order) and the SwiGLU-pair epilogue, against torch fp32; rows >= M untouched."""
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_gemm_nt_decode_modes(L, M, shape, kernel):
+    """opadpo_gemm_nt_decode: bf16 output, fp32 K-split partial tiles (their sum in slice order) and the SwiGLU-pair epilogue, against
+    torch fp32; rows >= M untouched.  kernel 1 = the LDS-ring kernel (64 weight rows x <= 64 tokens x one K-slice per workgroup) for every
+    mode, 2 = the register-streaming kernel (gemm_nt_dec64r_kernel: every wave its own weight stream, K dealt to the waves by k-tile) for
+    every mode, 0 = the library's choice (the register kernel for bf16 output up to 256 column tiles, e.g. q|k|v)."""
     import ctypes as C
     N, K = shape
     lib = L.load()
+    L.set_flags(10, 1 | (kernel << 5))
     a, w = rnd(M, K, scale=0.5, seed=1), rnd(N, K, scale=0.05, seed=2)
     want = a.float() @ w.float().t()
     ob = torch.full((M + 2, N), 7.0, dtype=BF, device=dev())
@@ -1176,6 +1180,7 @@ def test_gemm_nt_decode_modes(L, M, shape):
     for _ in range(5):
         L.call("opadpo_gemm_nt_decode", L.ptr(abig), K + 64, L.ptr(wbig), K + 128, K, L.ptr(o3), N, 0, M, N, 1, L.stream())
         assert torch.equal(o2, o3)
+    L.set_flags(10, True)
 
 
 @pytest.mark.parametrize("resid_f32", [True, False])

@@ -171,6 +171,38 @@ def main():
         L.set_flags(10, True)
         json.dump(res, open(os.path.join(REPO, "gpurun_out", "gemm_skinny.json"), "w"), indent=1)
         return
+    if only == "dec":      # the decode GEMMs for 17..64 tokens (opadpo_gemm_nt_decode): ring kernel vs the register-streaming kernel
+        lib = L.load()
+        for M_ in [int(v) for v in os.environ.get("GB_MS", "64,32").split(",")]:
+            for name, N, K1, mode, splits in (("qkv", 12288, 4096, 0, 1), ("o", 4096, 4096, 1, 0), ("gate_up", 22016, 4096, 2, 1),
+                                              ("down", 4096, 11008, 1, 0), ("lm_head", 32000, 4096, 1, 1)):
+                copies = max(2, int(6.0e8 // (N * K1 * 2)) + 1)
+                ws = [(torch.randn(N, K1, device=dev) * 0.02).to(BF) for _ in range(copies)]
+                a1 = torch.randn(M_, K1, device=dev).to(BF)
+                S = lib.opadpo_gemm_nt_decode_splits(N, K1, splits) if mode == 1 else 1
+                out = torch.empty(S * M_ * (N // 2 if mode == 2 else N), dtype=torch.float32 if mode == 1 else BF, device=dev)
+                ref = None
+                for label, v in (("ring", 1), ("r64", 2), ("auto", 0)):
+                    L.set_flags(10, 1 | (v << 5))
+                    it = [0]
+
+                    def fn():
+                        w = ws[it[0] % copies]
+                        it[0] += 1
+                        L.call("opadpo_gemm_nt_decode", L.ptr(a1), K1, L.ptr(w), K1, K1, L.ptr(out), N // 2 if mode == 2 else N, mode, M_, N, splits, L.stream())
+                    t = timeit(fn, iters=3 * copies, warm=copies)
+                    it[0] = 0
+                    fn()
+                    torch.cuda.synchronize()
+                    got = out.float().view(S, M_, -1).sum(0) if mode == 1 else out.float().view(M_, -1)
+                    if ref is None:
+                        ref = got.clone()
+                    err = float((got - ref).abs().max() / ref.abs().max())
+                    res.append(dict(kernel=label, name=name, M=M_, N=N, K=K1, splits=S, us=round(t * 1e6, 2), GBps=round(N * K1 * 2 / t / 1e9), rel_vs_ring=err))
+                    print(res[-1], flush=True)
+                del ws
+        L.set_flags(10, True)
+        return
     if only == "pmc":      # few launches of the two big shapes, default variant only (PMC passes serialize kernels)
         L.set_flags(int(os.environ.get("GB_VARIANT", 10)), True)
         for name, N, K1, K2, grp in shapes[:2]:
