@@ -381,8 +381,14 @@ constexpr int P_STAGE = 2 * P_TILE;              // A + B
 // N <= 4096 (o / down projection, every dgrad into the hidden width, the r-wide LoRA products) is 1.5-4 % faster B first, the wide
 // projections (q|k|v, gate|up, lm_head) 2.5-3 % faster A first - independent of group_m, of a third / fourth barrier per K-tile that
 // lengthens every piece's lead by 50 MFMAs, and of hand-placed lgkmcnt waits (all built and measured in round 3, none moved the time).
+// OPADPO_W4_DIAG (compile-time, diagnostics only - results are WRONG with any bit set; tools/build_diag.sh): timing of the K-loop with one of its
+// stall sources removed.  1: no vmcnt waits, 2: no barriers, 4: no DMA issue, 8: no fragment reads after the first K-tile, 16: no lgkmcnt(0) before barrier 1
+#ifndef OPADPO_W4_DIAG
+#define OPADPO_W4_DIAG 0
+#endif
 template <bool ORDER_B>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
+  constexpr int DIAG = OPADPO_W4_DIAG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -458,15 +464,28 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   };
   const i32x4_t qA1 = mk_rsrc(a1), qB1 = mk_rsrc(p.B1), qA2 = mk_rsrc(nt2 ? a2 : a1), qB2 = mk_rsrc(nt2 ? p.B2 : p.B1);
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
+  // Scalar diet of the K-loop (round 4): every scalar instruction between two MFMAs of the only wave on a SIMD costs issue time (the
+  // vendor kernel of this geometry runs the same MFMA / LDS / VMEM counts with a quarter fewer SALU instructions and 10 % fewer wave
+  // cycles).  (i) M0 is written by ONE s_add_u32 (stage offset + per-piece constant, both resident SGPRs) instead of s_add + s_mov;
+  // (ii) the descriptors / K origin of the operand pair being fetched live in loop-carried SGPRs that the (rare) switch to the
+  // K-concatenated tail overwrites, instead of 9 s_cselect + compare + subtract per K-tile.
+  unsigned pcoff[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) pcoff[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
+  i32x4_t curA = qA1, curB = qB1;
+  int kbase = 0;                                        // first K-tile of the operand pair in use by the in-loop DMA
+  // s_pack_ll_b32_b16 is the one two-operand scalar "add" that leaves SCC alone (an SCC clobber on the asm made the hazard recognizer put an
+  // s_nop in front of every second piece): M0 = {stage bit, piece offset} = (t & 1) * 64 KiB + offset - the dynamic LDS block starts at 0
+  // (the kernel has no static LDS; checked once below) and every piece offset is below 64 KiB.
+  if (lds0 != 0) __builtin_trap();
   auto dma_m0 = [&](int t, int q) {
-    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-    asm volatile("s_mov_b32 m0, %0" :: "s"(dst) : "memory");
+    const unsigned stg = (unsigned)__builtin_amdgcn_readfirstlane(t & 1);
+    asm volatile("s_pack_ll_b32_b16 m0, %0, %1" :: "s"(pcoff[q]), "s"(stg) : "memory");
   };
   auto dma_go = [&](int t, int q) {
-    const bool second = t >= nt1;
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((second ? (t - nt1) : t) * P_BK * 2);
-    const i32x4_t r = q < 8 ? (second ? qA2 : qA1) : (second ? qB2 : qB1);
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(r), "s"(soff) : "memory");
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((t - kbase) * P_BK * 2);
+    if (q < 8) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(curA), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(curB), "s"(soff) : "memory");
   };
 
   f32x4_t acc[8][8];
@@ -480,6 +499,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128;
   // fragment r of set kk of tile t: r = 0..7 -> B fragments, 8..15 -> A fragments
   auto read_frag = [&](int t, int kk, int r) {
+    if constexpr ((DIAG & 8) != 0) { if (t > 0 || kk > 0) return; }
     const char* st = smem + (t & 1) * P_STAGE;
     const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
     if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + ((r & 1) * 8 + (r & 6)) * 128 + cb);
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   };
   auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
     constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    constexpr bool dma = has_next2;
+    constexpr bool dma = has_next2 && !(DIAG & 4);
     auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };      // k-th piece issued -> piece id (0..7 = A rows, 8..15 = B rows)
     // schedule knobs.  R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
     // DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after); one MFMA sits
@@ -516,11 +536,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     mfma_run(0, R1, B1 - R1 - 1);
     W4_PIN();
     if constexpr (has_next2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (!(DIAG & 16)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       W4_PIN(); mfma_run(0, B1 - 1, 1); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
+      if constexpr (!(DIAG & 2)) __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
       W4_PIN();
-      if (t + 2 == nt1) { set_voff(true); W4_PIN(); }
+      if (t + 2 == nt1) { set_voff(true); curA = qA2; curB = qB2; kbase = nt1; W4_PIN(); }
     } else {
       mfma_run(0, B1 - 1, 1);
       W4_PIN();
@@ -544,10 +564,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     }
     W4_PIN();
     if constexpr (has_next) {
-      if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!(DIAG & 1)) {
+        if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       W4_PIN(); mfma_run(1, 35, 1); W4_PIN();
-      __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
+      if constexpr (!(DIAG & 2)) __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
     } else {
       mfma_run(1, 35, 1);
     }
@@ -584,6 +606,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   }
   __builtin_amdgcn_s_barrier();
   W4_PIN();
+  if (nt1 <= 1) { curA = qA2; curB = qB2; kbase = nt1; }      // tile 2 onwards already belongs to the tail (its voff was set above)
 #pragma unroll
   for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   W4_PIN();
