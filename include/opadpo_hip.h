@@ -49,7 +49,8 @@ const char* opadpo_last_error(void);
  * attention forward through a direct-to-LDS double-buffered K/V ring (default: register-staged single buffer, which keeps 3 blocks
  * per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
  * M <= 16 (default there: the whole-cache-line 8-row form), bits 5-6 = kernel behind opadpo_gemm_nt_decode (0 = the library's choice,
- * 1 = the LDS-ring kernel for every mode, 2 = the register-streaming kernel for every mode; A/B runs and tests). */
+ * 1 = the LDS-ring kernel of rounds 2-4, 3 = the whole-line streaming kernel gemm_nt_dec64x = the library's choice; A/B runs and tests), bits 7-8 = weight rows per workgroup of that kernel (0 = by shape, 1 / 2 / 3 =
+ * 48 / 64 / 128 rows; tests). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
@@ -87,7 +88,7 @@ int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, in
                             const uint16_t* A2, int lda2, const uint16_t* B2, int ldb2, int K2, int a2_group_n, int a2_group_stride,
                             uint16_t* C, int ldc, int M, int N, const int32_t* row_pos, float theta, int rope_cols, void* stream);
 
-/* Decode projection for up to 64 tokens (rollout at 33..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
+/* Decode projection for up to 64 tokens (rollout at 9..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
  * no bias / residual / LoRA tail (adapter-free or merged adapter).  Both operands are streamed through a 4-stage LDS ring by
  * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup; the bf16-output projection of at most 256 column tiles
  * (q|k|v) takes the register-streaming kernel instead (every wave its own weight stream, no LDS in the K-loop; round 4).  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles

@@ -257,7 +257,7 @@ struct opadpo_ctx {
     int B = 0, Lp = 0, max_ctx = 0, adapter = 0, max_new = 0;
     bf16_t *kc, *vc; uint8_t* key_mask; float *x, *x2, *hs; bf16_t *hn, *n1, *qkv, *t_qkv, *att, *t_o, *n2, *t_gu, *gu, *act, *t_d, *emb;
     float *hb, *rstd, *logits; int32_t *cur_tok, *step_d, *pos_d; uint8_t* finished; void* ws; size_t ws_bytes;
-    float *part_o, *part_d; int split_o = 1, split_d = 1; bool use64 = false;      // K-split partial tiles of the 33..64-token decode GEMMs
+    float *part_o, *part_d; int split_o = 1, split_d = 1; bool use64 = false;      // K-split partial tiles of the 9..64-token decode GEMMs
     int32_t* history; float temperature; int top_k; float top_p; uint64_t seed; int eos_id, pad_id, suppress_eos;
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t cap_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
   } dec;
@@ -1166,7 +1166,7 @@ static hipError_t decode_one(opadpo_ctx* c, hipStream_t st) {
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = launch_gather_rows(c->embed, H, D.cur_tok, D.emb, B, H, st)) != hipSuccess) return e;
   if (D.use64) {
-    // 33..64 tokens: LDS-ring decode GEMMs; x / hb = fp32 residual stream, part_o / part_d = K-slice partial tiles of the o / down
+    // 9..64 tokens: the decode GEMMs for <= 64 tokens (opadpo_gemm_nt_decode); x / hb = fp32 residual stream, part_o / part_d = K-slice partial tiles of the o / down
     // projections, added (in slice order) by the RMSNorm that follows them
     const int F = d.ffn;
     const size_t pstride = (size_t)B * H;
@@ -1253,9 +1253,10 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   D.history = history; D.temperature = temperature; D.top_k = top_k; D.top_p = top_p; D.seed = seed; D.eos_id = eos_id; D.pad_id = pad_id;
   D.suppress_eos = suppress_eos;
   D.ws_bytes = attn_decode_workspace_bytes(B, nh, hd, max_ctx);
-  // 25..64 sequences without LoRA tails (adapter-free or merged adapter): the LDS-ring decode GEMM (gemm_nt_dec64_kernel), the o / down
-  // projections K-split into fp32 partial tiles that the following RMSNorm adds.  OPADPO_DEC64_MIN (diagnostics): smallest batch taking it.
-  static const int dec64_min = getenv("OPADPO_DEC64_MIN") ? atoi(getenv("OPADPO_DEC64_MIN")) : 25;
+  // 9..64 sequences without LoRA tails (adapter-free or merged adapter): the decode GEMM for <= 64 tokens (gemm_nt_dec64x_kernel), the o / down
+  // projections K-split into fp32 partial tiles that the following RMSNorm adds.  Measured per decode step against the 8/16-row streaming kernels
+  // of the other path: B = 16 4.84 vs 5.15 ms, B = 8 4.12 vs 3.80 ms.  OPADPO_DEC64_MIN (diagnostics): smallest batch taking it.
+  static const int dec64_min = getenv("OPADPO_DEC64_MIN") ? atoi(getenv("OPADPO_DEC64_MIN")) : 9;
   D.use64 = B >= dec64_min && B <= 64 && ad.kind != 1 && H <= 256 * 8 * 3 && F % 64 == 0 && !(c->use_tr >= 0 && (c->use_tr & 32));
   D.split_o = D.use64 ? gemm_nt_dec64_splits(H, H, 0) : 1;
   D.split_d = D.use64 ? gemm_nt_dec64_splits(H, F, 0) : 1;

@@ -1368,8 +1368,14 @@ constexpr int D_BN = 64, D_BK = 64, D_HALF = 8192, D_STAGE = 16384;
 
 // KW = 2 (MODE 0 only): 32 weight rows per workgroup, waves 0,1 take the first 32 k of every tile and waves 2,3 the second (partials
 // meet in LDS once, at the end) - twice the workgroups for a projection whose 64-row tiles do not fill the chip (q|k|v: 192 -> 384).
+// OPADPO_DEC64_DIAG (compile-time, diagnostics only - results WRONG; tools/build_diag.sh): 1 no activation DMA, 2 no weight DMA, 4 no fragment
+// reads / MFMAs, 8 no barrier in the k-loop
+#ifndef OPADPO_DEC64_DIAG
+#define OPADPO_DEC64_DIAG 0
+#endif
 template <int MF, int MODE, int D_NS, int KW = 1>      // D_NS = ring depth: 4 (two workgroups per CU) or 8 (one per CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
+  constexpr int DDG = OPADPO_DEC64_DIAG;
   static_assert(KW == 1 || MODE == 0, "K-split inside the workgroup: bf16 output only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1409,8 +1415,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int piece = wave * 2 + j;
-      if (j < WP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(void, st + (wave * WP + j) * 1024), 16, voffW[j], k2, 0, 2);      // aux 2 = nt: streamed once
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, st + D_HALF + piece * 1024), 16, voffA[j], k2, 0, 0);
+      if (j < WP && !(DDG & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(void, st + (wave * WP + j) * 1024), 16, voffW[j], k2, 0, 2);      // aux 2 = nt: streamed once
+      if (!(DDG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, st + D_HALF + piece * 1024), 16, voffA[j], k2, 0, 0);
     }
   };
   f32x4_t acc[MF];
@@ -1424,14 +1430,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
     if (t0 + s < t1) issue(t0 + s);
   for (int t = t0; t < t1; ++t) {
     // stage t landed: this wave's pieces of stages t+1 .. t+NS-2 may stay in flight (2 + WP pieces each)
+    constexpr int PPS = ((DDG & 1) ? 0 : 2) + ((DDG & 2) ? 0 : WP);      // pieces per wave and stage
     if (t1 - t - 1 >= D_NS - 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D_NS - 2) * (2 + WP)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D_NS - 2) * PPS) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();                  // everyone's pieces of stage t are in; everyone is done reading stage t-1
+    if (!(DDG & 8)) __syncthreads();                  // everyone's pieces of stage t are in; everyone is done reading stage t-1
     if (t + D_NS - 1 < t1) issue(t + D_NS - 1);          // into the slot stage t-1 occupied
     const char* st = smem + ((t - t0) % D_NS) * D_STAGE;
+    if (DDG & 4) continue;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (KW == 2 && kk != (wave >> 1)) continue;
@@ -1499,157 +1507,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dec64_kernel(GemmNTArgs p) {
     }
   }
 }
-
-
-// ---------------------------------------------------------------------------------------------------
-// gemm_nt "dec64r" kernel (round 4): the same job as gemm_nt_dec64_kernel - <= 64 tokens against 16*NF weight rows per workgroup,
-// same MODEs, same K-split over gridDim.y - with NO LDS in the K-loop: every WAVE is its own stream.  The K range of the workgroup is
-// dealt to its 4 waves by 64-deep k-tile (wave w takes tiles t0 + w, t0 + w + 4, ...); a wave loads its NF weight fragments (16 rows x
-// 2 x 64 B each, nt) and its MF token fragments (L2-resident) straight into MFMA operand registers, PF tiles per batch, and multiplies
-// NF x MF x 2 MFMAs per tile; no barrier until the four partial accumulators meet in LDS once, at the end (summed in wave order:
-// deterministic).  Activation traffic from L2: 4 / NF bytes per weight byte - and that is what bounds it: time falls with the token count
-// (q|k|v 36.6 / 33.2 / 29.9 us at 64 / 48 / 32 tokens) where the ring kernel's does not.  Measured against the ring kernel at 64 tokens
-// (profiles/r04_dec64r_bench.txt): q|k|v 36.6 vs 45.2 us (the ring kernel's weak case: 192 tiles, run as 384 32-row workgroups whose
-// stages are two thirds activations), gate|up 69.6 vs 53.2, down 29.6 vs 23.4, o 13.3 vs 10.5, lm_head 75.5 vs 63.0 - so the launcher
-// takes it for the q|k|v projection only (mode 0, <= 256 tiles).  32-row workgroups (NF = 2) lost everywhere (q|k|v 49 us) and are not
-// instantiated; a 5-stage ring for the other kernel (80 KiB, still two workgroups per CU) changed nothing (53.5 vs 54.1 us on gate|up):
-// that kernel is not short of bytes in flight.
-// ---------------------------------------------------------------------------------------------------
-template <int MF, int MODE, int NF, int PF>
-__global__ __launch_bounds__(256, NF == 4 ? 2 : 3) void gemm_nt_dec64r_kernel(GemmNTArgs p) {
-  static_assert(NF == 2 || NF == 4, "32 or 64 weight rows per workgroup");
-  extern __shared__ __attribute__((aligned(16))) char smem[];          // [4 waves][NF][MF][64 lanes] f32x4 = NF*MF*4 KiB
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bt = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
-  const int nt = p.K1 / D_BK;
-  const int per = (nt + splits - 1) / splits;
-  const int t0 = split * per, t1 = min(nt, t0 + per);
-  constexpr int ROWS = NF * 16, GPB = 128 / ROWS;
-  // weight rows of this workgroup: ROWS consecutive rows, or (MODE 2) ROWS/2 gate rows + the ROWS/2 up rows 64 further
-  const int n0 = MODE == 2 ? (bt / GPB) * 128 + (bt % GPB) * (ROWS / 2) : bt * ROWS;
-  auto wrow = [&](int r) { return MODE == 2 ? n0 + (r < ROWS / 2 ? r : 64 - ROWS / 2 + r) : n0 + r; };
-  const int fr = lane & 15, fc = lane >> 4;
-  unsigned voffW[NF], voffA[MF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i) voffW[i] = (unsigned)wrow(i * 16 + fr) * (unsigned)p.ldb1 * 2u + fc * 16u;
-#pragma unroll
-  for (int f = 0; f < MF; ++f) voffA[f] = (unsigned)min(f * 16 + fr, p.M - 1) * (unsigned)p.lda1 * 2u + fc * 16u;
-  auto uni = [](const void* q) -> void* {
-    const unsigned long long v = (unsigned long long)q;
-    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
-  };
-  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)0xffffffffu, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uni(p.A1), 0, (int)0xffffffffu, 0x00020000);
-  struct Tile { u32x4_t w[NF][2], x[MF][2]; };
-  Tile buf[PF];
-  auto load = [&](Tile& b, int t) {
-    const int k2 = t * (D_BK * 2);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      b.w[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], k2, 2);            // aux 2 = nt: streamed once
-      b.w[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], k2 + 64, 2);       // the other half of the same 128-byte lines
-    }
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-      b.x[f][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[f], k2, 0);
-      b.x[f][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA[f], k2 + 64, 0);
-    }
-  };
-  f32x4_t acc[NF][MF];
-#pragma unroll
-  for (int i = 0; i < NF; ++i)
-#pragma unroll
-    for (int f = 0; f < MF; ++f) acc[i][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  auto compute = [&](const Tile& b) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int f = 0; f < MF; ++f)
-          acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&b.w[i][kk], *(const bf16x8_t*)&b.x[f][kk], acc[i][f], 0, 0, 0);
-  };
-  const int tw = t0 + wave;
-#pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (tw + 4 * s < t1) load(buf[s], tw + 4 * s);
-  int t = tw;
-  // steady state: every slot holds a tile and has a successor - no branches, so the compiler's vmcnt waits stay COUNTED (a conditional
-  // load makes it wait for everything at the loop head); the last PF..2*PF-1 tiles of the wave drain through the guarded loop
-  for (; t + 4 * (2 * PF - 1) < t1; t += 4 * PF) {
-#pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      compute(buf[s]);
-      __builtin_amdgcn_sched_barrier(0);         // keep the issue order: the scheduler otherwise sinks every load below the last MFMA (wait-all / compute-all)
-      load(buf[s], t + 4 * s + 4 * PF);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  for (; t < t1; t += 4 * PF) {
-#pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      const int tt = t + 4 * s;
-      if (tt < t1) {
-        compute(buf[s]);
-        if (tt + 4 * PF < t1) load(buf[s], tt + 4 * PF);
-      }
-    }
-  }
-  // the four k-partials of the workgroup meet in LDS; lane holds C[token f*16 + fr][columns fc*4 .. +3 of fragment i's 16 weight rows]
-  float* red = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < NF; ++i)
-#pragma unroll
-    for (int f = 0; f < MF; ++f) *(f32x4_t*)(red + ((((wave * NF + i) * MF + f) * 64 + lane) << 2)) = acc[i][f];
-  __syncthreads();
-  auto total = [&](int i, int f) {
-    f32x4_t v = *(const f32x4_t*)(red + ((((0 * NF + i) * MF + f) * 64 + lane) << 2));
-#pragma unroll
-    for (int w2 = 1; w2 < 4; ++w2) v += *(const f32x4_t*)(red + ((((w2 * NF + i) * MF + f) * 64 + lane) << 2));
-    return v;
-  };
-  if constexpr (MODE == 2) {
-    // fragments 0 .. NF/2-1 = gate rows, NF/2 .. NF-1 = the up rows of the same output columns; wave w < NF/2 finishes pair w
-    if (wave >= NF / 2) return;
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-      const int m = f * 16 + fr;
-      if (m >= p.M) continue;
-      const f32x4_t g = total(wave, f), u = total(NF / 2 + wave, f);
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gt = bf2f(f2bf(g[e])), up = bf2f(f2bf(u[e]));
-        o[e] = gt / (1.0f + __expf(-gt)) * up;
-      }
-      uint2 stv;
-      stv.x = pack_bf2(o[0], o[1]);
-      stv.y = pack_bf2(o[2], o[3]);
-      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + (bt / GPB) * 64 + (bt % GPB) * (ROWS / 2) + wave * 16 + fc * 4) = stv;
-    }
-    return;
-  }
-  for (int i = wave; i < NF; i += 4) {
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-      const int m = f * 16 + fr;
-      if (m >= p.M) continue;
-      const f32x4_t v = total(i, f);
-      const int n = n0 + i * 16 + fc * 4;
-      if constexpr (MODE == 1) {
-        *(float4*)((float*)p.C + ((size_t)split * p.M + m) * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 stv;
-        stv.x = pack_bf2(v[0], v[1]);
-        stv.y = pack_bf2(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = stv;
-      }
-    }
-  }
-}
-
 
 
 // [TK][128] bf16 tiles (256-byte rows) with the 16-byte-chunk swizzle chunk ^= (row & 7) << 1, which is
@@ -2061,7 +1918,8 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(GemmTNGroup G, int 
 }  // namespace
 
 static bool g_skinny8 = true;       // M <= 16 decode GEMMs: whole-cache-line form of the streaming kernel
-static int g_dec64_variant = getenv("OPADPO_DEC64_V") ? atoi(getenv("OPADPO_DEC64_V")) : 0;      // 0 auto, 1 LDS-ring kernel everywhere, 2 register-streaming kernel everywhere; use_tr bits 5-6
+static int g_dec64x_nw = 0;
+static int g_dec64_variant = getenv("OPADPO_DEC64_V") ? atoi(getenv("OPADPO_DEC64_V")) : 0;      // 0 / 3 the whole-line streaming kernel (dec64x), 1 the LDS-ring kernel; use_tr bits 5-6
 static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 8-wave 256x256 kernel (p8); 31: 4-wave 256x256 kernel (w4) forced; 15: M <= 64 streaming
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
@@ -2072,6 +1930,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
+  g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
 bool opadpo_flag_tr() { return g_use_tr; }
 
@@ -2326,6 +2185,217 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
 // decode GEMM for up to 64 tokens: C = A[M,K] . B[N,K]^T, no bias / residual / LoRA tail (a merged or adapter-free rollout).
 // mode 0: bf16 C[M,N]; 1: fp32, `splits` K-slices -> C[splits][M,N] partial tiles (the consumer adds them: launch_rmsnorm_sum_fwd);
 // 2: SwiGLU pair -> bf16 C[M, N/2].  splits <= 0: chosen so that about two workgroups per CU exist.
+// ---------------------------------------------------------------------------------------------------
+// gemm_nt "dec64x" kernel (round 4, second session): the decode GEMM for 9..64 tokens, rebuilt around what a weight STREAM wants
+// (tools/micro/wstream.hip, profiles/r04_decode_stream.txt).  Measured first, on the q|k|v weight (100 MB): a pure read runs at 5.3-5.4 TB/s
+// when every load instruction covers whole 128-byte lines (8 rows x 128 B), every wave walks its OWN 16 rows along K with 8+ loads in
+// flight and nothing synchronises the waves; at 4.3 TB/s with 16 rows x 64 B per instruction (the register-streaming kernel of the first
+// session); at 2.5-4.4 TB/s through a barrier per k-tile (the ring kernel above with its activation half and its MFMAs switched off,
+// OPADPO_DEC64_DIAG=5; the barrier alone costs 11-29 %).  Here:
+//   * a workgroup = NW weight waves x 16 rows (48 / 64 / 128 rows; MODE 2: half gate, half up rows) x one K range (gridDim.y slices, as
+//     the ring kernel) + TWO loader waves;
+//   * WEIGHTS go global -> registers, two 1-KiB loads per 64-deep k-tile and wave (rows 0-7 and 8-15 of the wave x 128 B, non-temporal), four
+//     k-tiles (8 loads) in flight per wave, no LDS.  A load covers 8 rows x 8 chunks of 16 B, an MFMA operand wants 16 rows x 4 chunks:
+//     lane l fetches row l & 7, chunk (l >> 4) + 4 * bit3(l) in the first load and the other four chunks in the second, so that
+//     A(k 0..31) = bit3 ? second : first is a per-lane select and A(k 32..63) the complementary select rotated by 8 lanes (DPP row_ror:8) -
+//     12 VALU per 2 x MF MFMAs;
+//   * ACTIVATIONS (<= 64 x K, L2-resident) are shared by the weight waves through LDS in 256-deep chunks: two 32-KiB stages (64 token rows x
+//     512 B, 16-byte chunks XOR-ed with token & 15: conflict-free ds_read_b128), filled by LDS-DMA one chunk ahead by the loader waves, ONE
+//     barrier per chunk = per 4 k-tiles.  The loaders own that stream because vmcnt counts in order: a weight wave waiting for its own pieces
+//     of the next chunk would wait for every older weight load too.
+// What bounds it (diagnostic builds, OPADPO_DEC64X_DIAG): NOT the MFMAs / fragment reads (off: +-0), not the barriers (off: 0 ... -13 %), not the
+// weight loads' lead (16 instead of 8 in flight: +-0) and not where the activations come from (always the same 32 KiB: +-0) - the ACTIVATION
+// PIECES themselves: without them q|k|v runs in 20.3 us = 4.97 TB/s (the pure-stream figure), with them in 29.8 us, linear in the token
+// count.  A CU's vector-memory pipeline moves ~35 GB/s whatever the source (the guide's ~10-13 B/clk/CU), weights + activation pieces alike:
+// time = bytes per CU.  Hence the rows per workgroup are chosen by shape (launch_gemm_nt_dec64): 48 rows where that makes 256 workgroups
+// (q|k|v: one per CU instead of 192 on three quarters of the chip), 128 rows (half the activation bytes per weight byte) where the grid still
+// covers the chip (gate|up, the K-split o / down projections, lm_head).  At 64 tokens: q|k|v 36.3 -> 25.8 us, gate|up 53.9 -> 45.3, down
+// 23.4 -> 22.1, o 10.6 -> 10.4, lm_head 62.6 -> 57.9; decode step at B = 64 8.63 -> 8.01 ms, B = 32 6.34 -> 5.70, B = 16 5.15 -> 4.84.
+// MODEs, K-split and the partial-sum protocol are the ring kernel's (0: bf16 C; 1: fp32 C[split][M][N]; 2: SwiGLU pairs).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr int X_KT = 4;                                  // k-tiles (64 deep) per activation chunk
+constexpr int X_STAGE = 64 * X_KT * D_BK * 2;            // 32 KiB
+// OPADPO_DEC64X_DIAG (compile-time, diagnostics only - results WRONG): 1 loaders issue nothing, 2 no fragment reads / MFMAs (weights XOR-ed
+// into the accumulators), 4 no barriers in the K loop
+#ifndef OPADPO_DEC64X_DIAG
+#define OPADPO_DEC64X_DIAG 0
+#endif
+#ifndef OPADPO_DEC64X_WAUX
+#define OPADPO_DEC64X_WAUX 2      // cache policy of the weight loads (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
+#ifndef OPADPO_DEC64X_XAUX
+#define OPADPO_DEC64X_XAUX 0      // cache policy of the activation pieces
+#endif
+template <int MF, int MODE, int NW>      // NW = weight waves (16 rows each) per workgroup: 3, 4 or 8; two more waves load the activations
+__global__ __launch_bounds__(64 * (NW + 2), NW == 8 ? 1 : 2) void gemm_nt_dec64x_kernel(GemmNTArgs p) {
+  static_assert(NW == 3 || NW == 4 || NW == 8, "48, 64 or 128 weight rows per workgroup");
+  static_assert(MODE != 2 || NW != 3, "SwiGLU pairs: 32 + 32 or 64 + 64 rows");
+  constexpr int XDG = OPADPO_DEC64X_DIAG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 activation stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bt = blockIdx.x, split = blockIdx.y, splits = gridDim.y;
+  const int nt = p.K1 / D_BK;
+  const int per = (nt + splits - 1) / splits;
+  const int t0 = split * per, t1 = min(nt, t0 + per);
+  const int nk = max(t1 - t0, 0), nc = (nk + X_KT - 1) / X_KT;
+  // weight rows of this workgroup: 16 * NW consecutive rows, or (MODE 2: rows per 128 = [64 gate | 64 up]) HALF gate rows + the HALF up rows 64 further
+  constexpr int ROWS = 16 * NW, HALF = ROWS / 2;
+  const int n0 = MODE == 2 ? (bt * HALF / 64) * 128 + (bt * HALF) % 64 : bt * ROWS;
+  auto wrow = [&](int r) { return MODE == 2 ? (r < HALF ? n0 + r : n0 + 64 + (r - HALF)) : n0 + r; };
+  auto uni = [](const void* q) -> void* {
+    const unsigned long long v = (unsigned long long)q;
+    return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(uni(p.B1), 0, (int)(((unsigned)(p.N - 1) * (unsigned)p.ldb1 + (unsigned)p.K1) * 2u), 0x00020000);
+  // the last activation chunk of a K range may reach past the end of the rows: the descriptor ends with the last row, the overshoot reads zeros
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(uni(p.A1), 0, (int)(((unsigned)(p.M - 1) * (unsigned)p.lda1 + (unsigned)p.K1) * 2u), 0x00020000);
+  const int fr = lane & 15, fc = lane >> 4, hi = (lane >> 3) & 1;
+  const unsigned voffWa = (unsigned)wrow(wave * 16 + (lane & 7)) * (unsigned)p.ldb1 * 2u + (unsigned)(fc + 4 * hi) * 16u;
+  const unsigned voffWb = (unsigned)wrow(wave * 16 + 8 + (lane & 7)) * (unsigned)p.ldb1 * 2u + (unsigned)(fc + 4 * (hi ^ 1)) * 16u;
+  // activation pieces: 1 KiB = 2 token rows x 512 B; the 8 * MF pieces of a chunk are dealt 4 * MF to each of the two LOADER waves (the last two waves).
+  // The loaders own the activation stream because vmcnt counts in order: a weight-streaming wave that also waited for its activation pieces
+  // of chunk c+1 would wait for every OLDER weight load as well, i.e. would never have more than one chunk of weights in flight across a
+  // chunk boundary (measured: 8 or 16 weight loads in flight per wave made no difference, 28 us on q|k|v either way).
+  constexpr int XP = 4 * MF;
+  if (wave >= NW) {
+    const int lw = wave - NW;
+    unsigned voffX[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int row = (lw * XP + i) * 2 + (lane >> 5);
+      voffX[i] = (unsigned)min(row, p.M - 1) * (unsigned)p.lda1 * 2u + (unsigned)(((lane & 31) ^ (row & 15)) * 16);
+    }
+    for (int c = 0; c < nc; ++c) {
+      // stage c & 1 held chunk c-2: every weight wave left it before it arrived at the barrier that ended chunk c-2 .. started chunk c-1
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (with this call in its view of the body the HOST pass silently drops the kernel's launch stub - found by bisection; the device pass is the only one that needs it)
+        if (!(XDG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, smem + (c & 1) * X_STAGE + (lw * XP + i) * 1024), 16, voffX[i], ((XDG & 8) ? 0 : (t0 + c * X_KT)) * (D_BK * 2), 0, OPADPO_DEC64X_XAUX);
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(XDG & 4)) __syncthreads();                    // barrier c: chunk c is in LDS for everyone
+    }
+    if constexpr (MODE == 2) { __syncthreads(); __syncthreads(); }      // the epilogue's two barriers
+    return;
+  }
+  // weight slots: the four k-tiles of ONE chunk in flight per wave (8 loads = 8 KiB; sixteen measured the same).  What bounds a wave is
+  // its own dependent chain per k-tile - wait for the weights, 12 VALU, fragment reads, 2 x MF MFMAs - so the activation fragments of
+  // k-tile j+1 are requested before the MFMAs of k-tile j (two register images).
+  u32x4_t wa[X_KT], wb[X_KT];
+  auto load_w = [&](int slot, int t) {
+    // past the K range: an offset beyond the descriptor's end - the load returns zeros without touching memory, and the load COUNT of a
+    // chunk stays static (the compiler's counted vmcnt waits survive)
+    const bool in = t < t1;
+    const int k2 = t * (D_BK * 2);
+    wa[slot] = __builtin_amdgcn_raw_buffer_load_b128(rW, in ? voffWa : 0xfffffff0u, in ? k2 : 0, OPADPO_DEC64X_WAUX);       // aux 2 = nt: streamed once
+    wb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rW, in ? voffWb : 0xfffffff0u, in ? k2 : 0, OPADPO_DEC64X_WAUX);
+  };
+  f32x4_t acc[MF];
+#pragma unroll
+  for (int f = 0; f < MF; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t xr[2][MF][2];
+  auto xread = [&](int buf, int kt, const char* xs) {     // activation fragments of k-tile kt of the chunk at xs
+    if (XDG & 2) return;
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+      const char* xrow = xs + (f * 16 + fr) * (X_KT * D_BK * 2);
+      xr[buf][f][0] = *(const bf16x8_t*)(xrow + (((kt * 8 + fc) ^ fr) << 4));
+      xr[buf][f][1] = *(const bf16x8_t*)(xrow + (((kt * 8 + 4 + fc) ^ fr) << 4));
+    }
+  };
+  auto mma = [&](int slot, int buf) {
+    if (XDG & 2) { acc[0][0] += __uint_as_float((wa[slot][0] ^ wb[slot][1] ^ wa[slot][2] ^ wb[slot][3] ^ wb[slot][0] ^ wa[slot][1] ^ wb[slot][2] ^ wa[slot][3]) & 0x3f800000u); return; }
+    u32x4_t a1, tt, a2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a1[e] = hi ? wb[slot][e] : wa[slot][e];
+      tt[e] = hi ? wa[slot][e] : wb[slot][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a2[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)tt[e], 0x128, 0xf, 0xf, true);      // row_ror:8
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a1, xr[buf][f][0], acc[f], 0, 0, 0);
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&a2, xr[buf][f][1], acc[f], 0, 0, 0);
+  };
+  if (nc > 0) {
+#pragma unroll
+    for (int j = 0; j < X_KT; ++j) load_w(j, t0 + j);
+    if (!(XDG & 4)) __syncthreads();                      // barrier 0: chunk 0 of the activations has landed (loader waves)
+    int c = 0;
+    for (; c + 1 < nc; ++c) {                             // a full chunk with a successor: static issue pattern, counted waits
+      const char* xs = smem + (c & 1) * X_STAGE;
+      xread(0, 0, xs);
+#pragma unroll
+      for (int j = 0; j < X_KT; ++j) {
+        if (j + 1 < X_KT) xread((j + 1) & 1, j + 1, xs);
+        mma(j, j & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(j, t0 + (c + 1) * X_KT + j);               // the same slot, one chunk on
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(XDG & 4)) __syncthreads();                    // barrier c+1: chunk c+1 is in (loaders); everyone is done reading chunk c
+    }
+    const int rem = nk - c * X_KT;                        // 1..4 k-tiles in the last chunk, nothing left to issue
+    const char* xs = smem + (c & 1) * X_STAGE;
+    xread(0, 0, xs);
+#pragma unroll
+    for (int j = 0; j < X_KT; ++j)
+      if (j < rem) {
+        if (j + 1 < rem) xread((j + 1) & 1, j + 1, xs);
+        mma(j, j & 1);
+      }
+  }
+  // lane holds C[token f*16 + fr][4 consecutive columns fc*4 .. +3 of the wave's 16 weight rows]
+  if constexpr (MODE == 2) {
+    __syncthreads();                                           // the stages are dead: reuse them for the gate / up exchange
+    float* ex = (float*)smem;                                  // [NW/2 up waves][MF][64 lanes][4]
+    if (wave >= NW / 2) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f) *(f32x4_t*)(ex + (((wave - NW / 2) * MF + f) * 64 + lane) * 4) = acc[f];
+    }
+    __syncthreads();
+    if (wave < NW / 2) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f) {
+        const int m = f * 16 + fr;
+        if (m >= p.M) continue;
+        const f32x4_t u = *(const f32x4_t*)(ex + ((wave * MF + f) * 64 + lane) * 4);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gt = bf2f(f2bf(acc[f][e])), up = bf2f(f2bf(u[e]));
+          o[e] = gt / (1.0f + __expf(-gt)) * up;
+        }
+        uint2 stv;
+        stv.x = pack_bf2(o[0], o[1]);
+        stv.y = pack_bf2(o[2], o[3]);
+        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + bt * HALF + wave * 16 + fc * 4) = stv;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int f = 0; f < MF; ++f) {
+    const int m = f * 16 + fr;
+    if (m >= p.M) continue;
+    const int n = n0 + wave * 16 + fc * 4;
+    if constexpr (MODE == 1) {
+      *(float4*)((float*)p.C + ((size_t)split * p.M + m) * p.ldc + n) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+    } else {
+      uint2 stv;
+      stv.x = pack_bf2(acc[f][0], acc[f][1]);
+      stv.y = pack_bf2(acc[f][2], acc[f][3]);
+      *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = stv;
+    }
+  }
+}
+}  // namespace
+
 int gemm_nt_dec64_splits(int N, int K, int splits);
 hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipStream_t st) {
   if (a.M <= 0) return hipSuccess;
@@ -2335,22 +2405,42 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
   if (mode != 1) splits = 1;
   splits = gemm_nt_dec64_splits(a.N, a.K1, splits);
   const int mf = (a.M + 15) / 16;
-  // register-streaming kernel (dec64r) for the bf16-output projection that does not fill the chip with 64-row workgroups (q|k|v: 192): measured at
-  // 64 / 48 / 32 tokens 36.6 / 33.2 / 29.9 us against 45.2 / 45.0 / 44.3 for the ring kernel's 32-row form; every other decode GEMM stays on the
-  // ring kernel (gate|up 53 vs 70 us, down 23 vs 30, lm_head 63 vs 76: dec64r is bound by its activation reads from L2).  g_dec64_variant
-  // 1 / 2 force the ring / the register kernel (experiments).
-  if (g_dec64_variant == 2 || (g_dec64_variant == 0 && mode == 0 && tiles <= 256)) {
-#define DR_GO(MF_, MD_)                                                                                                               \
+  // g_dec64_variant 1 keeps the LDS-ring kernel below (the kernel of rounds 2-4, the bit-for-bit reference of the tests); the register-streaming
+  // dec64r kernel of round 4 (q|k|v only, +3 %) is gone: dec64x beats it by 29 % there (profiles/r04_decode_stream.txt).
+  if (g_dec64_variant == 3 || g_dec64_variant == 0) {      // dec64x (the default): weights global -> registers in whole lines, activations through LDS in 256-deep chunks
+    // Rows per workgroup (16 x NW) by shape.  What bounds these launches is the vector-memory pipeline of a CU (weights + activation pieces,
+    // ~35 GB/s per CU whatever the source: profiles/r04_decode_stream.txt), so the estimate is bytes per CU = rounds of workgroups over the
+    // 256 CUs x (weight rows + token rows) of a workgroup: q|k|v (12288 rows) -> 48-row workgroups (256 of them), gate|up -> 128 rows
+    // (172), the K-split projections and the head -> 128 rows.
+    static const int nw_env = getenv("OPADPO_DEC64X_NW") ? atoi(getenv("OPADPO_DEC64X_NW")) : 0;      // diagnostics
+    const int nw_force = g_dec64x_nw == 1 ? 3 : g_dec64x_nw == 2 ? 4 : g_dec64x_nw == 3 ? 8 : nw_env;
+    int nw = 4;
+    {
+      long best = -1;
+      const int cand[3] = {8, 4, 3};
+      for (int ci = 0; ci < 3; ++ci) {
+        const int c = cand[ci];
+        if (a.N % (16 * c) || (mode == 2 && c == 3)) continue;
+        const long wgs = (long)(a.N / (16 * c)) * splits;
+        const long cost = ((wgs + 255) / 256) * (16 * c + 16 * mf);
+        if (best < 0 || cost < best) { best = cost; nw = c; }
+      }
+      if (nw_force == 3 || nw_force == 4 || nw_force == 8) { if (a.N % (16 * nw_force) == 0 && !(mode == 2 && nw_force == 3)) nw = nw_force; }
+    }
+#define DX_GO(MF_, MD_, NW_)                                                                                                          \
   do {                                                                                                                                \
     static bool at_ = false;                                                                                                          \
-    constexpr int lds_ = 4 * MF_ * 4096;                                                                                              \
-    if (!at_) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64r_kernel<MF_, MD_, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); at_ = true; } \
-    hipLaunchKernelGGL((gemm_nt_dec64r_kernel<MF_, MD_, 4, 2>), dim3(a.N / 64, splits), dim3(256), lds_, st, a);                      \
+    if (!at_) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64x_kernel<MF_, MD_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X_STAGE); at_ = true; } \
+    hipLaunchKernelGGL((gemm_nt_dec64x_kernel<MF_, MD_, NW_>), dim3(a.N / (16 * NW_), splits), dim3(64 * (NW_ + 2)), 2 * X_STAGE, st, a); \
   } while (0)
-#define DR_MODE(MD_) do { if (mf == 1) DR_GO(1, MD_); else if (mf == 2) DR_GO(2, MD_); else if (mf == 3) DR_GO(3, MD_); else DR_GO(4, MD_); } while (0)
-    if (mode == 0) DR_MODE(0); else if (mode == 1) DR_MODE(1); else DR_MODE(2);
-#undef DR_MODE
-#undef DR_GO
+#define DX_MF(MD_, NW_) do { if (mf == 1) DX_GO(1, MD_, NW_); else if (mf == 2) DX_GO(2, MD_, NW_); else if (mf == 3) DX_GO(3, MD_, NW_); else DX_GO(4, MD_, NW_); } while (0)
+#define DX_MODE(MD_) do { if (nw == 8) DX_MF(MD_, 8); else if (nw == 3) DX_MF(MD_, 3); else DX_MF(MD_, 4); } while (0)
+    if (mode == 0) DX_MODE(0);
+    else if (mode == 1) DX_MODE(1);
+    else { if (nw == 8) DX_MF(2, 8); else DX_MF(2, 4); }
+#undef DX_MODE
+#undef DX_MF
+#undef DX_GO
     return hipGetLastError();
   }
   static const int kw2_max = getenv("OPADPO_DEC64_KW2") ? atoi(getenv("OPADPO_DEC64_KW2")) : 256;      // diagnostics

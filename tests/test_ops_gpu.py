@@ -1139,12 +1139,13 @@ def test_gemm_nt_rope_pos(L, lora):
 
 @pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
 @pytest.mark.parametrize("shape", [(4096, 4096), (4096, 11008), (12288, 4096), (1024, 512)])
-@pytest.mark.parametrize("kernel", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [0, 1, 3 | (1 << 2), 3 | (2 << 2), 3 | (3 << 2)])
 def test_gemm_nt_decode_modes(L, M, shape, kernel):
     """opadpo_gemm_nt_decode: bf16 output, fp32 K-split partial tiles (their sum in slice order) and the SwiGLU-pair epilogue, against
-    torch fp32; rows >= M untouched.  kernel 1 = the LDS-ring kernel (64 weight rows x <= 64 tokens x one K-slice per workgroup) for every
-    mode, 2 = the register-streaming kernel (gemm_nt_dec64r_kernel: every wave its own weight stream, K dealt to the waves by k-tile) for
-    every mode, 0 = the library's choice (the register kernel for bf16 output up to 256 column tiles, e.g. q|k|v)."""
+    torch fp32; rows >= M untouched.  kernel 0 = the library's choice = gemm_nt_dec64x_kernel (weights global -> registers in whole 128-byte
+    lines, activations shared through LDS in 256-deep chunks by two loader waves) with the rows per workgroup chosen by shape; 3 + (1 / 2 / 3)
+    << 2 forces 48 / 64 / 128 weight rows per workgroup where the shape allows; 1 = the LDS-ring kernel of rounds 2-4 (64 weight rows x <= 64
+    tokens x one K-slice per workgroup, a barrier per k-tile)."""
     import ctypes as C
     N, K = shape
     lib = L.load()

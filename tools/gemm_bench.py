@@ -178,18 +178,19 @@ def main():
                                               ("down", 4096, 11008, 1, 0), ("lm_head", 32000, 4096, 1, 1)):
                 copies = max(2, int(6.0e8 // (N * K1 * 2)) + 1)
                 ws = [(torch.randn(N, K1, device=dev) * 0.02).to(BF) for _ in range(copies)]
-                a1 = torch.randn(M_, K1, device=dev).to(BF)
+                pad = int(os.environ.get("GB_LDA_PAD", 0))      # row stride of the activations = K + pad elements (L2 channel spread)
+                a1 = torch.randn(M_, K1 + pad, device=dev).to(BF)[:, :K1]
                 S = lib.opadpo_gemm_nt_decode_splits(N, K1, splits) if mode == 1 else 1
                 out = torch.empty(S * M_ * (N // 2 if mode == 2 else N), dtype=torch.float32 if mode == 1 else BF, device=dev)
                 ref = None
-                for label, v in (("ring", 1), ("r64", 2), ("auto", 0)):
+                for label, v in (("ring", 1), ("x48", 3 | (1 << 2)), ("x64", 3 | (2 << 2)), ("x128", 3 | (3 << 2)), ("auto", 0)):
                     L.set_flags(10, 1 | (v << 5))
                     it = [0]
 
                     def fn():
                         w = ws[it[0] % copies]
                         it[0] += 1
-                        L.call("opadpo_gemm_nt_decode", L.ptr(a1), K1, L.ptr(w), K1, K1, L.ptr(out), N // 2 if mode == 2 else N, mode, M_, N, splits, L.stream())
+                        L.call("opadpo_gemm_nt_decode", L.ptr(a1), a1.stride(0), L.ptr(w), K1, K1, L.ptr(out), N // 2 if mode == 2 else N, mode, M_, N, splits, L.stream())
                     t = timeit(fn, iters=3 * copies, warm=copies)
                     it[0] = 0
                     fn()
