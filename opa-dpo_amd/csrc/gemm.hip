@@ -2480,7 +2480,12 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
 int gemm_nt_dec64_splits(int N, int K, int splits) {
   const int nt = K / D_BK, tiles = N / D_BN;
   if (splits <= 0) {
-    static const int target = getenv("OPADPO_DEC64_BLOCKS") ? atoi(getenv("OPADPO_DEC64_BLOCKS")) : 512;      // diagnostics
+    // workgroup target of the K-split, counted in 64-row tiles: 256 = four K-slices for the 7B o / down projections (the dec64x kernel then
+    // runs them as 64-row workgroups x 4 slices).  Half the slices of round 2's target of 512 are half the partial tiles for the RMSNorm that
+    // adds them: decode step B = 64 8.00 -> 7.90 ms, B = 32 5.65 -> 5.59 (384: 8.03, 128: 8.42; profiles/r04_decode_stream.txt section 6).
+    // The LDS-ring kernel (OPADPO_DEC64_V=1) keeps 512.
+    static const int env_target = getenv("OPADPO_DEC64_BLOCKS") ? atoi(getenv("OPADPO_DEC64_BLOCKS")) : 0;      // diagnostics
+    const int target = env_target > 0 ? env_target : (g_dec64_variant == 1 ? 512 : 256);
     splits = (target + tiles - 1) / tiles;
     if (splits > nt / 4) splits = nt / 4 > 0 ? nt / 4 : 1;
   }
