@@ -89,9 +89,10 @@ int opadpo_gemm_nt_rope_pos(const uint16_t* A1, int lda1, const uint16_t* B1, in
                             uint16_t* C, int ldc, int M, int N, const int32_t* row_pos, float theta, int rope_cols, void* stream);
 
 /* Decode projection for up to 64 tokens (rollout at 9..64 sequences per device, online_generator.py:292-309): C = A[M,K] . B[N,K]^T,
- * no bias / residual / LoRA tail (adapter-free or merged adapter).  Both operands are streamed through a 4-stage LDS ring by
- * direct-to-LDS DMA, 64 weight rows x 64 tokens x one K-slice per workgroup; the bf16-output projection of at most 256 column tiles
- * (q|k|v) takes the register-streaming kernel instead (every wave its own weight stream, no LDS in the K-loop; round 4).  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
+ * no bias / residual / LoRA tail (adapter-free or merged adapter).  A weight stream: 48 / 64 / 128 weight rows (by shape) x <= 64 tokens x
+ * one K-slice per workgroup, the weights loaded global -> registers in whole 128-byte lines, the activations shared through LDS in
+ * 256-deep chunks by two loader waves (gemm_nt_dec64x_kernel, round 4; opadpo_set_flags use_tr bits 5-6 = 1 selects the LDS-ring kernel
+ * of rounds 2-4).  mode 0: bf16 C[M,N]; mode 1: fp32 partial tiles
  * C[splits][M,N] (ldc = row stride of one slice) - K is split over `splits` workgroups (<= 0: chosen by the library, query it with
  * opadpo_gemm_nt_decode_splits) and the consumer adds the slices (opadpo_rmsnorm_sum_fwd); mode 2: OPADPO_ACT_SWIGLU_PAIR weight
  * layout -> bf16 C[M, N/2] = silu(gate) * up.  M <= 64, N % 128 == 0, K % 64 == 0. */

@@ -154,7 +154,8 @@ def set_flags(use_glds=10, use_tr: bool = True) -> None:
     use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V
     ring (default: register-staged single buffer, 3 blocks per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256
     gemm_tn_w4_kernel, bit 4 = 16-row streaming kernel also for M <= 16 (default: gemm_nt_skinny8_kernel), bits 5-6 = kernel of
-    opadpo_gemm_nt_decode: 0 the library's choice, 1 the LDS-ring kernel everywhere, 2 the register-streaming kernel everywhere."""
+    opadpo_gemm_nt_decode: 0 / 3 the whole-line streaming kernel (gemm_nt_dec64x, the library's choice), 1 the LDS-ring kernel of rounds 2-4;
+    bits 7-8 = weight rows per workgroup of the streaming kernel (0 by shape, 1 / 2 / 3 = 48 / 64 / 128)."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))
 

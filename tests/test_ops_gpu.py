@@ -1184,6 +1184,33 @@ def test_gemm_nt_decode_modes(L, M, shape, kernel):
     L.set_flags(10, True)
 
 
+@pytest.mark.parametrize("shape,mode", [((15360, 5120), 0), ((5120, 13824), 1), ((27648, 5120), 2), ((5120, 5120), 1)])
+def test_gemm_nt_decode_13b_shapes(L, shape, mode):
+    """The decode projections of LLaVA-1.5-13B (hidden 5120, ffn 13824) at 64 and 40 tokens through the library's choice of kernel and rows per
+    workgroup: K ranges that are not whole 256-deep activation chunks per K-slice, 120 / 320-workgroup grids."""
+    N, K = shape
+    lib = L.load()
+    L.set_flags(10, 1)
+    for M in (64, 40):
+        a, w = rnd(M, K, scale=0.5, seed=11), rnd(N, K, scale=0.05, seed=12)
+        want = a.float() @ w.float().t()
+        if mode == 0:
+            ob = torch.empty(M, N, dtype=BF, device=dev())
+            L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(ob), N, 0, M, N, 1, L.stream())
+            assert relerr(ob, want) < 6e-3
+        elif mode == 1:
+            S = lib.opadpo_gemm_nt_decode_splits(N, K, 0)
+            part = torch.full((S, M, N), 3.0, device=dev())
+            L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(part), N, 1, M, N, 0, L.stream())
+            assert relerr(part.sum(0), want) < 1e-5, S
+        else:
+            F = N // 2
+            zb = want.view(M, F // 64, 2, 64).to(BF).float()
+            oa = torch.empty(M, F, dtype=BF, device=dev())
+            L.call("opadpo_gemm_nt_decode", L.ptr(a), K, L.ptr(w), K, K, L.ptr(oa), F, 2, M, N, 1, L.stream())
+            assert relerr(oa, (torch.nn.functional.silu(zb[:, :, 0]) * zb[:, :, 1]).reshape(M, F)) < 2e-2
+
+
 @pytest.mark.parametrize("resid_f32", [True, False])
 def test_rmsnorm_sum_fwd(L, resid_f32):
     rows, H, S = 37, 4096, 4
