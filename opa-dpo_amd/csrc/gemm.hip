@@ -2273,7 +2273,8 @@ __global__ __launch_bounds__(64 * (NW + 2), NW == 8 ? 1 : 2) void gemm_nt_dec64x
 #pragma unroll
       for (int i = 0; i < XP; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (with this call in its view of the body the HOST pass silently drops the kernel's launch stub - found by bisection; the device pass is the only one that needs it)
-        if (!(XDG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, smem + (c & 1) * X_STAGE + (lw * XP + i) * 1024), 16, voffX[i], ((XDG & 8) ? 0 : (t0 + c * X_KT)) * (D_BK * 2), 0, OPADPO_DEC64X_XAUX);
+        // pieces of token rows >= M are not fetched (49..63 tokens, and the second half of a 16-token fragment): their accumulator columns are never stored
+        if (!(XDG & 1) && (lw * XP + i) * 2 < p.M) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, smem + (c & 1) * X_STAGE + (lw * XP + i) * 1024), 16, voffX[i], ((XDG & 8) ? 0 : (t0 + c * X_KT)) * (D_BK * 2), 0, OPADPO_DEC64X_XAUX);
 #endif
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
