@@ -2423,7 +2423,8 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
         const int c = cand[ci];
         if (a.N % (16 * c) || (mode == 2 && c == 3)) continue;
         const long wgs = (long)(a.N / (16 * c)) * splits;
-        const long cost = ((wgs + 255) / 256) * (16 * c + 16 * mf);
+        long cost = ((wgs + 255) / 256) * (16 * c + 16 * mf);
+        if (c == 4 && wgs > 448 && wgs <= 512) cost = cost * 3 / 4;      // two full rounds of 64-row workgroups, two per CU: measured ahead of one round of 128-row ones (lm_head, 500: 46.8 vs 52.9 us at 8 tokens, 49.8 vs 53.6 at 32, 57.5 vs 57.9 at 64)
         if (best < 0 || cost < best) { best = cost; nw = c; }
       }
       if (nw_force == 3 || nw_force == 4 || nw_force == 8) { if (a.N % (16 * nw_force) == 0 && !(mode == 2 && nw_force == 3)) nw = nw_force; }

@@ -180,11 +180,11 @@ def main():
                 ws = [(torch.randn(N, K1, device=dev) * 0.02).to(BF) for _ in range(copies)]
                 pad = int(os.environ.get("GB_LDA_PAD", 0))      # row stride of the activations = K + pad elements (L2 channel spread)
                 a1 = torch.randn(M_, K1 + pad, device=dev).to(BF)[:, :K1]
-                S = lib.opadpo_gemm_nt_decode_splits(N, K1, splits) if mode == 1 else 1
-                out = torch.empty(S * M_ * (N // 2 if mode == 2 else N), dtype=torch.float32 if mode == 1 else BF, device=dev)
                 ref = None
                 for label, v in (("ring", 1), ("x48", 3 | (1 << 2)), ("x64", 3 | (2 << 2)), ("x128", 3 | (3 << 2)), ("auto", 0)):
                     L.set_flags(10, 1 | (v << 5))
+                    S = lib.opadpo_gemm_nt_decode_splits(N, K1, splits) if mode == 1 else 1      # the K-split target depends on the kernel in use
+                    out = torch.empty(S * M_ * (N // 2 if mode == 2 else N), dtype=torch.float32 if mode == 1 else BF, device=dev)
                     it = [0]
 
                     def fn():
