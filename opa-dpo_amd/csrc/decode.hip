@@ -395,7 +395,7 @@ __device__ __forceinline__ void pick_digit(const uint64_t* hist, uint64_t base, 
 
 __global__ __launch_bounds__(SAMP_T) void sample_kernel_fast(const float* logits, int ldl, int V, float inv_temp, int top_k, float top_p,
                                                              uint64_t seed, uint64_t step_arg, const int32_t* step_ptr, uint8_t* finished,
-                                                             int pad_id, int eos_id, int32_t* out, int32_t* history) {
+                                                             int pad_id, int eos_id, int32_t* out, int32_t* history, int compact) {
   extern __shared__ __attribute__((aligned(16))) float zs[];     // [V] scaled logits
   const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : step_arg;
   __shared__ uint64_t hist[256];
@@ -471,6 +471,75 @@ __global__ __launch_bounds__(SAMP_T) void sample_kernel_fast(const float* logits
       __syncthreads();
     }
     thr = prefix;
+    // COMPACT tail (round 4): after the top-k threshold the kept set is a few dozen tokens, yet the top-p descent, the mass sums and the draw
+    // swept the whole vocabulary seven more times.  The kept tokens are gathered into an LDS list (one more sweep); when they are at most 64,
+    // wave 0 finishes alone, one token per lane, with the SAME integer arithmetic: the masses are exact fixed-point integers, so their sums do not
+    // depend on the order; the top-p threshold "largest t with mass(thr <= key < t) <= budget" is the smallest kept key whose mass of keys <= it
+    // exceeds the budget (none: 2^32 - 1); the draw walks the kept tokens in the order (owner thread = index mod 1024, index) of the full-sweep
+    // form.  Same token for every (seed, step, row) as the sweeps (tests/test_ops_gpu.py::test_sampler_compact_tail_is_exact); more than 64 kept
+    // tokens (ties at the threshold) fall through to the sweeps.
+    if (compact) {
+      __shared__ int s_n;
+      __shared__ int s_idx[64];
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      for (int i = tid; i < V; i += SAMP_T)
+        if (fkey(zs[i]) >= thr) {
+          const int pos = atomicAdd(&s_n, 1);
+          if (pos < 64) s_idx[pos] = i;
+        }
+      __syncthreads();
+      const int n = s_n;
+      if (n <= 64) {
+        if (wave != 0) return;
+        const bool valid = lane < n;
+        const int idx = valid ? s_idx[lane] : 0x7fffffff;
+        const float x = valid ? zs[idx] : 0.f;
+        const uint32_t key = valid ? fkey(x) : 0u;
+        const uint64_t qm = valid ? qmass(x) : 0ull;
+        uint32_t thr2 = thr;
+        if (top_p < 1.0f) {
+          const uint64_t zk = wave_sum_u64(qm);
+          const uint64_t budget = (uint64_t)((1.0 - (double)top_p) * (double)zk);
+          uint64_t below_incl = 0;                         // mass of the kept keys <= this lane's key
+          for (int j = 0; j < n; ++j) {
+            const uint32_t kj = (uint32_t)__shfl((int)key, j, 64);
+            const uint64_t qj = (uint64_t)__shfl((long long)qm, j, 64);
+            if (kj <= key) below_incl += qj;
+          }
+          uint32_t t2 = (valid && below_incl > budget) ? key : 0xffffffffu;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) t2 = min(t2, (uint32_t)__shfl_xor((int)t2, o, 64));
+          thr2 = max(thr, t2);
+        }
+        const bool kept = valid && key >= thr2;
+        const uint64_t qk = kept ? qm : 0ull;
+        const uint64_t total = wave_sum_u64(qk);
+        const uint32_t ord = ((uint32_t)(idx & (SAMP_T - 1)) << 20) | (uint32_t)(idx >> 10);      // (owner thread, then index): V <= 32768 -> index / 1024 < 32
+        uint64_t before = 0;                               // kept mass ahead of this lane's token in the draw order
+        for (int j = 0; j < n; ++j) {
+          const uint32_t oj = (uint32_t)__shfl((int)ord, j, 64);
+          const uint64_t qj = (uint64_t)__shfl((long long)qk, j, 64);
+          if (oj < ord) before += qj;
+        }
+        const uint64_t r = mix64(mix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (uint64_t)row);
+        const uint64_t r24 = r >> 40;
+        const uint64_t target = (total >> 24) * r24 + (((total & 0xffffffull) * r24) >> 24);
+        if (total == 0) {
+          if (lane == 0) {
+            out[row] = pad_id;
+            if (history) history[step * gridDim.x + row] = pad_id;
+          }
+          return;
+        }
+        if (qk > 0 && before <= target && target < before + qk) {
+          out[row] = idx;
+          if (history) history[step * gridDim.x + row] = idx;
+          if (finished && eos_id >= 0 && idx == eos_id) finished[row] = 1;
+        }
+        return;
+      }
+    }
   }
   if (top_p < 1.0f) {
     uint64_t zk = 0;
@@ -624,9 +693,11 @@ hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float te
     (void)hipFuncSetAttribute((const void*)sample_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, SAMP_MAXV * 4);
     attr_set = true;
   }
+  const char* ce = getenv("OPADPO_SAMPLE_COMPACT");      // read per launch (one per decode step): 0 keeps the full sweeps (the exactness test flips it)
+  const int compact = ce ? atoi(ce) : 1;
   if (fast)
     hipLaunchKernelGGL(sample_kernel_fast, dim3(rows), dim3(SAMP_T), (size_t)V * 4, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed,
-                       step, step_ptr, finished, pad_id, eos_id, out, history);
+                       step, step_ptr, finished, pad_id, eos_id, out, history, compact);
   else
     hipLaunchKernelGGL(sample_kernel_generic, dim3(rows), dim3(256), 0, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed,
                        step, step_ptr, finished, pad_id, eos_id, out, history);

@@ -929,6 +929,43 @@ def test_sampler_filters_large_vocab(L, V):
         assert float((emp - p).abs().max()) < 0.06
 
 
+def test_sampler_compact_tail_is_exact(L):
+    """The sampler's compact tail (top-p threshold, mass sums and the draw on the <= 64 tokens the top-k threshold keeps, by one wave) draws the SAME
+    token as the full vocabulary sweeps for every (seed, step, row): distinct rows, several temperatures / k / p, coarse logits (ties at the
+    threshold: more than 64 kept tokens fall back to the sweeps), finished rows and the EOS flag."""
+    import os
+    V, rows = 32000, 512
+    g = torch.Generator(device="cpu").manual_seed(11)
+    smooth = (torch.randn(rows, V, generator=g) * 3).to(dev())
+    coarse = (torch.randint(-6, 7, (rows, V), generator=g).float() * 0.5).to(dev())          # 13 distinct values: thousands of ties at any threshold
+    mixed = smooth.clone()
+    mixed[:, :40] = 9.0                                                                     # 40 equal maxima: top-k 30 keeps all 40
+    fin = torch.zeros(rows, dtype=torch.uint8, device=dev())
+    fin[3] = 1
+    prev = os.environ.get("OPADPO_SAMPLE_COMPACT")
+    try:
+        for logits in (smooth, coarse, mixed):
+            for top_k, top_p, temp in ((30, 0.95, 1.0), (30, 0.95, 0.1), (64, 0.5, 1.3), (5, 1.0, 0.7), (1, 0.9, 1.0), (30, 0.01, 1.0), (200, 0.9, 1.0)):
+                res = []
+                for compact in ("0", "1"):
+                    os.environ["OPADPO_SAMPLE_COMPACT"] = compact
+                    outs = []
+                    for step in range(4):
+                        out = torch.full((rows,), -5, dtype=torch.int32, device=dev())
+                        f2 = fin.clone()
+                        L.call("opadpo_sample", logits.data_ptr(), V, rows, V, temp, top_k, top_p, 4242, step, None, f2.data_ptr(), 0, 17,
+                               out.data_ptr(), None, L.stream())
+                        outs += [out, f2.int()]
+                    res.append(torch.stack(outs))
+                torch.cuda.synchronize()
+                assert torch.equal(res[0], res[1]), (top_k, top_p, temp)
+    finally:
+        if prev is None:
+            os.environ.pop("OPADPO_SAMPLE_COMPACT", None)
+        else:
+            os.environ["OPADPO_SAMPLE_COMPACT"] = prev
+
+
 def test_errors_are_loud(L):
     a, b = rnd(10, 64), rnd(100, 64)   # N not a multiple of 128
     out = torch.empty(10, 100, dtype=BF, device=dev())
