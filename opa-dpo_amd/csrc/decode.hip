@@ -624,10 +624,20 @@ __global__ __launch_bounds__(SAMP_T) void sample_kernel_fast(const float* logits
 }  // namespace
 
 static int attn_decode_splits(int B, int nh, int max_ctx) {
-  if (B * nh >= 256) return 1;
+  static const int force = getenv("OPADPO_ATTN_DEC_SPLITS") ? atoi(getenv("OPADPO_ATTN_DEC_SPLITS")) : 0;      // diagnostics
+  if (force > 0) return std::min(force, std::max(1, max_ctx / 256));
+  // 257..767 (sequence, head) pairs (9..23 sequences at 32 heads): two key ranges per pair, run as 4-wave workgroups (>= 512 of them) - measured
+  // against one 16-wave workgroup per pair: decode step B = 12 4.47 -> 4.27 ms, B = 16 4.58 -> 4.40; from 768 pairs on 4-wave workgroups without a
+  // split (B = 24: 5.34 -> 5.12); up to 256 pairs the 16-wave form stays (B = 8: 3.80 against 4.07 with a split)
+  if (B * nh >= 768) return 1;
+  if (B * nh > 256) return std::min(2, std::max(1, max_ctx / 256));
   int splits = (256 + B * nh - 1) / (B * nh);
   splits = std::min(splits, std::max(1, max_ctx / 256));
   return std::max(1, std::min(splits, 16));
+}
+static bool attn_decode_fat(int B, int nh, int splits) {
+  static const int fat_lim = getenv("OPADPO_ATTN_DEC_FAT") ? atoi(getenv("OPADPO_ATTN_DEC_FAT")) : 512;      // diagnostics: 16-wave workgroups below this many of them
+  return B * nh * splits < fat_lim;
 }
 // the KV cache is read exactly once per decode step: non-temporal loads (round 4; same-box B = 64: 9.24 -> 8.93 ms per step, B = 8 neutral; OPADPO_DEC_NT=0 switches back)
 static int dec_nt() { static const int v = getenv("OPADPO_DEC_NT") ? atoi(getenv("OPADPO_DEC_NT")) : 1; return v; }
@@ -645,7 +655,7 @@ hipError_t launch_attn_decode_fused(const bf16_t* qkv, int ld, const float* cosb
   if (splits > 1 && (!workspace || workspace_bytes < attn_decode_workspace_bytes(B, nh, hd, max_ctx))) splits = 1;
   float* part = (float*)workspace;
   const float sl2 = scale * 1.4426950408889634f;
-  const bool fat = B * nh * splits < 1024;
+  const bool fat = attn_decode_fat(B, nh, splits);
   const dim3 gr(nh, B, splits);
 #define ADF(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_, true>), gr, dim3(NW_ * 64), 0, st, qkv, ld, kc, vc, o, key_mask, nh, 0, pos_ptr, max_ctx, sl2, part, cosb, sinb, kc, vc, dec_nt())
   if (hd == 128) { if (fat) ADF(128, 16); else ADF(128, 4); }
@@ -664,7 +674,7 @@ hipError_t launch_attn_decode(const bf16_t* q, const bf16_t* kc, const bf16_t* v
   if (splits > 1 && (!workspace || workspace_bytes < attn_decode_workspace_bytes(B, nh, hd, max_ctx))) splits = 1;
   float* part = (float*)workspace;
   const float sl2 = scale * 1.4426950408889634f;
-  const bool fat = B * nh * splits < 1024;       // few blocks: 16 waves each
+  const bool fat = attn_decode_fat(B, nh, splits);       // few blocks: 16 waves each
   const dim3 gr(nh, B, splits);
 #define AD(HD_, NW_) hipLaunchKernelGGL((attn_decode_kernel<HD_, NW_>), gr, dim3(NW_ * 64), 0, st, q, ldq, kc, vc, o, key_mask, nh, ctx, ctx_ptr, max_ctx, sl2, part, nullptr, nullptr, nullptr, nullptr, dec_nt())
   if (hd == 128) { if (fat) AD(128, 16); else AD(128, 4); }
