@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 // 64 MFMAs (16x16x32, 1024+ cycles) per iteration.  EVERY: one DMA per EVERY MFMAs; STAG: wave w issues STAG*w MFMAs later (mod EVERY);
 // SALU: scalar filler instructions per MFMA gap (0..3); READS: one ds_read_b128 per READS MFMAs (0 = none)
-template <int EVERY, int STAG, int SALU, int READS, int W, int AHEAD>
+template <int EVERY, int STAG, int SALU, int READS, int W, int AHEAD, int ADDR = 0>
 __device__ __forceinline__ void body(const char* src, char* smem, int wave, int lane, int iters, f32x4_t (&acc)[16], bf16x8_t& sink, const i32x4_t rq, unsigned& sacc) {
   bf16x8_t a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(lane * 0.01f); b[i] = (__bf16)(i * 0.5f); }
@@ -24,6 +24,10 @@ __device__ __forceinline__ void body(const char* src, char* smem, int wave, int 
 #pragma unroll
   for (int q = 0; q < 16; ++q) pc[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)(ldsb + q * 1024));
   constexpr int OFF = EVERY ? (STAG * W) % EVERY : 0;
+  // ADDR 3: as 1 with the 8-row group drawn pseudo-randomly from a 1-GiB buffer (every piece misses the L2s and the Infinity Cache);
+  // ADDR 0: a piece = 1 KiB contiguous; 1: 8 rows x 128 B, rows 8 KiB apart (what a GEMM operand tile is); 2: the same with the 16-byte chunks of a row
+  // XOR-permuted by the row (the swizzle gemm_nt_w4 applies on the source side)
+  const unsigned vo = ADDR == 0 ? lane * 16u : ((unsigned)((ADDR == 3 ? 0 : wave * 128) + (lane >> 3)) * 8192u + (unsigned)(((lane & 7) ^ (ADDR == 2 ? (lane >> 3) & 7 : 0)) * 16));
   for (int it = 0; it < iters; ++it) {
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((it * 16) & 1023) * 1024);
 #pragma unroll
@@ -40,7 +44,7 @@ __device__ __forceinline__ void body(const char* src, char* smem, int wave, int 
         if (AH < EVERY && (m + 1 + AH + EVERY - OFF) % EVERY == 0) m0w((m + 1 + AH + EVERY - OFF) / EVERY - 1);
         if ((m + 1 + EVERY - OFF) % EVERY == 0) {
           const int q = ((m + 1 + EVERY - OFF) / EVERY - 1) & 15;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(lane * 16), "s"(rq), "s"(soff + q * 1024) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(vo), "s"(rq), "s"(ADDR == 0 ? soff + q * 1024 : ADDR == 3 ? (unsigned)((((unsigned)(it * 1024 + blockIdx.x * 4 + wave) * 16u + q) * 2654435761u) % 130000u) * 8192u + (unsigned)((it & 63) * 128) : (unsigned)(q * 8 * 8192 + (it & 63) * 128)) : "memory");
           if (AH >= EVERY) m0w(q + 1);
         }
       }
@@ -55,7 +59,7 @@ __device__ __forceinline__ void body(const char* src, char* smem, int wave, int 
   }
 }
 
-template <int EVERY, int STAG, int SALU, int READS, int AHEAD>
+template <int EVERY, int STAG, int SALU, int READS, int AHEAD, int ADDR = 0>
 __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -68,10 +72,10 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
   unsigned sacc = 0;
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-  if (STAG == 0 || wave == 0) body<EVERY, STAG, SALU, READS, 0, AHEAD>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
-  else if (wave == 1) body<EVERY, STAG, SALU, READS, 1, AHEAD>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
-  else if (wave == 2) body<EVERY, STAG, SALU, READS, 2, AHEAD>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
-  else body<EVERY, STAG, SALU, READS, 3, AHEAD>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
+  if (STAG == 0 || wave == 0) body<EVERY, STAG, SALU, READS, 0, AHEAD, ADDR>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
+  else if (wave == 1) body<EVERY, STAG, SALU, READS, 1, AHEAD, ADDR>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
+  else if (wave == 2) body<EVERY, STAG, SALU, READS, 2, AHEAD, ADDR>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
+  else body<EVERY, STAG, SALU, READS, 3, AHEAD, ADDR>(src, smem, wave, lane, iters, acc, sink, rq, sacc);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
   float s = (float)sink[0] + (float)sacc;
@@ -79,11 +83,11 @@ __global__ __launch_bounds__(256) void k(const char* src, unsigned long long* ou
   if (lane == 0) { out[(blockIdx.x * 4 + wave) * 2] = t1 - t0; out[(blockIdx.x * 4 + wave) * 2 + 1] = (r1 - r0) + ((unsigned long long)(s == 12345.f) << 60); }
 }
 
-template <int EVERY, int STAG, int SALU, int READS, int AHEAD = 1>
+template <int EVERY, int STAG, int SALU, int READS, int AHEAD = 1, int ADDR = 0>
 void run(const char* name, const char* src, unsigned long long* out, int threads) {
   const int iters = 20000, blocks = 256, nw = threads / 64;
-  hipFuncSetAttribute((const void*)k<EVERY, STAG, SALU, READS, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<EVERY, STAG, SALU, READS, AHEAD>), dim3(blocks), dim3(threads), 65536, 0, src, out, iters);
+  hipFuncSetAttribute((const void*)k<EVERY, STAG, SALU, READS, AHEAD, ADDR>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<EVERY, STAG, SALU, READS, AHEAD, ADDR>), dim3(blocks), dim3(threads), 65536, 0, src, out, iters);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(blocks * 8);
   hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
@@ -98,7 +102,7 @@ void run(const char* name, const char* src, unsigned long long* out, int threads
 
 int main() {
   char* src; unsigned long long* out;
-  hipMalloc(&src, 64 << 20); hipMemset(src, 1, 64 << 20);
+  hipMalloc(&src, 1100u << 20); hipMemset(src, 1, 1100u << 20);
   hipMalloc(&out, 1 << 20);
   for (int threads : {256}) {
     run<0, 0, 0, 0>("bare MFMAs", src, out, threads);
@@ -111,6 +115,12 @@ int main() {
     run<8, 2, 0, 0>("DMA every 8, staggered by 2 per wave", src, out, threads);
     run<4, 0, 0, 2>("DMA every 4 same slot + ds_read_b128 every 2", src, out, threads);
     run<4, 1, 0, 2>("DMA every 4 staggered + ds_read_b128 every 2", src, out, threads);
+    run<4, 0, 0, 0, 1, 1>("DMA every 4, piece = 8 rows x 128 B (8 KiB apart)", src, out, threads);
+    run<4, 0, 0, 0, 1, 2>("DMA every 4, piece = 8 rows x 128 B, chunks XOR-permuted by row", src, out, threads);
+    run<4, 0, 0, 2, 1, 1>("DMA every 4 (8 rows x 128 B) + ds_read_b128 every 2", src, out, threads);
+    run<4, 0, 0, 2, 1, 2>("DMA every 4 (8 rows x 128 B, permuted) + ds_read_b128 every 2", src, out, threads);
+    run<4, 0, 0, 0, 1, 3>("DMA every 4, piece = 8 rows x 128 B from HBM (no cache hits)", src, out, threads);
+    run<8, 0, 0, 0, 1, 3>("DMA every 8, piece = 8 rows x 128 B from HBM (no cache hits)", src, out, threads);
     run<4, 0, 0, 0, 0>("DMA every 4, M0 written back to back with the DMA", src, out, threads);
     run<4, 0, 0, 0, 2>("DMA every 4, M0 written 2 MFMAs ahead", src, out, threads);
     run<4, 0, 0, 0, 3>("DMA every 4, M0 written 3 MFMAs ahead", src, out, threads);
