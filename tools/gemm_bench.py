@@ -113,6 +113,8 @@ def main():
             a1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
             b1 = (torch.rand(n, n, device=dev) * 2 - 1).to(BF)
             out = torch.empty(n, n, dtype=BF, device=dev)
+            if os.environ.get("GB_CUBE_BCAST"):      # diagnostics: every row of both operands is the SAME row (stride 0) - all operand fetches hit the caches
+                a1, b1 = a1[:1].expand(n, n), b1[:1].expand(n, n)
             for variant in [int(v) for v in os.environ.get("GB_VARIANTS", "31,17,4,-1").split(",")]:
                 if variant >= 0:
                     L.set_flags(variant, True)
