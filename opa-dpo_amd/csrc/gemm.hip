@@ -2192,7 +2192,8 @@ hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st) {
 // flight and nothing synchronises the waves; at 4.3 TB/s with 16 rows x 64 B per instruction (the register-streaming kernel of the first
 // session); at 2.5-4.4 TB/s through a barrier per k-tile (the ring kernel above with its activation half and its MFMAs switched off,
 // OPADPO_DEC64_DIAG=5; the barrier alone costs 11-29 %).  Here:
-//   * a workgroup = NW weight waves x 16 rows (48 / 64 / 128 rows; MODE 2: half gate, half up rows) x one K range (gridDim.y slices, as
+//   * a workgroup = NW weight waves x 16 rows (48 / 64 / 96 / 128 rows; MODE 2: half gate, half up rows - 48 + 48 for the 7B gate|up: 230
+//     workgroups on 256 CUs instead of 172 of 128 rows, 44.8 -> 39.6 us at 64 tokens) x one K range (gridDim.y slices, as
 //     the ring kernel) + TWO loader waves;
 //   * WEIGHTS go global -> registers, two 1-KiB loads per 64-deep k-tile and wave (rows 0-7 and 8-15 of the wave x 128 B, non-temporal), four
 //     k-tiles (8 loads) in flight per wave, no LDS.  A load covers 8 rows x 8 chunks of 16 B, an MFMA operand wants 16 rows x 4 chunks:
@@ -2227,10 +2228,11 @@ constexpr int X_STAGE = 64 * X_KT * D_BK * 2;            // 32 KiB
 #ifndef OPADPO_DEC64X_XAUX
 #define OPADPO_DEC64X_XAUX 0      // cache policy of the activation pieces
 #endif
-template <int MF, int MODE, int NW>      // NW = weight waves (16 rows each) per workgroup: 3, 4 or 8; two more waves load the activations
+template <int MF, int MODE, int NW>      // NW = weight waves (16 rows each) per workgroup: 3, 4, 6 (SwiGLU pairs) or 8; two more waves load the activations
 __global__ __launch_bounds__(64 * (NW + 2), NW == 8 ? 1 : 2) void gemm_nt_dec64x_kernel(GemmNTArgs p) {
-  static_assert(NW == 3 || NW == 4 || NW == 8, "48, 64 or 128 weight rows per workgroup");
-  static_assert(MODE != 2 || NW != 3, "SwiGLU pairs: 32 + 32 or 64 + 64 rows");
+  static_assert(NW == 3 || NW == 4 || NW == 6 || NW == 8, "48, 64, 96 or 128 weight rows per workgroup");
+  static_assert(MODE != 2 || NW != 3, "SwiGLU pairs: 32 + 32, 48 + 48 or 64 + 64 rows");
+  static_assert(MODE == 2 || NW != 6, "96-row workgroups: SwiGLU pairs only");
   constexpr int XDG = OPADPO_DEC64X_DIAG;
   extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 activation stages
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2242,8 +2244,19 @@ __global__ __launch_bounds__(64 * (NW + 2), NW == 8 ? 1 : 2) void gemm_nt_dec64x
   const int nk = max(t1 - t0, 0), nc = (nk + X_KT - 1) / X_KT;
   // weight rows of this workgroup: 16 * NW consecutive rows, or (MODE 2: rows per 128 = [64 gate | 64 up]) HALF gate rows + the HALF up rows 64 further
   constexpr int ROWS = 16 * NW, HALF = ROWS / 2;
-  const int n0 = MODE == 2 ? (bt * HALF / 64) * 128 + (bt * HALF) % 64 : bt * ROWS;
-  auto wrow = [&](int r) { return MODE == 2 ? (r < HALF ? n0 + r : n0 + 64 + (r - HALF)) : n0 + r; };
+  // MODE 2 in gate-row units: workgroup bt owns the gate rows g = bt * HALF .. + HALF - 1 and their up rows; gate row g is weight row (g / 64) * 128 +
+  // g % 64, its up row 64 further (a wave's 16 rows never straddle a block of 64).  HALF = 48 does not divide the 11008 gate rows of the 7B MLP: the
+  // waves of the last workgroup that lie past the end redo its last 16 valid rows (they keep the barriers' count) and store nothing.
+  const int n0 = MODE == 2 ? 0 : bt * ROWS;
+  const int gw = wave < NW ? (wave < NW / 2 ? wave : wave - NW / 2) : 0;                     // MODE 2: the wave's 16-row group inside its half
+  const int g_raw = bt * HALF + gw * 16;
+  const bool g_live = MODE != 2 || g_raw < p.N / 2;
+  const int g0 = MODE == 2 ? (g_live ? g_raw : p.N / 2 - 16) : 0;                          // first gate row of the wave
+  auto wrow = [&](int r) {                                                                // r = row inside the workgroup, wave-major
+    if (MODE != 2) return n0 + r;
+    const int g = g0 + (r & 15);
+    return (g / 64) * 128 + g % 64 + (r >= HALF ? 64 : 0);
+  };
   auto uni = [](const void* q) -> void* {
     const unsigned long long v = (unsigned long long)q;
     return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
@@ -2375,7 +2388,7 @@ __global__ __launch_bounds__(64 * (NW + 2), NW == 8 ? 1 : 2) void gemm_nt_dec64x
         uint2 stv;
         stv.x = pack_bf2(o[0], o[1]);
         stv.y = pack_bf2(o[2], o[3]);
-        *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + bt * HALF + wave * 16 + fc * 4) = stv;
+        if (g_live) *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + g0 + fc * 4) = stv;
       }
     }
     return;
@@ -2418,28 +2431,31 @@ hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipSt
     int nw = 4;
     {
       long best = -1;
-      const int cand[3] = {8, 4, 3};
-      for (int ci = 0; ci < 3; ++ci) {
+      const int cand[4] = {8, 6, 4, 3};
+      for (int ci = 0; ci < 4; ++ci) {
         const int c = cand[ci];
-        if (a.N % (16 * c) || (mode == 2 && c == 3)) continue;
-        const long wgs = (long)(a.N / (16 * c)) * splits;
+        // 96-row workgroups (48 gate + 48 up rows) exist for the SwiGLU-pair mode only, where the last workgroup may be partly filled
+        if (mode == 2 ? (c == 3 || (c != 6 && a.N % (16 * c))) : (c == 6 || a.N % (16 * c))) continue;
+        const long wgs = (mode == 2 ? (long)(a.N / 2 + 8 * c - 1) / (8 * c) : (long)(a.N / (16 * c))) * splits;
         long cost = ((wgs + 255) / 256) * (16 * c + 16 * mf);
         if (c == 4 && wgs > 448 && wgs <= 512) cost = cost * 3 / 4;      // two full rounds of 64-row workgroups, two per CU: measured ahead of one round of 128-row ones (lm_head, 500: 46.8 vs 52.9 us at 8 tokens, 49.8 vs 53.6 at 32, 57.5 vs 57.9 at 64)
         if (best < 0 || cost < best) { best = cost; nw = c; }
       }
       if (nw_force == 3 || nw_force == 4 || nw_force == 8) { if (a.N % (16 * nw_force) == 0 && !(mode == 2 && nw_force == 3)) nw = nw_force; }
+      if (nw_force == 6 && mode == 2) nw = 6;
     }
+    const int grid_x = mode == 2 ? (a.N / 2 + 8 * nw - 1) / (8 * nw) : a.N / (16 * nw);
 #define DX_GO(MF_, MD_, NW_)                                                                                                          \
   do {                                                                                                                                \
     static bool at_ = false;                                                                                                          \
     if (!at_) { (void)hipFuncSetAttribute((const void*)gemm_nt_dec64x_kernel<MF_, MD_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X_STAGE); at_ = true; } \
-    hipLaunchKernelGGL((gemm_nt_dec64x_kernel<MF_, MD_, NW_>), dim3(a.N / (16 * NW_), splits), dim3(64 * (NW_ + 2)), 2 * X_STAGE, st, a); \
+    hipLaunchKernelGGL((gemm_nt_dec64x_kernel<MF_, MD_, NW_>), dim3(grid_x, splits), dim3(64 * (NW_ + 2)), 2 * X_STAGE, st, a); \
   } while (0)
 #define DX_MF(MD_, NW_) do { if (mf == 1) DX_GO(1, MD_, NW_); else if (mf == 2) DX_GO(2, MD_, NW_); else if (mf == 3) DX_GO(3, MD_, NW_); else DX_GO(4, MD_, NW_); } while (0)
 #define DX_MODE(MD_) do { if (nw == 8) DX_MF(MD_, 8); else if (nw == 3) DX_MF(MD_, 3); else DX_MF(MD_, 4); } while (0)
     if (mode == 0) DX_MODE(0);
     else if (mode == 1) DX_MODE(1);
-    else { if (nw == 8) DX_MF(2, 8); else DX_MF(2, 4); }
+    else { if (nw == 8) DX_MF(2, 8); else if (nw == 6) DX_MF(2, 6); else DX_MF(2, 4); }
 #undef DX_MODE
 #undef DX_MF
 #undef DX_GO
