@@ -39,7 +39,9 @@ extern "C" {
                                 * stored pre-activations [gate | up] = [M,2N] and C (ldc) receives [d_gate | d_up] = [M,2N]: opadpo_silu_mul_bwd applied
                                 * in the epilogue on the bf16-rounded d_act tile (bit-identical to the two-call form, d_act never written) */
 #define OPADPO_GEMM_STREAM 0x100 /* OR into `act`: M <= 64 (one token per sequence, KV-cache decode) -> weight-streaming
-                                  * schedule (one workgroup per 16/32 weight rows, K split over its waves) */
+                                  * schedule (one workgroup per 16/32 weight rows, K split over its waves); from 8 token rows a
+                                  * problem with nothing fused (no LoRA tail, bias, residual or scale; plain or SWIGLU_PAIR store) runs on
+                                  * the whole-line kernel of opadpo_gemm_nt_decode, bit-identical to that entry point */
 
 int opadpo_abi_version(void);
 const char* opadpo_last_error(void);

@@ -1973,6 +1973,20 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
   }
+  // Decode-sized weight streams with nothing fused (no LoRA tail, bias, residual or scale; plain or SwiGLU-pair epilogue) go to the whole-line
+  // streaming kernel behind opadpo_gemm_nt_decode from 8 token rows up: the rollout's q|k|v, gate|up and lm_head at 8 sequences (decode step
+  // 3.79 -> 3.71 ms) and the lm_head at 9-64 (B=16: 4.42 -> 4.30 ms).  Below 8 rows the 8-row kernels are ahead in the step (B=5: 3.73 vs 3.86 ms,
+  // B=4: 3.41 vs 3.52; profiles/r04_decode_stream.txt section 16), and the projections with a residual epilogue (o, down) stay on them too.
+  // OPADPO_STREAM_DEC64X = fewest token rows routed (default 8; 0 = never).
+  static const int route_x = getenv("OPADPO_STREAM_DEC64X") ? atoi(getenv("OPADPO_STREAM_DEC64X")) : 8;
+  if (route_x > 0 && a.M >= route_x && stream_hint && g_gemm_variant == 10 && g_dec64_variant != 1 && a.M <= 64 && a.K2 == 0 && !a.bias && !a.R && a.alpha == 1.0f &&
+      a.a1_group_n <= 0 && !a.rope_cos && !a.rope_pos && a.K1 % 64 == 0 && a.N % 128 == 0 && a.lda1 % 8 == 0 && a.ldb1 % 8 == 0 && a.ldc % 4 == 0 &&
+      (a.act == 0 || (a.act == OPADPO_ACT_SWIGLU_PAIR && !a.out_f32)) && (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9) {
+    GemmNTArgs d = a;
+    const int mode = a.act == OPADPO_ACT_SWIGLU_PAIR ? 2 : a.out_f32 ? 1 : 0;
+    d.act = 0;
+    return launch_gemm_nt_dec64(d, mode, 1, st);
+  }
   if (a.rope_cos || a.rope_pos) {      // fused rotary embedding: only the 4-wave 256x256 kernel implements it (bf16 out, alpha-only epilogue)
     const bool ok32 = (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 &&
                       (a.K2 == 0 || ((double)a.M * a.lda2 * 2 < 4.0e9 && (double)a.N * a.ldb2 * 2 < 4.0e9));

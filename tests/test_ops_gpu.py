@@ -1221,6 +1221,44 @@ def test_gemm_nt_decode_modes(L, M, shape, kernel):
     L.set_flags(10, True)
 
 
+@pytest.mark.parametrize("M", [8, 13, 64])
+def test_gemm_nt_stream_routes_to_decode_kernel(L, M):
+    """opadpo_gemm_nt with the stream hint and nothing fused (8-64 token rows, plain bf16 / fp32 or SwiGLU-pair store) hands the problem to the
+    whole-line kernel of opadpo_gemm_nt_decode: the two entry points agree bit for bit, column-window operands included; a residual keeps the
+    call on the 8-row kernels (still right)."""
+    N, K = 1024, 512
+    L.set_flags(10, True)
+    A = rnd(M, K + 64, scale=0.5, seed=21); W = rnd(N, K + 32, scale=0.05, seed=22)
+    a, w = A[:, 32:32 + K], W[:, 8:8 + K]
+    want = a.float() @ w.float().t()
+    O = torch.full((M + 1, N + 16), 5.0, dtype=BF, device=dev()); out = O[:M, 8:8 + N]
+    with L.decode_schedule():
+        L.gemm_nt(a, w, out)
+    ref = torch.empty(M, N, dtype=BF, device=dev())
+    L.call("opadpo_gemm_nt_decode", L.ptr(a), A.stride(0), L.ptr(w), W.stride(0), K, L.ptr(ref), N, 0, M, N, 1, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and relerr(out, want) < 6e-3
+    assert float((O[M].float() - 5.0).abs().max()) == 0.0 and float((O[:M, :8].float() - 5.0).abs().max()) == 0.0 and float((O[:M, 8 + N:].float() - 5.0).abs().max()) == 0.0
+    of = torch.empty(M, N, device=dev()); rf = torch.empty(1, M, N, device=dev())
+    with L.decode_schedule():
+        L.gemm_nt(a, w, of)
+    L.call("opadpo_gemm_nt_decode", L.ptr(a), A.stride(0), L.ptr(w), W.stride(0), K, L.ptr(rf), N, 1, M, N, 1, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(of, rf[0]) and relerr(of, want) < 1e-5
+    F = N // 2
+    os_ = torch.empty(M, F, dtype=BF, device=dev()); rs = torch.empty(M, F, dtype=BF, device=dev())
+    with L.decode_schedule():
+        L.gemm_nt(a, w, os_, act=L.ACT_SWIGLU_PAIR)
+    L.call("opadpo_gemm_nt_decode", L.ptr(a), A.stride(0), L.ptr(w), W.stride(0), K, L.ptr(rs), F, 2, M, N, 1, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(os_, rs)
+    res = torch.randn(M, N, device=dev()); o2 = torch.empty(M, N, device=dev())
+    with L.decode_schedule():
+        L.gemm_nt(a, w, o2, residual=res)
+    torch.cuda.synchronize()
+    assert relerr(o2, want + res) < 2e-5
+
+
 @pytest.mark.parametrize("shape,mode", [((15360, 5120), 0), ((5120, 13824), 1), ((27648, 5120), 2), ((5120, 5120), 1)])
 def test_gemm_nt_decode_13b_shapes(L, shape, mode):
     """The decode projections of LLaVA-1.5-13B (hidden 5120, ffn 13824) at 64 and 40 tokens through the library's choice of kernel and rows per
