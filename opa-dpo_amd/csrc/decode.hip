@@ -631,7 +631,9 @@ static int attn_decode_splits(int B, int nh, int max_ctx) {
   // split (B = 24: 5.34 -> 5.12); up to 256 pairs the 16-wave form stays (B = 8: 3.80 against 4.07 with a split)
   if (B * nh >= 768) return 1;
   if (B * nh > 256) return std::min(2, std::max(1, max_ctx / 256));
-  int splits = (256 + B * nh - 1) / (B * nh);
+  // up to 256 pairs: as many key ranges as keep the 16-wave workgroups within ONE round of the 256 CUs (rounded up, 5..7 sequences ran 320-448
+  // workgroups in two rounds: attention 27.4 + 4.9 us merge per layer at B = 5 against 23.2 at B = 8; profiles/r04k_rollout_b*_kernel_stats.csv)
+  int splits = std::max(1, 256 / (B * nh));
   splits = std::min(splits, std::max(1, max_ctx / 256));
   return std::max(1, std::min(splits, 16));
 }
