@@ -629,7 +629,13 @@ static int attn_decode_splits(int B, int nh, int max_ctx) {
   // 257..767 (sequence, head) pairs (9..23 sequences at 32 heads): two key ranges per pair, run as 4-wave workgroups (>= 512 of them) - measured
   // against one 16-wave workgroup per pair: decode step B = 12 4.47 -> 4.27 ms, B = 16 4.58 -> 4.40; from 768 pairs on 4-wave workgroups without a
   // split (B = 24: 5.34 -> 5.12); up to 256 pairs the 16-wave form stays (B = 8: 3.80 against 4.07 with a split)
-  if (B * nh >= 768) return 1;
+  if (B * nh >= 768) {
+    // 4-wave workgroups, 1024 of them resident on the chip: a partly filled last round costs a whole one (attention per layer 65.6 us at 32
+    // sequences, 106 at 40, 127.6 at 64), so two key ranges per pair are used where they cut the rounds by a fifth or more - 33..48 sequences at 32
+    // heads: decode step B = 36 6.62 -> 6.18 ms, B = 40 6.76 -> 6.34, B = 48 7.09 -> 6.79; B = 56 / 64 stay unsplit (7.38 / 7.70 against 7.56 / 7.98)
+    const int pairs = B * nh, r1 = (pairs + 1023) / 1024, r2x2 = (2 * pairs + 1023) / 1024;
+    return (r2x2 * 5 <= r1 * 8 && max_ctx >= 512) ? 2 : 1;
+  }
   if (B * nh > 256) return std::min(2, std::max(1, max_ctx / 256));
   // up to 256 pairs: as many key ranges as keep the 16-wave workgroups within ONE round of the 256 CUs (rounded up, 5..7 sequences ran 320-448
   // workgroups in two rounds: attention 27.4 + 4.9 us merge per layer at B = 5 against 23.2 at B = 8; profiles/r04k_rollout_b*_kernel_stats.csv)

@@ -722,7 +722,8 @@ def test_adamw_and_sumsq(L):
 
 
 @pytest.mark.parametrize("B,nh,hd,ctx,max_ctx", [(3, 2, 128, 70, 96), (1, 4, 128, 900, 1024), (2, 2, 64, 333, 512), (40, 32, 128, 130, 160),
-                                                 (2, 3, 128, 1, 64), (8, 32, 128, 750, 768), (1, 1, 64, 2000, 2048)])
+                                                 (2, 3, 128, 1, 64), (8, 32, 128, 750, 768), (1, 1, 64, 2000, 2048),
+                                                 (36, 32, 128, 530, 544), (5, 32, 128, 600, 640)])
 def test_attn_decode(L, B, nh, hd, ctx, max_ctx):
     """single-token attention over the head-major KV cache; split-KV path (few sequences -> workspace + merge launch)
     and single-block path agree with torch fp32; the device-resident ctx pointer gives the same bits."""
@@ -786,7 +787,7 @@ def test_rope_kv_append(L):
 
 
 @pytest.mark.parametrize("B,nh,hd,pos,max_ctx", [(2, 4, 128, 29, 48), (3, 2, 64, 0, 16), (1, 8, 128, 700, 1024), (5, 32, 128, 301, 512),
-                                                 (64, 32, 128, 130, 256), (4, 32, 128, 751, 800)])
+                                                 (64, 32, 128, 130, 256), (4, 32, 128, 751, 800), (40, 32, 128, 520, 576), (6, 32, 128, 300, 512)])
 def test_attn_decode_fused(L, B, nh, hd, pos, max_ctx):
     """opadpo_attn_decode_fused == opadpo_rope_kv_append followed by opadpo_attn_decode: identical cache contents (bits), attention
     output equal up to the order in which the newest key enters the online softmax; qkv is not modified; slots > pos never read."""
