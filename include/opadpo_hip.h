@@ -222,7 +222,10 @@ int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16,
  * keys 0..ctx-1 valid where key_mask[b*max_ctx + j] != 0; ctx_ptr (device int32, nullable) overrides ctx with
  * ctx_ptr[0] + 1 (position of the newest key) for graph replay.  workspace (nullable): device scratch of at least
  * opadpo_attn_decode_workspace_bytes(B, nh, hd, max_ctx) bytes; with it the key range is split over several blocks
- * (+ one merge launch) when B*nh alone cannot fill the 256 CUs.  Cache slots >= ctx are never read. */
+ * (+ one merge launch) where that fills the 256 CUs better: up to 256 (sequence, head) pairs as many ranges as fit ONE round of 16-wave
+ * workgroups, two ranges of 4-wave workgroups for 257-767 pairs, and from 768 pairs two ranges only where they cut the rounds of the 1024
+ * resident 4-wave workgroups by a fifth or more (max_ctx >= 512; the byte count returned is 0 when the geometry has one range).
+ * Cache slots >= ctx are never read. */
 int opadpo_attn_decode(const uint16_t* q, int ldq, const uint16_t* k_cache, const uint16_t* v_cache, uint16_t* o,
                        const uint8_t* key_mask, int B, int nh, int hd, int ctx, const int32_t* ctx_ptr, int max_ctx,
                        float scale, void* workspace, size_t workspace_bytes, void* stream);
