@@ -103,3 +103,29 @@ def test_context_lifecycle_and_errors_need_no_gpu(built_lib):
     bad = Dims(250, 2, 2, 128, 384, 512, 1e-5, 10000.0, 128, 2, 2, 256, 56, 14, 1e-5, 128, 256.0)     # hidden != heads * head_dim
     h2 = ctypes.c_void_p()
     assert lib.opadpo_ctx_create(ctypes.byref(bad), 0, ctypes.byref(h2)) != 0 and not h2.value
+
+
+def test_decode_attention_key_range_rule(built_lib):
+    """Host-side geometry of opadpo_attn_decode, read through the workspace size (B * nh * ranges * (hd + 2) floats, 0 for one range):
+    up to 256 (sequence, head) pairs as many key ranges as fit ONE round of the 256 CUs; two ranges for 257-767 pairs; from 768 pairs two
+    ranges only where they cut the rounds of 1024 resident workgroups by a fifth or more; never more ranges than max_ctx / 256."""
+    lib = ctypes.CDLL(built_lib)
+    f = lib.opadpo_attn_decode_workspace_bytes
+    f.restype = ctypes.c_size_t
+    f.argtypes = [ctypes.c_int] * 4
+    nh, hd, ctx = 32, 128, 1024
+
+    def ranges(B, nh=nh, max_ctx=ctx):
+        b = f(B, nh, hd, max_ctx)
+        assert b % (B * nh * (hd + 2) * 4) == 0
+        return max(1, b // (B * nh * (hd + 2) * 4))
+
+    assert [ranges(B) for B in (1, 2, 3, 4)] == [4, 4, 2, 2]            # 4 = the max_ctx / 256 cap
+    assert [ranges(B) for B in (5, 6, 7, 8)] == [1, 1, 1, 1]            # 160-256 pairs: one round of 16-wave workgroups
+    assert [ranges(B) for B in (9, 12, 16, 23)] == [2, 2, 2, 2]
+    assert [ranges(B) for B in (24, 28, 32)] == [1, 1, 1]
+    assert [ranges(B) for B in (33, 36, 40, 48)] == [2, 2, 2, 2]
+    assert [ranges(B) for B in (49, 56, 64)] == [1, 1, 1]
+    assert ranges(40, max_ctx=384) == 1 and ranges(12, max_ctx=384) == 1 and ranges(2, max_ctx=600) == 2
+    assert ranges(32, nh=40) == 2 and ranges(64, nh=40) == 1            # 13B head count
+    assert f(0, nh, hd, ctx) == 0
