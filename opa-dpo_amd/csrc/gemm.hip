@@ -361,34 +361,29 @@ constexpr int P_STAGE = 2 * P_TILE;              // A + B
 // gemm_nt "w4" kernel: 256x256 tile, BK = 64, FOUR waves (2x2), each owning a 128x128 block of C in 64 accumulator
 // fragments (256 accumulator registers -> one wave per SIMD, 512-register budget), two 64-KiB LDS stages filled by
 // buffer_load ... lds.  One wave per SIMD means nothing else can feed the matrix pipe, so every non-MFMA instruction of
-// the K-loop is placed INSIDE the MFMA stream (one issue slot per 1-5 MFMAs, pinned with sched_barrier) and a wave reads
-// each LDS fragment for 8 MFMAs (128 KiB of LDS reads per K-tile and block instead of 192 KiB in the 8-wave kernel).
-// Long-lead schedule per K-tile t (128 MFMAs):
-//   P1: 40 MFMAs(kk=0) | 16 reads set1(t)                  | lgkmcnt(0), barrier  -> the stage of tile t is dead
-//   P2: 24 MFMAs(kk=0) | 6 DMA (t+2)
-//   P3: 36 MFMAs(kk=1) | 7 DMA (t+2)                       | vmcnt(13), barrier   -> tile t+1 has landed
-//   P4: 28 MFMAs(kk=1) | 16 reads set0(t+1), 3 DMA (t+2)
-// so a DMA piece is waited for 104-184 MFMAs (1.8-3.1 k cycles) after its issue (a single-barrier schedule with <= 1 tile of
-// lead stalled on the ~19 % of pieces that miss the XCD's L2).  The MFMA is inline asm with the accumulator tied in place in
-// an AGPR tuple ("+a"): with the builtin, the register allocator rotated the 64 accumulators through other AGPRs / VGPRs
-// across the pinned scheduling regions (152 v_accvgpr_* + 34 s_nop per K-tile).  The DMA is two inline-asm halves: M0 (the
-// LDS destination) is written one MFMA AHEAD of the buffer_load, which costs the MFMA stream 6.5 instead of 10.5 cycles per
-// piece (tools/micro/mfma_dma.hip).  1.40-1.48 PF/s on the training shapes; DESIGN.md section 8.1 keeps the numbers of the
-// schedules this one replaced (single barrier, 8-wave 4-phase, register-staged operands, in-kernel s_memtime stamps).
+// the K-loop sits INSIDE the MFMA stream and a wave reads each LDS fragment for 8 MFMAs (128 KiB of LDS reads per K-tile
+// and block instead of 192 KiB in the 8-wave kernel).
+// Round 5: the K-loop is ONE asm block with explicit registers, generated by csrc/w4_kloop_gen.py into csrc/w4_kloop.inc (the
+// generator holds the register plan, the slot table and its hazard checks).  Rounds 1-4 wrote the same schedule idea in HIP (asm
+// MFMAs / DMA halves pinned with sched_barrier): 562 quad-cycles per K-tile and wave against 522 for the bare MFMAs; the bisect against the
+// vendor library's kernel of this geometry (tools/micro/kloop_bisect_gen.py, profiles/r05_kloop_bisect.txt) named the elements:
+//   * the CU's vector-memory path takes one 1-KiB LDS-DMA piece per wave every 64 cycles: 13 pieces at a period of 4 MFMAs are free,
+//     at a period of 3 they cost +17 quad-cycles per K-tile, at 2 +66 (bursts of 5 at period 3 are absorbed by the queue);
+//   * the landing wait + barrier of tile t+1 belong at MFMA 92 (not 100) so that the 16 fragment reads of the next tile spread over
+//     30 MFMA gaps with never two memory instructions in one gap;
+//   * what the compiler adds around asm statements (lgkmcnt re-waits it cannot prove redundant, v_add3 address arithmetic per
+//     fragment group, a taken branch in mid-tile, accumulators allocated out of order) is worth another 14 quad-cycles.
+// Schedule per K-tile t (128 MFMAs): 16 reads of k-half 1 in gaps 1..31 | lgkmcnt(0) + barrier at 39/40: the stage of tile t is dead |
+// 13 pieces of tile t+2 at gaps 41, 45, .. 89 (M0 written in the gap after the previous piece) | vmcnt(13) + barrier at 92/93: tile t+1
+// has landed | 16 reads of k-half 0 of tile t+1 + the last 3 pieces over gaps 94..121 | lgkmcnt(0) at 127.  531 quad-cycles in the harness.
 // ------------------------------------------------------------------------------------------
-// ORDER_B: the 16 DMA pieces of a K-tile go B half first (pieces 8..15, then 0..7) instead of A half first.  Nothing else changes (both
-// halves are waited for together), yet same-box sustained runs (tools/ab_gemm.sh, 300 launches per shape) show a stable preference by shape:
+// ORDER_B: the 16 DMA pieces of a K-tile go B half first instead of A half first.  Nothing else changes (both halves are waited for
+// together), yet same-box sustained runs (tools/ab_gemm.sh, 300 launches per shape) show a stable preference by shape:
 // N <= 4096 (o / down projection, every dgrad into the hidden width, the r-wide LoRA products) is 1.5-4 % faster B first, the wide
-// projections (q|k|v, gate|up, lm_head) 2.5-3 % faster A first - independent of group_m, of a third / fourth barrier per K-tile that
-// lengthens every piece's lead by 50 MFMAs, and of hand-placed lgkmcnt waits (all built and measured in round 3, none moved the time).
-// OPADPO_W4_DIAG (compile-time, diagnostics only - results are WRONG with any bit set; tools/build_diag.sh): timing of the K-loop with one of its
-// stall sources removed.  1: no vmcnt waits, 2: no barriers, 4: no DMA issue, 8: no fragment reads after the first K-tile, 16: no lgkmcnt(0) before barrier 1
-#ifndef OPADPO_W4_DIAG
-#define OPADPO_W4_DIAG 0
-#endif
+// projections (q|k|v, gate|up, lm_head) 2.5-3 % faster A first.
+#include "w4_kloop.inc"
 template <bool ORDER_B>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
-  constexpr int DIAG = OPADPO_W4_DIAG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -431,194 +426,79 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   // all 8 fragments of a lane are one base address + immediates.  The permutation costs nothing: it lives in the per-lane source offsets.
   const unsigned lrowB_lo = (unsigned)((srow & 1) * 8 + (srow & 6));     // + (pi & 1) + (pi >> 1) * 16 + wave * 64
   const unsigned m_last = (unsigned)(p.M - 1);
-  // q = 0..7: A pieces (8 rows x 128 B each) wave*8 + q, q = 8..15: B pieces.  No vector ALU work per piece: the 16 per-lane
-  // byte offsets sit in registers (recomputed only where the K-concatenated tail switches operands), the K position is the
-  // scalar offset, the descriptor is chosen per tile on the scalar unit (the vendor library's hand-written kernel of this
-  // geometry does the same; a v_mad_u64_u32 per piece between two MFMAs is a quarter-rate instruction in an in-order wave).
-  unsigned voff[16];
-  auto set_voff = [&](bool second, int which = 0) {      // which: 0 = A and B pieces, 1 = A only, 2 = B only
+  // per-lane byte offsets of the wave's 16 pieces of a K-tile (8 rows x 128 B each): vo[0..7] the B pieces, vo[8..15] the A pieces (rows
+  // clamped to M - 1).  No vector ALU work per piece in the loop: the K position is the scalar offset, the descriptor sits in SGPRs.
+  auto calc_voff = [&](bool second, unsigned (&vo)[16]) {
     const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
 #pragma unroll
     for (int pi = 0; pi < 8; ++pi) {
-      if (which != 2) voff[pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
-      if (which != 1) voff[8 + pi] = ((unsigned)n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb +
-                                     (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
+      vo[8 + pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
+      vo[pi] = ((unsigned)n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb + (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
     }
   };
+  unsigned vo1[16], vo2[16];
+  calc_voff(false, vo1);
+  calc_voff(true, vo2);
+  if (__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)LDS_PTR(void, smem)) != 0) __builtin_trap();      // the asm block addresses the dynamic LDS block from 0 (the kernel has no static LDS)
+  // prologue: K-tiles 0 and 1 (q = 0..7: A pieces wave*8 + q, q = 8..15: B pieces)
   auto issue_piece = [&](int t, int q) {
     const bool second = t >= nt1;
     const int k0 = (second ? (t - nt1) : t) * P_BK;
     char* base = smem + (t & 1) * P_STAGE;
     const int piece = wave * 8 + (q & 7);
-    if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, voff[q], k0 * 2, 0, 0);
+    const unsigned v = second ? vo2[q < 8 ? 8 + q : q - 8] : vo1[q < 8 ? 8 + q : q - 8];
+    if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rA2 : rA1, LDS_PTR(void, base + piece * 1024), 16, v, k0 * 2, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(second ? rB2 : rB1, LDS_PTR(void, base + P_TILE + piece * 1024), 16, v, k0 * 2, 0, 0);
   };
-  // the in-loop DMA as two inline-asm halves (M0 first, the load one MFMA later); nothing between the halves uses M0
-  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-  auto mk_rsrc = [&](const void* base) {
-    const unsigned long long v = (unsigned long long)base;
-    i32x4_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)v); r[1] = __builtin_amdgcn_readfirstlane((int)((v >> 32) & 0xffffu));
-    r[2] = -1; r[3] = 0x00020000;
-    return r;
-  };
-  const i32x4_t qA1 = mk_rsrc(a1), qB1 = mk_rsrc(p.B1), qA2 = mk_rsrc(nt2 ? a2 : a1), qB2 = mk_rsrc(nt2 ? p.B2 : p.B1);
-  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
-  // Scalar diet of the K-loop (round 4): every scalar instruction between two MFMAs of the only wave on a SIMD costs issue time (the
-  // vendor kernel of this geometry runs the same MFMA / LDS / VMEM counts with a quarter fewer SALU instructions and 10 % fewer wave
-  // cycles).  (i) M0 is written by ONE s_add_u32 (stage offset + per-piece constant, both resident SGPRs) instead of s_add + s_mov;
-  // (ii) the descriptors / K origin of the operand pair being fetched live in loop-carried SGPRs that the (rare) switch to the
-  // K-concatenated tail overwrites, instead of 9 s_cselect + compare + subtract per K-tile.
-  unsigned pcoff[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) pcoff[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
-  i32x4_t curA = qA1, curB = qB1;
-  int kbase = 0;                                        // first K-tile of the operand pair in use by the in-loop DMA
-  // s_pack_ll_b32_b16 is the one two-operand scalar "add" that leaves SCC alone (an SCC clobber on the asm made the hazard recognizer put an
-  // s_nop in front of every second piece): M0 = {stage bit, piece offset} = (t & 1) * 64 KiB + offset - the dynamic LDS block starts at 0
-  // (the kernel has no static LDS; checked once below) and every piece offset is below 64 KiB.
-  if (lds0 != 0) __builtin_trap();
-  auto dma_m0 = [&](int t, int q) {
-    const unsigned stg = (unsigned)__builtin_amdgcn_readfirstlane(t & 1);
-    asm volatile("s_pack_ll_b32_b16 m0, %0, %1" :: "s"(pcoff[q]), "s"(stg) : "memory");
-  };
-  auto dma_go = [&](int t, int q) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((t - kbase) * P_BK * 2);
-    if (q < 8) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(curA), "s"(soff) : "memory");
-    else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(curB), "s"(soff) : "memory");
-  };
+  for (int q = 0; q < 16; ++q) issue_piece(0, q);
+  if (nt > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_piece(1, q);
+  }
+  // (the wait for tile 0 + barrier open the asm block: the accumulator clears and the block's operand set-up below run under the DMA latency)
 
   f32x4_t acc[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t fa[2][8], fb[2][8];
   const int frow = lane & 15, fchk = lane >> 4;
-  const int fsw = (frow >> 1) & 7;                                       // swizzle term: same for every fragment of a lane
-  const int offA = (wr * 128 + frow) * 128, offB = P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128;
-  // fragment r of set kk of tile t: r = 0..7 -> B fragments, 8..15 -> A fragments
-  auto read_frag = [&](int t, int kk, int r) {
-    if constexpr ((DIAG & 8) != 0) { if (t > 0 || kk > 0) return; }
-    const char* st = smem + (t & 1) * P_STAGE;
-    const int cb = ((kk * 4 + fchk) ^ fsw) << 4;
-    if (r < 8) fb[kk][r] = *(const bf16x8_t*)(st + offB + ((r & 1) * 8 + (r & 6)) * 128 + cb);
-    else fa[kk][r - 8] = *(const bf16x8_t*)(st + offA + (r - 8) * 2048 + cb);
-  };
-#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // MFMAs idx0..idx0+n-1 of a sub-step (idx = i*8 + j: A fragment i is needed from idx 8i on)
-  // The MFMA is written as inline asm with the accumulator tied in place in an AGPR tuple ("+a"): with the builtin, the
-  // register allocator rotates accumulators through other AGPRs / VGPRs across the pinned scheduling regions of the long
-  // schedules (152 v_accvgpr_* + 34 s_nop per K-tile were measured in the loop body).
-  auto mfma_run = [&](int kk, int idx0, int n) {
-#pragma unroll
-    for (int e = 0; e < n; ++e) {
-      const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
-    }
-  };
-  auto tile_body_ll = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
-    constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
-    constexpr bool dma = has_next2 && !(DIAG & 4);
-    auto piece_of = [](int k) { return ORDER_B ? (k + 8) & 15 : k; };      // k-th piece issued -> piece id (0..7 = A rows, 8..15 = B rows)
-    // schedule knobs.  R1: MFMAs over which the 16 set-1 reads are spread; B1: MFMA index of the stage-release barrier;
-    // DSTEP: MFMAs per DMA piece after the barrier (13 pieces before the vmcnt wait at MFMA 100, 3 after); one MFMA sits
-    // between each s_waitcnt and its s_barrier
-    constexpr int R1 = 32, B1 = 40, DSTEP = 4;
-    // ---- P1: the 16 fragment reads of set 1, then slack MFMAs that cover their latency
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      mfma_run(0, (g * R1) / 16, ((g + 1) * R1) / 16 - (g * R1) / 16);
-      W4_PIN();
-      read_frag(t, 1, g);
-      W4_PIN();
-    }
-    mfma_run(0, R1, B1 - R1 - 1);
-    W4_PIN();
-    if constexpr (has_next2) {
-      if constexpr (!(DIAG & 16)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      W4_PIN(); mfma_run(0, B1 - 1, 1); W4_PIN();
-      if constexpr (!(DIAG & 2)) __builtin_amdgcn_s_barrier();            // every read of tile t's stage is done: it can take tile t+2
-      W4_PIN();
-      if (t + 2 == nt1) { set_voff(true); curA = qA2; curB = qB2; kbase = nt1; W4_PIN(); }
-    } else {
-      mfma_run(0, B1 - 1, 1);
-      W4_PIN();
-    }
-    // ---- P2/P3: MFMAs B1..99 (kk = 0 up to 63, then kk = 1), 13 DMA pieces of tile t+2, one per DSTEP MFMAs
-    {
-      constexpr int NM = 100 - B1;             // MFMAs in this span
-#pragma unroll
-      for (int m = 0; m < NM - 1; ++m) {
-        const int gi = B1 + m;                 // global MFMA index 0..127 of the tile
-        mfma_run(gi >> 6, gi & 63, 1);
-        if constexpr (dma) {
-          if ((m + 2) % DSTEP == 0 && (m + 2) / DSTEP <= 13) { W4_PIN(); dma_m0(t + 2, piece_of((m + 2) / DSTEP - 1)); W4_PIN(); }
-        }
-        if ((m + 1) % DSTEP == 0 && (m + 1) / DSTEP <= 13) {
-          W4_PIN();
-          if constexpr (dma) dma_go(t + 2, piece_of((m + 1) / DSTEP - 1));
-          W4_PIN();
-        }
-      }
-    }
-    W4_PIN();
-    if constexpr (has_next) {
-      if constexpr (!(DIAG & 1)) {
-        if constexpr (dma) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");      // the 13 pieces above stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      W4_PIN(); mfma_run(1, 35, 1); W4_PIN();
-      if constexpr (!(DIAG & 2)) __builtin_amdgcn_s_barrier();            // tile t+1 (issued during tile t-1) has landed for everyone
-    } else {
-      mfma_run(1, 35, 1);
-    }
-    W4_PIN();
-    // ---- P4: 28 MFMAs, the 16 reads of set 0 of tile t+1, the last 3 pieces
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      mfma_run(1, 36 + g * 3, 2);
-      W4_PIN();
-      if constexpr (has_next) read_frag(t + 1, 0, 2 * g);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_m0(t + 2, piece_of(13 + (g - 1) / 3)); }
-      W4_PIN();
-      mfma_run(1, 36 + g * 3 + 2, 1);
-      W4_PIN();
-      if constexpr (has_next) read_frag(t + 1, 0, 2 * g + 1);
-      if constexpr (dma) { if (g == 1 || g == 4 || g == 7) dma_go(t + 2, piece_of(13 + (g - 1) / 3)); }
-      W4_PIN();
-    }
-    mfma_run(1, 60, 4);
-    W4_PIN();
-  };
-  using T_ = std::true_type; using F_ = std::false_type;
-
-  set_voff(false);
-#pragma unroll
-  for (int q = 0; q < 16; ++q) issue_piece(0, q);
-  if (nt > 1) {
-    if (nt1 == 1) set_voff(true);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) issue_piece(1, q);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  W4_PIN();
-  if (nt1 <= 1) { curA = qA2; curB = qB2; kbase = nt1; }      // tile 2 onwards already belongs to the tail (its voff was set above)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
-  W4_PIN();
   {
-    int t = 0;
-    for (; t + 2 < nt; ++t) tile_body_ll(t, T_{}, T_{});
-    if (t + 1 < nt) { tile_body_ll(t, T_{}, F_{}); ++t; }
-    tile_body_ll(t, F_{}, F_{});
+    // operands of the asm block (names fixed by w4_kloop.inc)
+    const int fsw = (frow >> 1) & 7;                                       // swizzle term: same for every fragment of a lane
+    const unsigned offA = (unsigned)((wr * 128 + frow) * 128), offB = (unsigned)(P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128);
+    const unsigned cb0 = (unsigned)((fchk ^ fsw) << 4), cb1 = (unsigned)(((4 + fchk) ^ fsw) << 4);
+    unsigned w4k_rb[4] = {offB + cb0, offB + cb1, offA + cb0, offA + cb1};
+    auto lo32 = [](const void* q) { return __builtin_amdgcn_readfirstlane((int)(unsigned long long)q); };
+    auto hi16 = [](const void* q) { return __builtin_amdgcn_readfirstlane((int)(((unsigned long long)q >> 32) & 0xffffu)); };
+    const void* pa2 = nt2 ? (const void*)a2 : (const void*)a1; const void* pb2 = nt2 ? (const void*)p.B2 : (const void*)p.B1;
+    const int n_loop = max(nt - 2, 0);
+    int w4k_na = __builtin_amdgcn_readfirstlane(min(max(nt1 - 2, 0), n_loop));
+    int w4k_nb = __builtin_amdgcn_readfirstlane(n_loop - w4k_na);
+    const bool first_pair = w4k_na > 0;                                    // the loop starts fetching from the first operand pair
+    unsigned w4k_vo[16], w4k_vo2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { w4k_vo[q] = first_pair ? vo1[q] : vo2[q]; w4k_vo2[q] = vo2[q]; }
+    int w4k_dx[4] = {first_pair ? lo32(p.B1) : lo32(pb2), first_pair ? hi16(p.B1) : hi16(pb2), -1, 0x00020000};
+    int w4k_dy[4] = {first_pair ? lo32(a1) : lo32(pa2), first_pair ? hi16(a1) : hi16(pa2), -1, 0x00020000};
+    const int w4k_dx2[4] = {lo32(pb2), hi16(pb2), -1, 0x00020000};
+    const int w4k_dy2[4] = {lo32(pa2), hi16(pa2), -1, 0x00020000};
+    int w4k_stg = 0;
+    // K byte offset of the tile fetched LAST (the loop adds 128 before its first piece): tile 1 of the pair in use
+    int w4k_koff = __builtin_amdgcn_readfirstlane(first_pair ? 128 : (1 - nt1) * 128);
+    const int w4k_koff2 = -128;
+    const int w4k_has2 = __builtin_amdgcn_readfirstlane(nt >= 2 ? 1 : 0);
+    int w4k_pcx[8], w4k_pcy[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      w4k_pcy[q] = __builtin_amdgcn_readfirstlane((wave * 8 + q) * 1024);
+      w4k_pcx[q] = __builtin_amdgcn_readfirstlane(P_TILE + (wave * 8 + q) * 1024);
+    }
+    if constexpr (ORDER_B) W4K_RUN(W4K_TEXT_BFIRST);
+    else W4K_RUN(W4K_TEXT_AFIRST);
   }
-#undef W4_PIN
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> VALU readers (the compiler does not see the MFMAs inside the asm: 64 wait states cover the 8-pass latency)
-  __builtin_amdgcn_sched_barrier(0);                                             // ... and no accumulator read may be scheduled above them
+  __builtin_amdgcn_sched_barrier(0);                                             // no accumulator read may be scheduled above the block
   // Accumulator layout (B tile rows interleaved, see above): acc[i][j][r] of lane (frow, fchk) is row i*16 + 4*fchk + r, column 8*frow + j
   // of the wave's 128x128 block - the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns.
   auto staged_epi = [&]() {
