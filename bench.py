@@ -347,6 +347,42 @@ def _free_port():
     return p
 
 
+def _dist_timeout():
+    import datetime
+    return datetime.timedelta(seconds=int(os.environ.get("OPADPO_DIST_TIMEOUT_S", "180")))
+
+
+def rank_info(rank, local, use_gpu=True):
+    """What THIS rank is bound to, as the runtime reports it (gathered over the process group into the line's `dist.ranks`)."""
+    info = {"rank": rank, "local_rank": local, "pid": os.getpid(), "device": "cpu"}
+    if use_gpu and torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(local)
+        info.update({"device": pr.name, "uuid": str(getattr(pr, "uuid", "")), "arch": getattr(pr, "gcnArchName", ""),
+                     "compute_units": pr.multi_processor_count, "hbm_GB": pr.total_memory / 1e9})
+    return info
+
+
+def preflight(world, dev, backend):
+    """First collective of the run, right after the rendezvous and BEFORE any model state exists: the sum of ones over the group must be the
+    world size.  Bounded by the process group's timeout (OPADPO_DIST_TIMEOUT_S, default 180 s) so a rank that never arrives ends the run with a
+    reason instead of a hang at the first barrier of the timed region."""
+    if world <= 1:
+        return 1.0
+    probe = torch.ones(1, device=dev)
+    dist.all_reduce(probe)
+    if float(probe) != float(world):
+        raise RuntimeError(f"pre-flight all-reduce of ones over {backend} returned {float(probe)} for world size {world}")
+    return float(probe)
+
+
+def collective_lib_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return "RCCL/NCCL " + ".".join(str(x) for x in v)
+    except Exception as e:      # CPU-only build or gloo
+        return None
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher environment (RANK / WORLD_SIZE unset): start the N ranks the way
     the reference's run/train_opa_dpo.sh:96-100 starts the trainer (`torchrun --nproc-per-node=$GPUS_PER_NODE`, one process per GPU) - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
@@ -378,7 +414,10 @@ def dry_run(args, world, rank, local):
         torch.cuda.set_device(local)
     backend = "nccl" if use_gpu else "gloo"
     if world > 1:
-        dist.init_process_group(backend, **({"device_id": dev} if use_gpu else {}))
+        dist.init_process_group(backend, timeout=_dist_timeout(), **({"device_id": dev} if use_gpu else {}))
+    if os.environ.get("OPADPO_BENCH_FAIL_RANK") == str(rank):      # tests: a rank that dies after the rendezvous (the others sit in the pre-flight)
+        raise RuntimeError(f"injected failure on rank {rank} (OPADPO_BENCH_FAIL_RANK)")
+    preflight(world, dev, backend)
 
     def t_sumsq(g, out):
         out += (g.double() ** 2).sum().float()
@@ -433,12 +472,12 @@ def dry_run(args, world, rank, local):
         ref.step(grad_accum_div=world)
     err = float((work.float().cpu() - w1.float()).abs().max())
     tt = torch.tensor([dt, -dt, err], dtype=torch.float64, device=dev)
-    seen, same = [{"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local) if use_gpu else "cpu"}], True
+    seen, same = [rank_info(rank, local, use_gpu)], True
     ones = 1.0
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local) if use_gpu else "cpu"})
+        dist.all_gather_object(seen, rank_info(rank, local, use_gpu))
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)
         ones = float(probe)
@@ -454,7 +493,8 @@ def dry_run(args, world, rank, local):
                "config": {"workload": f"DRY RUN (no kernels): launcher + rendezvous + bucketed {args.optimizer_mode} exchange of a {numel}-element "
                                       f"flat LoRA buffer ({args.model} layout, {len(opt.buckets)} buckets) with torch stand-ins for the update kernels",
                           "parallelism": f"dp{world}"},
-               "dist": {"backend": backend if world > 1 else None, "world_size": world, "allreduce_of_ones": ones, "ranks": seen,
+               "dist": {"backend": backend if world > 1 else None, "collective_library": collective_lib_version() if use_gpu else None,
+                        "world_size": world, "allreduce_of_ones": ones, "ranks": seen,
                         "ms_per_step_min_over_ranks": -float(tt[1]) / steps * 1e3, "ms_per_step_max_over_ranks": float(tt[0]) / steps * 1e3,
                         "replicas_identical_after_step": same, "max_abs_diff_vs_1_rank_step_on_averaged_gradient": float(tt[2]), "self_check": ok},
                "roofline": None, "cpu_baseline": None}
@@ -528,9 +568,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if share or args.backend == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=_dist_timeout())
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=_dist_timeout())
+        if os.environ.get("OPADPO_BENCH_FAIL_RANK") == str(rank):
+            raise RuntimeError(f"injected failure on rank {rank} (OPADPO_BENCH_FAIL_RANK)")
+        preflight(world, dev if not (share or args.backend == "gloo") else torch.device("cpu"), dist.get_backend())
 
     from opadpo_amd import lib as L
     from opadpo_amd.dims import LlavaDims, lora_param_count, pair_flops, pair_flops_packed
@@ -645,12 +688,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # what the collective backend actually saw: every rank's (rank, local device, device name) through RCCL itself
         seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local)})
+        dist.all_gather_object(seen, rank_info(rank, local))
+        peak = torch.tensor([torch.cuda.max_memory_allocated() / 1e9], device=dev)
+        dist.all_reduce(peak, op=dist.ReduceOp.MAX)
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                       # sum of ones over RCCL = number of ranks in the communicator
         tmin = torch.tensor([dt], device=dev)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        dist_rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(probe), "ranks": seen,
+        dist_rec = {"backend": dist.get_backend(), "collective_library": collective_lib_version(), "world_size": dist.get_world_size(),
+                    "allreduce_of_ones": float(probe), "ranks": seen, "hbm_peak_allocated_GB_max_over_ranks": float(peak),
                     "ms_per_step_min_over_ranks": float(tmin) / args.steps * 1e3, "ms_per_step_max_over_ranks": float(tmax) / args.steps * 1e3,
                     "exchange": f"{args.optimizer_mode}: per-bucket {'reduce_scatter + all_gather' if args.optimizer_mode == 'zero1' else 'all_reduce'} of the flat LoRA gradient, launched from the backward's layer hook"}
         if not args.no_side_legs:
@@ -782,6 +828,20 @@ def main():
                 del dense_pool
             except Exception as e:
                 out["dense"] = {"error": repr(e)}
+            # (a2) the same step with the frozen reference adapter UNMERGED (the trainer CLI's default since round 5: policy and reference run
+            # the same K-concatenated kernels, so their log-ratio at equal adapters is exactly 0 like in the reference, dpo_trainer.py:444-449);
+            # the headline keeps the merged copy (no LoRA GEMMs in the no-grad pass) and says so in config.reference_adapter
+            if not args.no_merge_ref and ref_ad.merged is not None:
+                try:
+                    saved_merged, ref_ad.merged = ref_ad.merged, None
+                    step_no[0] = 0
+                    dt_u = timed(1, 4)
+                    out["reference_unmerged"] = {"value": args.pairs * args.accum / dt_u, "unit": "pairs/s", "ms_per_step": dt_u * 1e3, "steps": 4,
+                                                 "note": "opadpo_train's default (--merge_ref_adapter 0): log-ratio exactly 0 at equal adapters"}
+                except Exception as e:
+                    out["reference_unmerged"] = {"error": repr(e)}
+                finally:
+                    ref_ad.merged = saved_merged
             # (b) does the data-parallel exchange hide behind the backward?  Same step with a 1-rank RCCL group: every bucket's bf16 staging
             # cast + reduce_scatter is launched from the layer hook INSIDE the backward, all-gathers after AdamW (optim.FlatAdamW zero1),
             # A/B against the collective-free step measured back to back on the same pool
@@ -874,4 +934,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # one line with the reason, a non-zero exit: the launcher (torch.distributed.run) then ends the other ranks
+        import traceback
+        traceback.print_exc()
+        print(f"[bench] FAILED on rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        os._exit(1)

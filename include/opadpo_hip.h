@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define OPADPO_ABI_VERSION 1
+#define OPADPO_ABI_VERSION 2      /* 2 (round 5): + opadpo_ctx_wgrad_deterministic; opadpo_gemm_tn_group_workspace_bytes is 0 for MIXED lists too */
 #define OPADPO_ACT_NONE 0
 #define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
@@ -52,7 +52,8 @@ const char* opadpo_last_error(void);
  * per CU), bit 3 = 128x128 gemm_tn kernel instead of the default 256x256 one, bit 4 = 16-row weight-streaming decode GEMM also for
  * M <= 16 (default there: the whole-cache-line 8-row form), bits 5-6 = kernel behind opadpo_gemm_nt_decode (0 = the library's choice,
  * 1 = the LDS-ring kernel of rounds 2-4, 3 = the whole-line streaming kernel gemm_nt_dec64x = the library's choice; A/B runs and tests), bits 7-8 = weight rows per workgroup of that kernel (0 = by shape, 1 / 2 / 3 =
- * 48 / 64 / 128 rows; tests). */
+ * 48 / 64 / 128 rows; tests), bit 9 = opadpo_sample runs its full vocabulary sweeps instead of the one-wave tail on the kept tokens (identical draws; the
+ * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
@@ -312,8 +313,14 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
  * a time, logits recomputed per chunk in the backward: no [rows, vocab] buffer; default: chunked when the fp32 logits of the batch shape S*K*T reach 4 GiB);
  * bit 11 = rotary embedding as its own in-place kernel (default on ragged rows: inside the q|k|v projection's epilogue, opadpo_gemm_nt_rope_pos);
- * bit 12 = LoRA wgrads flushed with fp32 atomics (default: partial tiles to a workspace + ordered reduce, bit-reproducible gradients) */
+ * bit 12 = LoRA wgrads flushed with fp32 atomics (default: partial tiles to a workspace + ordered reduce, bit-reproducible gradients).
+ *   PRECONDITION of the default: every wgrad of a layer runs on the 256x256 kernel, i.e. lora_r % 256 == 0 (the shipped DPO recipe: r = 256).
+ *   With r = 64 / 128 (the reference's online_generation / opa_train defaults) the wgrads run on the 128x128 kernel and flush with fp32
+ *   atomics whatever this bit says: results correct to fp32 summation order, not bit-reproducible - opadpo_ctx_wgrad_deterministic tells. */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
+/* how the LAST opadpo_seq_logprobs_bwd of this context flushed its LoRA wgrads: 1 = ordered reduce (bit-reproducible), 0 = fp32 atomics
+ * (bit 12 set, or lora_r % 256 != 0), -1 = no backward yet */
+int opadpo_ctx_wgrad_deterministic(const opadpo_ctx* ctx);
 /* return cached arenas and the workspace to the allocator */
 int opadpo_ctx_trim(opadpo_ctx* ctx);
 size_t opadpo_ctx_bytes_peak(const opadpo_ctx* ctx);

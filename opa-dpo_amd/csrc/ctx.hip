@@ -222,6 +222,7 @@ struct opadpo_ctx {
   opadpo_dims d;
   int device = 0;
   std::string err;
+  int wgrad_det = -1;                             // how the last backward flushed its LoRA wgrads: 1 ordered reduce (bit-reproducible), 0 fp32 atomics, -1 no backward yet
   // borrowed weights
   const bf16_t *embed = nullptr, *norm = nullptr, *lm_head = nullptr, *lm_head_t = nullptr;
   std::vector<opadpo_layer_weights> layers;
@@ -644,6 +645,7 @@ int opadpo_ctx_trim(opadpo_ctx* c) {
 }
 
 size_t opadpo_ctx_bytes_peak(const opadpo_ctx* c) { return c ? c->bytes_peak : 0; }
+int opadpo_ctx_wgrad_deterministic(const opadpo_ctx* c) { return c ? c->wgrad_det : -1; }
 
 int opadpo_ctx_profile(opadpo_ctx* c, int enable) {
   if (!c) return (int)hipErrorInvalidValue;
@@ -1013,6 +1015,7 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   bf16_t* dt_ra = cv.take<bf16_t>((size_t)M * r);        // dT of the o projection (dt_r keeps the down projection's until the grouped wgrad)
   float* d_full = cv.take<float>(sv->Uc > 0 ? MH : 1);   // compact top layer: its residual gradient scattered back to every row
   float* tn_ws = cv.take<float>(tn_ws_floats);
+  c->wgrad_det = tn_ws_floats > 1 ? 1 : 0;
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");

@@ -701,6 +701,9 @@ hipError_t launch_rope_kv_append(bf16_t* qkv, int ld, const float* cosb, const f
   return hipGetLastError();
 }
 
+// 1 (default): one-wave tail on the kept tokens after the top-k threshold; 0: the full vocabulary sweeps (identical draws; the exactness test's yardstick)
+static int g_sample_compact = getenv("OPADPO_SAMPLE_COMPACT") ? atoi(getenv("OPADPO_SAMPLE_COMPACT")) : 1;
+void opadpo_set_sample_compact(bool on) { g_sample_compact = on ? 1 : 0; }
 hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
                          uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
                          int32_t* out, int32_t* history, hipStream_t st) {
@@ -711,8 +714,7 @@ hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float te
     (void)hipFuncSetAttribute((const void*)sample_kernel_fast, hipFuncAttributeMaxDynamicSharedMemorySize, SAMP_MAXV * 4);
     attr_set = true;
   }
-  const char* ce = getenv("OPADPO_SAMPLE_COMPACT");      // read per launch (one per decode step): 0 keeps the full sweeps (the exactness test flips it)
-  const int compact = ce ? atoi(ce) : 1;
+  const int compact = g_sample_compact;      // process switch (opadpo_set_flags use_tr bit 9 / OPADPO_SAMPLE_COMPACT=0 at load): the same for eager and captured launches
   if (fast)
     hipLaunchKernelGGL(sample_kernel_fast, dim3(rows), dim3(SAMP_T), (size_t)V * 4, st, logits, ldl, V, 1.0f / temperature, top_k, top_p, seed,
                        step, step_ptr, finished, pad_id, eos_id, out, history, compact);

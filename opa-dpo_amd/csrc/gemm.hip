@@ -1810,6 +1810,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
+  opadpo_set_sample_compact((use_tr & 512) == 0);
   g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
 bool opadpo_flag_tr() { return g_use_tr; }
@@ -2043,6 +2044,9 @@ size_t gemm_tn_group_workspace_bytes(const GemmTNArgs* list, int n) {
     need = std::max(need, (size_t)n_runs * smax * 65536 * sizeof(float));
   };
   if (n <= 0 || n > 8) return 0;
+  // 0 unless EVERY problem of the list runs on the 256x256 kernel (grouped or alone): a mixed list would send the others to the 128x128
+  // kernel's fp32 atomics behind an API that promises a bit-reproducible result
+  for (int i = 0; i < n; ++i) if (list[i].M > 0 && !tn_w4_ok(list[i], list[i].M)) return 0;
   bool group = true;
   for (int i = 0; i < n; ++i) group = group && tn_w4_ok(list[i], list[0].M);
   if (group) one(list, n);

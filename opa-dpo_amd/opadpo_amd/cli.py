@@ -43,7 +43,7 @@ FLAGS = [
     ("base_model_name", str, "./base_models/llava-v1.5-7b"), ("vision_tower", str, "different"), ("mm_vision_select_layer", int, -2),
     ("mm_use_im_start_end", "st", None), ("mm_use_im_patch_token", "st", None), ("freeze_mm_mlp_adapter", "st", None),
     # additions of this build
-    ("optimizer_mode", str, "zero1"), ("synthetic", str, None), ("merge_ref_adapter", int, 1),
+    ("optimizer_mode", str, "zero1"), ("synthetic", str, None), ("merge_ref_adapter", int, 0),
 ]
 
 
@@ -159,7 +159,11 @@ def main(argv: Optional[List[str]] = None) -> None:
     engine = CtxEngine(base)          # sequence-level C entry points (opadpo_ctx): layer loop, workspace, activations below the ABI
     policy = AutoregressivePolicy(engine, LoraAdapter(d, adapter_sd, dev, True), args.response_len, args.temperature, "lora_policy")
     ref_adapter = LoraAdapter(d, ref_sd, dev, False)
-    if args.merge_ref_adapter:      # frozen reference adapter folded into its own bf16 weight copy (model.LoraAdapter.merge_into_base)
+    # Default 0 (round 5): the frozen reference adapter runs through the SAME K-concatenated kernels as the policy, so the log-ratio of two
+    # equal adapters is exactly 0 on every token - the reference's semantics (dpo_trainer.py:444-449, 997-1016), and every *_gap_mean / accuracy
+    # statistic of the first steps starts from 0 instead of from rounding noise.  1 folds it into its own bf16 weight copy
+    # (model.LoraAdapter.merge_into_base: -4 % step time, |log-ratio| 0.03 nat per token at equal adapters); bench.py measures both.
+    if args.merge_ref_adapter:
         ref_adapter.merge_into_base(base)
     ref_policy = AutoregressivePolicy(engine, ref_adapter, args.response_len, args.temperature, "lora_ref_policy")
     trainer = DPOTrainer(args, policy, ref_policy, optimizer_mode=args.optimizer_mode, frozen_adapter_state=vision_lora,

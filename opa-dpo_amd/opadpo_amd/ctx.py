@@ -162,6 +162,11 @@ class CtxEngine(LlavaEngine):
         self._call("opadpo_ctx_profile_read", C.byref(f), C.byref(ms), C.byref(n))
         return f.value, ms.value, n.value
 
+    def wgrad_deterministic(self) -> int:
+        """How the last backward flushed its LoRA wgrads: 1 ordered reduce (bit-reproducible), 0 fp32 atomics (use_tr bit 12, or
+        lora_r % 256 != 0 - the 128x128 wgrad kernel has no ordered flush), -1 no backward yet."""
+        return int(self._lib.opadpo_ctx_wgrad_deterministic(self.ctx))
+
     def _ensure_rope(self, n_pos: int) -> None:
         if n_pos > self._rope_len:
             n = max(n_pos, 2048)

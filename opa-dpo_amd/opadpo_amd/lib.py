@@ -93,7 +93,7 @@ SIGNATURES.update({
     "opadpo_decode_end": [_p],
 })
 OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes", "opadpo_gemm_tn_group_workspace_bytes",
-                 "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_ctx_bytes_peak"]
+                 "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_ctx_bytes_peak", "opadpo_ctx_wgrad_deterministic"]
 
 _lib: Optional[C.CDLL] = None
 
@@ -136,8 +136,12 @@ def load() -> C.CDLL:
     lib.opadpo_ctx_last_error.restype = C.c_char_p
     lib.opadpo_ctx_bytes_peak.argtypes = [_p]
     lib.opadpo_ctx_bytes_peak.restype = _sz
-    if lib.opadpo_abi_version() != 1:
-        raise OpadpoError("ABI version mismatch")
+    if hasattr(lib, "opadpo_ctx_wgrad_deterministic"):
+        lib.opadpo_ctx_wgrad_deterministic.argtypes = [_p]
+        lib.opadpo_ctx_wgrad_deterministic.restype = _i
+    # the shipped library must be THIS ABI; an older build named by OPADPO_LIB_PATH (same-box A/B of two kernel versions) may be one behind
+    if lib.opadpo_abi_version() != 2 and not (os.environ.get("OPADPO_LIB_PATH") and lib.opadpo_abi_version() == 1):
+        raise OpadpoError(f"ABI version mismatch: library {lib.opadpo_abi_version()}, binding 2 (rebuild: python opa-dpo_amd/build.py)")
     _lib = lib
     g = os.environ.get("OPADPO_USE_GLDS")
     t = os.environ.get("OPADPO_USE_TR")

@@ -56,7 +56,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     for name in parse_header():
         assert hasattr(lib, name), f"{name} declared in include/opadpo_hip.h but not exported"
     lib.opadpo_abi_version.restype = ctypes.c_int
-    assert lib.opadpo_abi_version() == 1
+    assert lib.opadpo_abi_version() == 2
 
 
 def test_binding_matches_header(built_lib):
@@ -129,3 +129,13 @@ def test_decode_attention_key_range_rule(built_lib):
     assert ranges(40, max_ctx=384) == 1 and ranges(12, max_ctx=384) == 1 and ranges(2, max_ctx=600) == 2
     assert ranges(32, nh=40) == 2 and ranges(64, nh=40) == 1            # 13B head count
     assert f(0, nh, hd, ctx) == 0
+
+
+def test_generated_kloop_is_current():
+    """opa-dpo_amd/csrc/w4_kloop.inc (the K-loop of gemm_nt_w4_kernel as an asm block) is generated: the committed file must be what the
+    committed generator emits, and the generator's hazard checks (LDS stage reuse, fragment registers, M0, vmcnt bookkeeping) must hold."""
+    import subprocess
+    import sys
+    gen = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opa-dpo_amd", "csrc", "w4_kloop_gen.py")
+    r = subprocess.run([sys.executable, gen, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

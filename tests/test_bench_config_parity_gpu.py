@@ -85,7 +85,7 @@ def _grad_blocks(d, adapter, ol):
             got = adapter.g(i, name).cpu()
             ref = torch.zeros(rows, cols)
             for mod, ab, r0, nr in pm[name]:
-                ref[r0:r0 + nr] = ol[f"base_model.model.model.layers.{i}.{mod}.{ab}.weight"].grad
+                ref[r0:r0 + nr] = ol[f"base_model.model.model.layers.{i}.{mod}.{ab}.weight"].grad.cpu()
             assert bool(torch.isfinite(got).all())
             # relative Frobenius error, and the projection of the HIP gradient on the oracle's (1 = no scale / sign error)
             out[f"L{i}_{name}"] = (float((got - ref).norm() / (ref.norm() + 1e-12)), float((got * ref).sum() / ((ref * ref).sum() + 1e-30)))
@@ -146,6 +146,17 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False, requi
     loss.backward()
     torch.cuda.synchronize()
     # ---- oracle -----------------------------------------------------------------------------------------------------
+    # evaluated on ODEV (the accelerator by default, torch's fp32 kernels; OPADPO_ORACLE_DEVICE=cpu for the host): the same torch code the CPU
+    # tests pin against transformers (tests/test_parity_gpu.py::test_oracle_is_device_independent); 6-10 full-width passes per configuration cost
+    # 90-180 s of host time each test
+    odev = torch.device(os.environ.get("OPADPO_ORACLE_DEVICE", "cuda:0"))
+    W = {k: v.to(odev) for k, v in W.items()}
+    lora_pol = {k: v.to(odev) for k, v in lora_pol.items()}
+    lora_ref = {k: v.to(odev) for k, v in lora_ref.items()}
+    images, queries, qmask = images.to(odev), queries.to(odev), qmask.to(odev)
+    resp_host = resp
+    resp = {k: v.to(odev) for k, v in resp.items()}
+    wts = {k: v.to(odev) for k, v in wts.items()}
     with torch.no_grad():
         Wm, rest = LR.merge_llm_lora(W, lora_ref, od, emulate_bf16=True)
         ref_emu_merged = LR.policy_forward(images, queries, qmask, resp, Wm, rest, od, 1.0, emulate_bf16=True)
@@ -163,6 +174,7 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False, requi
     if check_grads:
         oloss = sum((pol_f32[k + "_logprobs"] * wts[k]).sum() for k in resp)
         oloss.backward()
+    resp = resp_host
     worst = {}
     for k in resp:
         valid = resp[k] != 0
@@ -173,13 +185,13 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False, requi
                                     ("oracle_emu_vs_fp32_policy", pol_emu, pol_f32)):
             if want_d is None:
                 continue
-            got, want = got_d[k + "_logprobs"].detach().cpu(), want_d[k + "_logprobs"].detach()
+            got, want = got_d[k + "_logprobs"].detach().cpu(), want_d[k + "_logprobs"].detach().cpu()
             assert bool((got[~valid] == 0).all()) and bool((want[~valid] == 0).all())        # mask placement is exact (Quirk Q4)
             mean, p99, mx = _relstats(got, want, valid)
             REPORT[f"{tag}_{name}_{k}"] = {"mean": mean, "p99": p99, "max": mx}
             w = worst.setdefault(name, [0.0, 0.0, 0.0])
             worst[name] = [max(w[0], mean), max(w[1], p99), max(w[2], mx)]
-        ent, ent_want = r_out[k + "_entropies"].cpu(), (ref_f32 if ref_f32 is not None else ref_emu_merged)[k + "_entropies"]
+        ent, ent_want = r_out[k + "_entropies"].cpu(), (ref_f32 if ref_f32 is not None else ref_emu_merged)[k + "_entropies"].cpu()
         REPORT[f"{tag}_ref_entropy_maxabs_{k}"] = float((ent - ent_want).abs().max())
         assert float((ent - ent_want).abs().max()) < 5e-2
     REPORT[f"{tag}_worst"] = worst
@@ -187,7 +199,7 @@ def _check_config(tag, kw, B, Q, T, *, check_grads=True, assert_1e3=False, requi
         blocks = _grad_blocks(d, pol_ad, ol)
         REPORT[f"{tag}_grad_blocks"] = blocks
         # the weighted sum can cancel: error relative to the sum of |terms|
-        scale = sum(float((pol_f32[k + "_logprobs"].detach().abs() * wts[k].abs()).sum()) for k in resp)
+        scale = sum(float((pol_f32[k + "_logprobs"].detach().abs() * wts[k].abs()).sum()) for k in resp)      # (both on ODEV)
         REPORT[f"{tag}_loss_rel"] = abs(float(loss.detach()) - float(oloss.detach())) / scale
     _dump()
     print(f"[{tag}] rows={M}", json.dumps(worst))
@@ -422,3 +434,43 @@ def test_rollout_batch64_7b_width():
     REPORT["rollout_b64_checked"] = {"rows": rows, "steps": n_chk, "near_ties_resolved_to_second": close, "ctx_max": Q + d.n_patches - 1 + N}
     _dump()
     eng.close()
+
+
+def test_north_star_1e3_literal_one_layer_vs_fp32_oracle():
+    """north_star: "per-token DPO log-probs match the reference ... within 1e-3 relative".  Asserted LITERALLY where nothing amplifies bf16
+    rounding yet: ONE decoder layer at full 7B width (every benchmarked kernel at its benchmark shape), the trained policy adapter
+    K-concatenated, packed ragged rows through the context API, against the FP32 oracle (no emulation - the reference arithmetic itself) on
+    >= 5 000 response tokens: mean relative error < 1e-3.  (Deeper models sit on the bf16 floor the full-depth tests measure; this is the
+    one place the literal number holds, so a regression past it is red.)"""
+    from opadpo_amd.model import LoraAdapter
+    from opadpo_amd.policy import AutoregressivePolicy
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    kw = dict(hidden=4096, n_layers=1, n_heads=32, head_dim=128, ffn=11008, vocab=32000, v_hidden=128, v_layers=2,
+              v_heads=2, v_ffn=256, image_size=56, patch=14, lora_r=256, lora_alpha=512.0)
+    d, od, W, eng, dev, LR = _model(kw)
+    lora_pol = {k: v.to(BF).float() for k, v in LR.init_lora(od, seed=1, b_std=0.01, with_vision=False).items()}
+    B, Q, T = 10, 128, 384
+    images, queries, qmask, resp = _inputs(d, B, Q, T, seed=13)
+    n_tok = sum(int((resp[k] != 0).sum()) for k in resp)
+    assert n_tok >= 5000, n_tok
+    pol_ad = LoraAdapter(d, lora_pol, dev, trainable=True)
+    with torch.no_grad():
+        p_out = AutoregressivePolicy(eng, pol_ad, T, pack_responses=True)(images=images.to(dev), queries=queries, queries_attn_masks=qmask, **resp)
+        Wd = {k: v.to(dev) for k, v in W.items()}
+        want = LR.policy_forward(images.to(dev), queries.to(dev), qmask.to(dev), {k: v.to(dev) for k, v in resp.items()}, Wd,
+                                 {k: v.to(dev) for k, v in lora_pol.items()}, od, 1.0)
+    tot, cnt, worst = 0.0, 0, 0.0
+    for k in resp:
+        valid = resp[k] != 0
+        got, w = p_out[k + "_logprobs"].cpu(), want[k + "_logprobs"].cpu()
+        assert bool((got[~valid] == 0).all())
+        r = ((got - w).abs()[valid] / w.abs()[valid].clamp_min(1e-3)).double()
+        tot += float(r.sum()); cnt += int(valid.sum()); worst = max(worst, float(r.max()))
+    mean = tot / cnt
+    REPORT["north_star_1e3_literal"] = {"tokens": cnt, "mean_rel": mean, "max_rel": worst}
+    _dump()
+    print("[north_star_1e3]", REPORT["north_star_1e3_literal"])
+    assert mean < 1e-3, REPORT["north_star_1e3_literal"]
+    eng.release()
+    torch.cuda.empty_cache()

@@ -66,3 +66,26 @@ def test_world_size_mismatch_is_reported():
     env.update(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = _run("--gpus", "2", "--dry-run", env=env, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_a_dying_rank_ends_the_launch_quickly_with_a_reason():
+    """The first node run will be unattended: when one rank raises (here: right after the rendezvous, while rank 0 already sits in the
+    pre-flight all-reduce) the launcher must come back non-zero with the reason on stderr - within a minute, not after a collective timeout."""
+    import time
+    env = _env()
+    env["OPADPO_BENCH_FAIL_RANK"] = "1"
+    env["OPADPO_DIST_TIMEOUT_S"] = "40"
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--model", "tiny", "--steps", "1", env=env, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 60, time.time() - t0
+    assert "FAILED on rank 1 of 2" in r.stderr and "injected failure" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no bench line from a failed run
+
+
+def test_dry_run_records_what_each_rank_is_bound_to():
+    r = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--model", "tiny", "--steps", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    ds = json.loads(r.stdout.strip().splitlines()[-1])["dist"]
+    assert len({x["pid"] for x in ds["ranks"]}) == 2 and all("device" in x for x in ds["ranks"])
+    assert "collective_library" in ds

@@ -240,7 +240,7 @@ def test_gemm_nt_grouped_a1(L, variant):
     assert relerr(out, want) < 6e-3
 
 
-def test_gemm_nt_grouped_a1_split_k_tail(L):
+def test_gemm_nt_grouped_a1_partial_round_tail(L):
     """The benchmark's dT_qkv shape on ragged rows: N = 3r = 768 with one A1 column group per 256 outputs, 96 row tiles -> 288 tiles of
     256x256 = one full round + 32 tiles run as 8 K-slices each (the group offset and the K-slice offset of A1 must compose); also the
     deep-K one-round case (N = 256, K = 11008: 96 tiles as two slices each).  Against fp32 torch and the 128x128 kernel."""
@@ -943,13 +943,13 @@ def test_sampler_compact_tail_is_exact(L):
     mixed[:, :40] = 9.0                                                                     # 40 equal maxima: top-k 30 keeps all 40
     fin = torch.zeros(rows, dtype=torch.uint8, device=dev())
     fin[3] = 1
-    prev = os.environ.get("OPADPO_SAMPLE_COMPACT")
+    lib = L.load()
     try:
         for logits in (smooth, coarse, mixed):
             for top_k, top_p, temp in ((30, 0.95, 1.0), (30, 0.95, 0.1), (64, 0.5, 1.3), (5, 1.0, 0.7), (1, 0.9, 1.0), (30, 0.01, 1.0), (200, 0.9, 1.0)):
                 res = []
-                for compact in ("0", "1"):
-                    os.environ["OPADPO_SAMPLE_COMPACT"] = compact
+                for full_sweeps in (512, 0):                    # opadpo_set_flags use_tr bit 9
+                    lib.opadpo_set_flags(10, 1 | full_sweeps)
                     outs = []
                     for step in range(4):
                         out = torch.full((rows,), -5, dtype=torch.int32, device=dev())
@@ -961,10 +961,7 @@ def test_sampler_compact_tail_is_exact(L):
                 torch.cuda.synchronize()
                 assert torch.equal(res[0], res[1]), (top_k, top_p, temp)
     finally:
-        if prev is None:
-            os.environ.pop("OPADPO_SAMPLE_COMPACT", None)
-        else:
-            os.environ["OPADPO_SAMPLE_COMPACT"] = prev
+        lib.opadpo_set_flags(10, 1)
 
 
 def test_errors_are_loud(L):
@@ -997,7 +994,7 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
 
 @pytest.mark.parametrize("R,K,r,mode", [(17, 4096, 0, "bf16"), (17, 4096, 256, "f32"), (18, 4096, 256, "bf16_res"), (19, 2048, 0, "f32_res"),
                                          (22, 1024, 256, "bf16"), (22, 4096, 0, "alpha"), (33, 4096, 256, "bf16")])
-def test_gemm_nt_split_k_tail(L, R, K, r, mode):
+def test_gemm_nt_partial_round_tail_tiles(L, R, K, r, mode):
     """A partly filled last round of 256x256 tiles (R row tiles x 16 column tiles: 272 / 288 / 304 / 352 / 528 tiles) runs as quarter
     tiles on the 128x128 kernel (round 2 ran a split-K tail + reduce launch here; removed): every epilogue of the plain kernel
     (bf16 / fp32 out, bf16 / fp32 residual, alpha, K-concatenated LoRA tail, ragged last row tile) against fp32 torch, and BIT-EQUAL to the
@@ -1420,6 +1417,12 @@ def test_gemm_tn_group_deterministic_form(L, M):
     assert need_of(bad) == 0
     with pytest.raises(L.OpadpoError):
         L.call("opadpo_gemm_tn_group_det", *arrs(bad, [torch.zeros(256, 128, device=dev())]), ws.data_ptr(), need, L.stream())
+    # a MIXED list (one problem the 256x256 kernel cannot take among good ones) is refused too: its odd member would flush with fp32 atomics
+    # behind the deterministic entry point (round-4 review)
+    mixed = probs[:2] + bad
+    assert need_of(mixed) == 0
+    with pytest.raises(L.OpadpoError):
+        L.call("opadpo_gemm_tn_group_det", *arrs(mixed, [d1[0], d1[1], torch.zeros(256, 128, device=dev())]), ws.data_ptr(), need, L.stream())
 
 
 @pytest.mark.parametrize("seg", [(0, 0), (200, 140)])

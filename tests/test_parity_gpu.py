@@ -912,3 +912,39 @@ def test_merged_reference_adapter():
     print(f"merged-reference check: max |delta logp| merged vs K-concatenated {diff:.3e}; adapter effect {effect:.3e}")
     assert effect > 20 * diff, f"adapter effect {effect} vs merge error {diff}: the test would not see a dropped adapter"
     assert diff < 3e-2, f"merged vs K-concatenated reference log-probs differ by {diff}"
+
+
+def test_oracle_is_device_independent(setup):
+    """tests/test_fullsize_gpu.py evaluates oracle/llava_ref.py on the accelerator (three full-depth passes per model do not fit the
+    suite's time budget on host cores).  Same torch code, fp32, torch's own kernels: its fp32 result must be the CPU result to fp32
+    rounding, and its bf16-emulating result must sit within the emulation's own rounding noise of the CPU's."""
+    s = setup
+    LR, od = s["LR"], s["od"]
+    g = torch.Generator().manual_seed(5)
+    B, Q, T = 3, 24, 40
+    images = torch.randn(B, 3, od.image_size, od.image_size, generator=g)
+    queries = torch.randint(3, od.vocab, (B, Q), generator=g)
+    qmask = torch.ones(B, Q, dtype=torch.bool)
+    queries[1, :5] = 0; qmask[1, :5] = False
+    for b in range(B):
+        queries[b, 8 + b] = -200
+    resp = {}
+    for k in ("chosen_response", "rejected_response"):
+        ids = torch.randint(3, od.vocab, (B, T), generator=g)
+        ids[0, 30] = 2; ids[0, 31:] = 0
+        resp[k] = ids
+    dev = s["dev"]
+    Wd = {k: v.to(dev) for k, v in s["W"].items()}
+    ld = {k: v.to(dev) for k, v in s["lora_pol"].items()}
+    respd = {k: v.to(dev) for k, v in resp.items()}
+    with torch.no_grad():
+        for emu, tol_mean, tol_max in ((False, 2e-6, 5e-5), (True, 2e-3, 5e-2)):
+            c = LR.policy_forward(images, queries, qmask, resp, s["W"], s["lora_pol"], od, 1.0, emulate_bf16=emu)
+            a = LR.policy_forward(images.to(dev), queries.to(dev), qmask.to(dev), respd, Wd, ld, od, 1.0, emulate_bf16=emu)
+            for k in resp:
+                valid = resp[k] != 0
+                x, y = c[k + "_logprobs"], a[k + "_logprobs"].cpu()
+                assert bool((y[~valid] == 0).all())
+                rel = ((x - y).abs()[valid] / x.abs()[valid].clamp_min(1e-3)).double()
+                REPORT[f"oracle_device_{'emu' if emu else 'fp32'}_{k}"] = {"mean": float(rel.mean()), "max": float(rel.max())}
+                assert float(rel.mean()) < tol_mean and float(rel.max()) < tol_max, (emu, k, float(rel.mean()), float(rel.max()))
