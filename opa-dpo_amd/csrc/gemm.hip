@@ -381,6 +381,62 @@ constexpr int P_STAGE = 2 * P_TILE;              // A + B
 // together), yet same-box sustained runs (tools/ab_gemm.sh, 300 launches per shape) show a stable preference by shape:
 // N <= 4096 (o / down projection, every dgrad into the hidden width, the r-wide LoRA products) is 1.5-4 % faster B first, the wide
 // projections (q|k|v, gate|up, lm_head) 2.5-3 % faster A first.
+// wave-uniform copy of a pointer (both halves through readfirstlane): a base the compiler cannot prove uniform turns buffer accesses into waterfall loops
+__device__ __forceinline__ void* w4_uniform_ptr(const void* q) {
+  const unsigned long long v = (unsigned long long)q;
+  return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+// Direct epilogue of the 4-wave 256x256 kernels: accumulator layout acc[i][j][r] of lane (frow, fchk) = row i*16 + 4*fchk + r, column 8*frow + j of the
+// wave's 128x128 block (the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns).  No LDS, no barrier.
+__device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
+  // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
+  // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
+  // then held 4 columns of 16 rows: 32-byte pieces, 27 us per block.)
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+  const unsigned esz = p.out_f32 ? 4u : 2u;
+  const bool small = ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * esz < 0xffffffffull;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.C), 0, small ? (int)((unsigned)p.M * (unsigned)p.ldc * esz) : 0, 0x00020000);
+  const int mrow0 = m0 + wr * 128 + 4 * fchk, col = ncol0 + 8 * frow;
+  epi_dispatch_plain(p, [&](auto MD_) {
+    constexpr int md = decltype(MD_)::value;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v[8][4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc_read4(acc[i][j], v[j]);
+        epi_pre4<md>(p, 0, v[j]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mrow0 + i * 16 + r;
+        if (p.out_f32) {
+          u32x4s_t lo, hi;
+          lo[0] = __float_as_uint(v[0][r]); lo[1] = __float_as_uint(v[1][r]); lo[2] = __float_as_uint(v[2][r]); lo[3] = __float_as_uint(v[3][r]);
+          hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
+          if (small) {
+            const unsigned vo = ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 4u;
+            if (p.store_nt) { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 2); }
+            else { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 0); }
+          } else if (m < p.M) {
+            *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col) = lo;
+            *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col + 4) = hi;
+          }
+        } else {
+          u32x4s_t o;
+          o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
+          if (small) {
+            if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 2);
+            else __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 0);
+          }
+          else if (m < p.M) *(u32x4s_t*)((bf16_t*)p.C + (size_t)m * p.ldc + col) = o;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
+    }
+  });
+}
+
 #include "w4_kloop.inc"
 template <bool ORDER_B>
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
@@ -506,52 +562,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     const int ncol0 = n0 + wc * 128;
     const bool special = p.act == OPADPO_ACT_SWIGLU_PAIR || p.act == OPADPO_ACT_SWIGLU_BWD || ((p.rope_pos || p.rope_cos) && n0 < p.rope_cols);
     if (!p.R && !special) {
-      // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
-      // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
-      // then held 4 columns of 16 rows: 32-byte pieces, 27 us per block.)
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
-      const unsigned esz = p.out_f32 ? 4u : 2u;
-      const bool small = ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * esz < 0xffffffffull;
-      const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(uni(p.C), 0, small ? (int)((unsigned)p.M * (unsigned)p.ldc * esz) : 0, 0x00020000);
-      const int mrow0 = m0 + wr * 128 + 4 * fchk, col = ncol0 + 8 * frow;
-      epi_dispatch_plain(p, [&](auto MD_) {
-        constexpr int md = decltype(MD_)::value;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float v[8][4];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            acc_read4(acc[i][j], v[j]);
-            epi_pre4<md>(p, 0, v[j]);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mrow0 + i * 16 + r;
-            if (p.out_f32) {
-              u32x4s_t lo, hi;
-              lo[0] = __float_as_uint(v[0][r]); lo[1] = __float_as_uint(v[1][r]); lo[2] = __float_as_uint(v[2][r]); lo[3] = __float_as_uint(v[3][r]);
-              hi[0] = __float_as_uint(v[4][r]); hi[1] = __float_as_uint(v[5][r]); hi[2] = __float_as_uint(v[6][r]); hi[3] = __float_as_uint(v[7][r]);
-              if (small) {
-                const unsigned vo = ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 4u;
-                if (p.store_nt) { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 2); }
-                else { __builtin_amdgcn_raw_buffer_store_b128(lo, rC, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(hi, rC, vo + 16u, 0, 0); }
-              } else if (m < p.M) {
-                *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col) = lo;
-                *(u32x4s_t*)((float*)p.C + (size_t)m * p.ldc + col + 4) = hi;
-              }
-            } else {
-              u32x4s_t o;
-              o[0] = pack_bf2(v[0][r], v[1][r]); o[1] = pack_bf2(v[2][r], v[3][r]); o[2] = pack_bf2(v[4][r], v[5][r]); o[3] = pack_bf2(v[6][r], v[7][r]);
-              if (small) {
-                if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 2);
-                else __builtin_amdgcn_raw_buffer_store_b128(o, rC, ((unsigned)m * (unsigned)p.ldc + (unsigned)col) * 2u, 0, 0);
-              }
-              else if (m < p.M) *(u32x4s_t*)((bf16_t*)p.C + (size_t)m * p.ldc + col) = o;
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);      // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
-        }
-      });
+      w4_direct_epilogue(p, acc, m0, ncol0, wr, frow, fchk);
       return;
     }
     // Staged epilogues (residual operand, SwiGLU pair / backward, rotary embedding): each wave passes its 128x128 block through its own
@@ -800,6 +811,126 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     });
   };
   staged_epi();
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_nt "w4s" kernel (round 5): the 4-wave 256x256 kernel as a STREAMING persistent kernel for the plain products (alpha-only, bf16 or fp32
+// out, no residual / activation / rotary epilogue - those need the LDS stages for staging).  One workgroup per CU walks the tiles b, b + grid,
+// b + 2 grid, .. of the same XCD-aware tile order; the K-tile stream never drains at an output-tile boundary: the last two K-tiles of a tile fetch
+// K-tiles 0 and 1 of the NEXT tile, the last one reads the next tile's first fragments, and the (direct, LDS-free) epilogue stores the finished
+// tile while those pieces fly.  What a tile of the one-tile-per-workgroup kernel pays besides its K-loop - workgroup dispatch, address set-up,
+// the 2-K-tile pipeline fill with nothing to compute, the drain - is paid once per workgroup instead of once per tile.  The stores are issued
+// AFTER the next tile's first pieces, so the in-order vmcnt waits of the next tile's loop never sit behind a store that has not been issued yet (what
+// sank the round-4 persistent kernel).  Bit-identical to gemm_nt_w4_kernel (same k order; tests/test_ops_gpu.py).  Needs K1 >= 3 K-tiles.
+// ------------------------------------------------------------------------------------------
+template <bool ORDER_B>
+__global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
+  const int width = p.group_m * tiles_n;
+  auto tile_of = [&](int b, int& m0, int& n0) {
+    const int swz = xcd_remap(b, n_tiles);
+    const int group_id = swz / width;
+    const int first_m = group_id * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
+    m0 = __builtin_amdgcn_readfirstlane((first_m + (swz % width) % gsz) * P_BM);
+    n0 = __builtin_amdgcn_readfirstlane(((swz % width) / gsz) * P_BN);
+  };
+  const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK;
+  const int srow = lane >> 3, spos = lane & 7;
+  const unsigned lrow = (unsigned)(wave * 64 + srow);
+  const unsigned csw[2] = {(unsigned)((spos ^ ((srow >> 1) & 7)) * 16), (unsigned)((spos ^ ((4 + (srow >> 1)) & 7)) * 16)};
+  const unsigned lrowB_lo = (unsigned)((srow & 1) * 8 + (srow & 6));
+  const unsigned m_last = (unsigned)(p.M - 1);
+  auto calc_voff = [&](bool second, int m0, int n0, unsigned (&vo)[16]) {      // as in gemm_nt_w4_kernel: vo[0..7] B pieces, vo[8..15] A pieces
+    const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi) {
+      vo[8 + pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
+      vo[pi] = ((unsigned)n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb + (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
+    }
+  };
+  auto lo32 = [](const void* q) { return __builtin_amdgcn_readfirstlane((int)(unsigned long long)q); };
+  auto hi16 = [](const void* q) { return __builtin_amdgcn_readfirstlane((int)(((unsigned long long)q >> 32) & 0xffffu)); };
+  auto a1_of = [&](int n0) -> const bf16_t* { return p.a1_group_n > 0 ? p.A1 + (size_t)(n0 / p.a1_group_n) * p.a1_group_stride : p.A1; };
+  auto a2_of = [&](int n0) -> const bf16_t* { if (!nt2) return a1_of(n0); return p.a2_group_n > 0 ? p.A2 + (size_t)(n0 / p.a2_group_n) * p.a2_group_stride : p.A2; };
+  if (__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)LDS_PTR(void, smem)) != 0) __builtin_trap();
+
+  int b = blockIdx.x, m0, n0;
+  tile_of(b, m0, n0);
+  unsigned w4k_vo[16];
+  calc_voff(false, m0, n0, w4k_vo);
+  {   // pipeline fill, once per workgroup: K-tiles 0 and 1 of the first tile (K1 >= 3 K-tiles: both from the first operand pair)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(a1_of(n0)), 0, (int)0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.B1), 0, (int)0xffffffffu, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        char* base = smem + t * P_STAGE;
+        const int piece = wave * 8 + (q & 7);
+        if (q < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(void, base + piece * 1024), 16, w4k_vo[8 + q], t * P_BK * 2, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_PTR(void, base + P_TILE + piece * 1024), 16, w4k_vo[q - 8], t * P_BK * 2, 0, 0);
+      }
+  }
+  f32x4_t acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t w4k_fr[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f) w4k_fr[f] = bf16x8_t{};
+  const int frow = lane & 15, fchk = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const unsigned offA = (unsigned)((wr * 128 + frow) * 128), offB = (unsigned)(P_TILE + (wc * 128 + (frow >> 1) * 16 + (frow & 1)) * 128);
+  const unsigned cb0 = (unsigned)((fchk ^ fsw) << 4), cb1 = (unsigned)(((4 + fchk) ^ fsw) << 4);
+  unsigned w4k_rb[4] = {offB + cb0, offB + cb1, offA + cb0, offA + cb1};
+  int w4k_dx[4] = {lo32(p.B1), hi16(p.B1), -1, 0x00020000};
+  int w4k_dy[4] = {lo32(a1_of(n0)), hi16(a1_of(n0)), -1, 0x00020000};
+  int w4k_stg = 0;
+  int w4k_koff = 128;                                          // K byte offset of the tile fetched last (the loop adds 128 before its first piece)
+  int w4k_pcx[8], w4k_pcy[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    w4k_pcy[q] = __builtin_amdgcn_readfirstlane((wave * 8 + q) * 1024);
+    w4k_pcx[q] = __builtin_amdgcn_readfirstlane(P_TILE + (wave * 8 + q) * 1024);
+  }
+  int w4k_first = 1;
+  for (;;) {
+    const int nb = b + (int)gridDim.x;
+    // 1 = there is a next tile (s37 of the streaming text).  Computed on the scalar unit by hand: hipcc lowers the select of this uniform compare
+    // through a vector register, which the scalar asm operand below cannot take ("illegal VGPR to SGPR copy")
+    int w4k_has2;
+    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(w4k_has2) : "s"(nb), "s"(n_tiles) : "scc");
+    int m0n = m0, n0n = n0;
+    if (w4k_has2) tile_of(nb, m0n, n0n);
+    unsigned w4k_vo2[16], w4k_vo3[16];
+    calc_voff(true, m0, n0, w4k_vo2);                          // second operand pair of THIS tile (the K-concatenated LoRA tail)
+    calc_voff(false, m0n, n0n, w4k_vo3);                       // first operand pair of the NEXT tile
+    const void* pb2 = nt2 ? (const void*)p.B2 : (const void*)p.B1;
+    const int w4k_dx2[4] = {lo32(pb2), hi16(pb2), -1, 0x00020000};
+    const int w4k_dy2[4] = {lo32(a2_of(n0)), hi16(a2_of(n0)), -1, 0x00020000};
+    const int w4k_dx3[4] = {lo32(p.B1), hi16(p.B1), -1, 0x00020000};
+    const int w4k_dy3[4] = {lo32(a1_of(n0n)), hi16(a1_of(n0n)), -1, 0x00020000};
+    int w4k_na = __builtin_amdgcn_readfirstlane(nt1 - 3), w4k_nb = __builtin_amdgcn_readfirstlane(nt2);
+    // (loop-carried scalars: stated wave-uniform once more, or the PHIs of the tile loop end up in vector registers)
+    w4k_stg = __builtin_amdgcn_readfirstlane(w4k_stg); w4k_koff = __builtin_amdgcn_readfirstlane(w4k_koff);
+    w4k_first = __builtin_amdgcn_readfirstlane(w4k_first);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { w4k_dx[q] = __builtin_amdgcn_readfirstlane(w4k_dx[q]); w4k_dy[q] = __builtin_amdgcn_readfirstlane(w4k_dy[q]); }
+    if constexpr (ORDER_B) W4S_RUN(W4S_TEXT_BFIRST);
+    else W4S_RUN(W4S_TEXT_AFIRST);
+    __builtin_amdgcn_sched_barrier(0);
+    w4_direct_epilogue(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!w4k_has2) break;
+    b = nb; m0 = m0n; n0 = n0n;
+    w4k_first = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1817,11 +1948,21 @@ bool opadpo_flag_tr() { return g_use_tr; }
 
 // piece order of the 4-wave 256x256 kernel by shape (see gemm_nt_w4_kernel): B half first for N <= 16 column tiles
 static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B first (experiments)
+// Streaming form (gemm_nt_w4s_kernel, round 5) for the plain products whenever every workgroup gets at least two tiles: one workgroup per CU walks
+// the tile list and keeps its K-tile pipeline full across output tiles.  OPADPO_W4S=0 / variant 31: one tile per workgroup (A/B, cross-check).
+static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
-    if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                         \
-    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                            \
+    const int grid_ = (GRID_);                                                                                               \
+    const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.R && !a.bias && a.act == 0 && !a.rope_cos && !a.rope_pos && \
+                         a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * g_w4s_cus;                         \
+    if (stream_) {                                                                                                           \
+      if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(g_w4s_cus), dim3(256), 2 * P_STAGE, st, a, grid_);           \
+      else hipLaunchKernelGGL(gemm_nt_w4s_kernel<false>, dim3(g_w4s_cus), dim3(256), 2 * P_STAGE, st, a, grid_);              \
+    }                                                                                                                        \
+    else if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                   \
+    else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                            \
   } while (0)
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
@@ -1849,6 +1990,14 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    {
+      int dev_ = 0; hipDeviceProp_t pr_;
+      g_w4s_cus = (hipGetDevice(&dev_) == hipSuccess && hipGetDeviceProperties(&pr_, dev_) == hipSuccess) ? pr_.multiProcessorCount : 256;
+      g_w4s = getenv("OPADPO_W4S") ? atoi(getenv("OPADPO_W4S")) : 1;
+      if (getenv("OPADPO_W4S_MAXNT")) g_w4s_maxnt = atoi(getenv("OPADPO_W4S_MAXNT"));
+    }
     (void)hipFuncSetAttribute((const void*)gemm_nt_tail64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_tail64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);

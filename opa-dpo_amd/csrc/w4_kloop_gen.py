@@ -31,10 +31,11 @@ def frag_reg(op, kk, f):
     return f"v[{base + 4 * f}:{base + 4 * f + 3}]"
 
 
-def mfma(k):
+def mfma(k, zero_c=False):
     kk, i, j = k // 64, (k % 64) // 8, k % 8
     a = 4 * (8 * i + j)
-    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {frag_reg('Y', kk, i)}, {frag_reg('X', kk, j)}, a[{a}:{a + 3}]"
+    c = "0" if zero_c else f"a[{a}:{a + 3}]"
+    return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {frag_reg('Y', kk, i)}, {frag_reg('X', kk, j)}, {c}"
 
 
 def slots_r5(first="X", spread_end=True, early_release=False, period=4):
@@ -137,8 +138,12 @@ def rd(op, kk, f):
 
 
 def tile_text(slots, piece_ops, mode):
-    """mode 'loop': steady state; 'tail_a': tile nt - 2 (no pieces, the landing wait is vmcnt(0)); 'tail_b': the last tile (no reads of a next tile)"""
+    """mode 'loop': steady state; 'first': K-tile 0 of an output tile of the streaming kernel (a steady-state tile whose first MFMA on every accumulator
+    starts from 0, outside the counted loop); 'tail_a': tile nt - 2 (no pieces, the landing wait is vmcnt(0)); 'tail_b': the last tile (no reads of a next tile)"""
     out = []
+    first = mode == "first"
+    if first:
+        mode = "loop"
     for k in range(129):
         for it in slots[k]:
             if it[0] == "rd":
@@ -177,12 +182,12 @@ def tile_text(slots, piece_ops, mode):
             else:
                 raise ValueError(it)
         if k < 128:
-            out.append(mfma(k))
-            if mode == "loop" and k == 125:
+            out.append(mfma(k, zero_c=first and k < 64))
+            if mode == "loop" and not first and k == 125:
                 out.append("s_sub_u32 s39, s39, 1")
-            if mode == "loop" and k == 126:
+            if mode == "loop" and not first and k == 126:
                 out.append("s_cmp_lg_u32 s39, 0")
-    if mode == "loop":
+    if mode == "loop" and not first:
         out.append("s_cbranch_scc1 1b")
     return out
 
@@ -215,12 +220,55 @@ def block_text(first):
     return t
 
 
+def switch_text(tag):
+    """addresses, descriptors and K origin of the operand pair fetched next (generic operands vo<tag>_p, dx<tag>_q, dy<tag>_q)"""
+    t = [f"v_mov_b32_e32 v{140 + p}, %[vo{tag}_{p}]" for p in range(16)]
+    t += [f"s_mov_b32 s{40 + q}, %[dx{tag}_{q}]" for q in range(4)] + [f"s_mov_b32 s{44 + q}, %[dy{tag}_{q}]" for q in range(4)]
+    t += ["s_mov_b32 s49, -128"]                          # the loop adds 128 before its first piece: K-tile 0 of the new pair
+    return t
+
+
+def stream_text(first):
+    """One OUTPUT tile of the streaming (persistent) kernel gemm_nt_w4s_kernel: the K-tile stream never drains at an output-tile boundary - the last two
+    K-tiles of a tile fetch K-tiles 0 and 1 of the workgroup's NEXT output tile, its last K-tile reads the next tile's first fragments, then the (C++)
+    epilogue stores this tile while those pieces are in flight.  K-tiles: FIRST (t = 0, accumulators start from 0) | s39 x LOOP from the first pair |
+    switch, s38 x LOOP from the second pair (K-concatenated LoRA tail) | switch to the next tile's first pair, 2 x LOOP - or, on the workgroup's last tile
+    (s37 = 0), the two draining tails.  s36 = 1 on the workgroup's first tile (wait for K-tile 0, read its fragments).  Needs K1 >= 3 K-tiles."""
+    slots = slots_r5(first=first)
+    po = piece_order(first)
+    check_slots(slots, po)
+    t = ["s_cmp_eq_u32 s36, 0", "s_cbranch_scc1 8f", "s_waitcnt vmcnt(16)", "s_barrier"]
+    for op in ("X", "Y"):
+        for f in range(8):
+            t.append(rd(op, 0, f))
+    t += ["s_waitcnt lgkmcnt(0)", "8:"]
+    t += tile_text(slots, po, "first")
+    t += ["s_mov_b32 s35, 0", "s_cmp_eq_u32 s39, 0", "s_cbranch_scc1 3f", "1:"]
+    t += tile_text(slots, po, "loop")
+    t += ["3:", "s_cmp_lg_u32 s35, 0", "s_cbranch_scc1 4f",
+          "s_mov_b32 s35, 1", "s_cmp_eq_u32 s38, 0", "s_cbranch_scc1 4f"]
+    t += switch_text("2") + ["s_mov_b32 s39, s38", "s_branch 1b"]
+    t += ["4:", "s_cmp_lg_u32 s35, 1", "s_cbranch_scc1 9f",
+          "s_mov_b32 s35, 2", "s_cmp_eq_u32 s37, 0", "s_cbranch_scc1 6f"]
+    t += switch_text("3") + ["s_mov_b32 s39, 2", "s_branch 1b"]
+    t += ["6:"]
+    t += tile_text(slots, po, "tail_a")
+    t += tile_text(slots, po, "tail_b")
+    t += ["9:", "s_nop 15", "s_nop 15", "s_nop 15", "s_nop 15"]
+    return t
+
+
 def main():
     L = []
     L.append("// GENERATED by opa-dpo_amd/csrc/w4_kloop_gen.py - do not edit; re-run the generator after changing it.")
     L.append("// K-loop of gemm_nt_w4_kernel as one asm block (register plan, schedule and its hazard checks: see the generator).")
     for first, name in (("X", "W4K_TEXT_BFIRST"), ("Y", "W4K_TEXT_AFIRST")):
         txt = block_text(first)
+        L.append(f"#define {name} \\")
+        L += ['  "' + l + '\\n" \\' for l in txt]
+        L.append('  ""')
+    for first, name in (("X", "W4S_TEXT_BFIRST"), ("Y", "W4S_TEXT_AFIRST")):
+        txt = stream_text(first)
         L.append(f"#define {name} \\")
         L += ['  "' + l + '\\n" \\' for l in txt]
         L.append('  ""')
@@ -247,6 +295,16 @@ def main():
     wrap("W4K_INS", ins)
     wrap("W4K_CLOBBERS", clob)
     L.append("#define W4K_RUN(TEXT) asm volatile(TEXT : W4K_OUTS : W4K_INS : W4K_CLOBBERS)")
+    # streaming kernel: the fragments of k-half 0 (v[4:67]) live across the C++ epilogue between two output tiles -> in/out operands, not clobbers
+    s_outs = list(outs) + [f'"+{{v[{4 + 4 * f}:{7 + 4 * f}]}}"(w4k_fr[{f}])' for f in range(16)]
+    s_ins = [x for x in ins if "koff2" not in x] + ['"{s36}"(w4k_first)']
+    s_ins += [f'[vo3_{p}] "v"(w4k_vo3[{p}])' for p in range(16)]
+    s_ins += [f'[dx3_{q}] "s"(w4k_dx3[{q}])' for q in range(4)] + [f'[dy3_{q}] "s"(w4k_dy3[{q}])' for q in range(4)]
+    s_clob = [f'"v{i}"' for i in range(68, 132)] + ['"s35"', '"memory"', '"scc"']
+    wrap("W4S_OUTS", s_outs)
+    wrap("W4S_INS", s_ins)
+    wrap("W4S_CLOBBERS", s_clob)
+    L.append("#define W4S_RUN(TEXT) asm volatile(TEXT : W4S_OUTS : W4S_INS : W4S_CLOBBERS)")
     out = os.path.join(HERE, "w4_kloop.inc")
     text = "\n".join(L) + "\n"
     if "--check" in os.sys.argv:
