@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -822,7 +823,26 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
 // the 2-K-tile pipeline fill with nothing to compute, the drain - is paid once per workgroup instead of once per tile.  The stores are issued
 // AFTER the next tile's first pieces, so the in-order vmcnt waits of the next tile's loop never sit behind a store that has not been issued yet (what
 // sank the round-4 persistent kernel).  Bit-identical to gemm_nt_w4_kernel (same k order; tests/test_ops_gpu.py).  Needs K1 >= 3 K-tiles.
+// Where a tile's cycles go (OPADPO_W4S_DIAG build + tools/w4s_diag.py, profiles/r05c_w4s_tile_anatomy.txt; K = 4096, wave 0): K-loop 139 k
+// (2.18 k per K-tile), epilogue 7.7 k for a bf16 tile and 13-21 k for an fp32 tile, per-tile set-up 1.4 k.  The epilogue is the CU's STORE rate -
+// 128 KiB per tile at ~17 B per cycle and CU (the ~35 GB/s per-CU vector-memory figure of the decode kernels) - not a chip-wide write burst:
+// starting the workgroups of an XCD in 2-8 phases up to a burst apart changed nothing for bf16 tiles (7.74 k in every variant; built, measured,
+// removed).  Hiding it needs the finished tile parked somewhere for ~4 K-tiles; registers (256 accumulators + 128 fragment registers) and LDS
+// (2 x 64 KiB stages) are both full.
 // ------------------------------------------------------------------------------------------
+#ifndef OPADPO_W4S_DIAG
+#define OPADPO_W4S_DIAG 0
+#endif
+#if OPADPO_W4S_DIAG
+// diagnostics build (tools/build_diag.sh w4sdiag:"-DOPADPO_W4S_DIAG=1"): cycles of wave 0 of every workgroup spent in [0] the K-loop block, [1] the epilogue,
+// [2] the per-tile set-up between them, [3] tiles - summed over the launch; read with opadpo_debug_w4s_read
+__device__ unsigned long long g_w4s_diag[4];
+extern "C" int opadpo_debug_w4s_read(unsigned long long* out4, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_w4s_diag), 32);
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w4s_diag), z, 32); }
+  return (int)e;
+}
+#endif
 template <bool ORDER_B>
 __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -900,6 +920,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
     w4k_pcx[q] = __builtin_amdgcn_readfirstlane(P_TILE + (wave * 8 + q) * 1024);
   }
   int w4k_first = 1;
+#if OPADPO_W4S_DIAG
+  unsigned long long dg_asm = 0, dg_epi = 0, dg_glue = 0, dg_n = 0, dg_t = __builtin_readcyclecounter();
+#endif
   for (;;) {
     const int nb = b + (int)gridDim.x;
     // 1 = there is a next tile (s37 of the streaming text).  Computed on the scalar unit by hand: hipcc lowers the select of this uniform compare
@@ -922,15 +945,27 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
     w4k_first = __builtin_amdgcn_readfirstlane(w4k_first);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { w4k_dx[q] = __builtin_amdgcn_readfirstlane(w4k_dx[q]); w4k_dy[q] = __builtin_amdgcn_readfirstlane(w4k_dy[q]); }
+#if OPADPO_W4S_DIAG
+    { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); dg_glue += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#endif
     if constexpr (ORDER_B) W4S_RUN(W4S_TEXT_BFIRST);
     else W4S_RUN(W4S_TEXT_AFIRST);
     __builtin_amdgcn_sched_barrier(0);
+#if OPADPO_W4S_DIAG
+    { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
+#endif
     w4_direct_epilogue(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     __builtin_amdgcn_sched_barrier(0);
+#if OPADPO_W4S_DIAG
+    { const unsigned long long t_ = __builtin_readcyclecounter(); dg_epi += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
+#endif
     if (!w4k_has2) break;
     b = nb; m0 = m0n; n0 = n0n;
     w4k_first = 0;
   }
+#if OPADPO_W4S_DIAG
+  if (tid == 0) { atomicAdd(&g_w4s_diag[0], dg_asm); atomicAdd(&g_w4s_diag[1], dg_epi); atomicAdd(&g_w4s_diag[2], dg_glue); atomicAdd(&g_w4s_diag[3], dg_n); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
