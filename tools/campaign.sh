@@ -21,7 +21,7 @@ bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1; cp $R/gpurun_out/pmc_bench.json
 if [ "${LIGHT:-0}" != "1" ]; then PMC_V=1 GB_MODE=attn2 bash tools/pmc_attn32.sh > $O/pmc_attn.log 2>&1; cp $R/gpurun_out/pmc_attn32.json $O/pmc_attn_sq.json; fi
 python bench.py --steps 220 --warmup 5 --sustained --no-rollout --no-side-legs --no-cpu-baseline --no-exchange-probe > $O/sustained.json 2> $O/sustained.err
 python -c "import json;r=json.load(open('$O/sustained.json'));s=r['sustained'];print('sustained', r['value'], s['pairs_per_s_first_20'], s['pairs_per_s_last_20'], s['sclk_mhz'], s['power_w'])"
-if [ "${LIGHT:-0}" != "1" ]; then OPADPO_P7_EMU=1 python -m pytest tests/test_fullsize_gpu.py -x -q -m gpu -k p7 > $O/p7.log 2>&1; tail -2 $O/p7.log; cp $R/gpurun_out/parity_fulldepth.json $O/parity_fulldepth.json; fi
+if [ "${LIGHT:-0}" != "1" ]; then python -m pytest tests/test_fullsize_gpu.py -x -q -m gpu -k p7 > $O/p7.log 2>&1; tail -2 $O/p7.log; cp $R/gpurun_out/parity_fulldepth.json $O/parity_fulldepth.json; fi
 python bench.py --model 13b --steps 6 --warmup 2 --no-rollout --no-side-legs --no-exchange-probe > $O/bench_13b.json 2> $O/bench_13b.err
 python -c "import json;r=json.load(open('$O/bench_13b.json'));print('13b', r['value'], r['ms_per_step'], r['hbm_peak_allocated_GB'])"
 GB_M=24576 python tools/gemm_bench.py > $O/gemm_bench.txt 2>/dev/null      # per shape: this library's kernels and the vendor GEMM (torch.matmul -> hipBLASLt) side by side
