@@ -1,8 +1,8 @@
 #!/bin/bash
 # Experiment / diagnostic builds of the library: gemm.hip compiled with extra -D flags, everything else from opa-dpo_amd/build/*.o
 #   tools/build_diag.sh name1:"-DFLAG=1 -DOTHER=2" name2:"..."      ->  opa-dpo_amd/lib/libopadpo_hip_<name>.so
-#   OPADPO_W4_DIAG=<bits>: a stall source of the 256x256 GEMM K-loop removed (results WRONG, only the timing means something)
-#   OPADPO_W4_SCHED=<n>:   slot schedule of the K-tile (see w4_slot in gemm.hip)
+#   OPADPO_W4S_DIAG=1:    per-tile cycle accounting of the streaming 256x256 GEMM (K-loop / epilogue / set-up; read with tools/w4s_diag.py)
+#   (the K-loop itself is generated text since round 5: schedule experiments go through tools/micro/kloop_bisect_gen.py, not through -D flags)
 # then   tools/ab_gemm.sh new name1 name2 ...   /   tools/pmc_diag.sh new name1 ...
 R=$(cd "$(dirname "$0")/.." && pwd)
 python $R/opa-dpo_amd/build.py > /dev/null || exit 1
