@@ -53,7 +53,8 @@ const char* opadpo_last_error(void);
  * M <= 16 (default there: the whole-cache-line 8-row form), bits 5-6 = kernel behind opadpo_gemm_nt_decode (0 = the library's choice,
  * 1 = the LDS-ring kernel of rounds 2-4, 3 = the whole-line streaming kernel gemm_nt_dec64x = the library's choice; A/B runs and tests), bits 7-8 = weight rows per workgroup of that kernel (0 = by shape, 1 / 2 / 3 =
  * 48 / 64 / 128 rows; tests), bit 9 = opadpo_sample runs its full vocabulary sweeps instead of the one-wave tail on the kept tokens (identical draws; the
- * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree). */
+ * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree), bit 10 = the streaming 256x256 GEMM runs on 8
+ * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------

@@ -1969,6 +1969,7 @@ static int g_dec64_variant = getenv("OPADPO_DEC64_V") ? atoi(getenv("OPADPO_DEC6
 static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 8-wave 256x256 kernel (p8); 31: 4-wave 256x256 kernel (w4) forced; 15: M <= 64 streaming
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
+static bool g_w4s_few = false;      // opadpo_set_flags use_tr bit 10 (tests): 8 workgroups walk the tile list, so small problems exercise long walks
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
@@ -1977,6 +1978,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_skinny8 = (use_tr & 16) == 0;
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
   opadpo_set_sample_compact((use_tr & 512) == 0);
+  g_w4s_few = (use_tr & 1024) != 0;
   g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
 bool opadpo_flag_tr() { return g_use_tr; }
@@ -1989,12 +1991,12 @@ static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
-    const int grid_ = (GRID_);                                                                                               \
+    const int grid_ = (GRID_), cus_ = g_w4s_few ? 8 : g_w4s_cus;                                                             \
     const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.R && !a.bias && a.act == 0 && !a.rope_cos && !a.rope_pos && \
-                         a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * g_w4s_cus;                         \
+                         a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
     if (stream_) {                                                                                                           \
-      if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(g_w4s_cus), dim3(256), 2 * P_STAGE, st, a, grid_);           \
-      else hipLaunchKernelGGL(gemm_nt_w4s_kernel<false>, dim3(g_w4s_cus), dim3(256), 2 * P_STAGE, st, a, grid_);              \
+      if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                \
+      else hipLaunchKernelGGL(gemm_nt_w4s_kernel<false>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                   \
     }                                                                                                                        \
     else if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                   \
     else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                            \

@@ -195,6 +195,39 @@ def test_gemm_nt_256_kernels_race_screen(L):
     assert relerr(outs[17], want) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K1,K2,f32,alpha", [(1100, 1024, 192, 0, False, 1.0),      # 5 x 4 tiles on 8 workgroups: walks of 2-3 tiles, K1 = 3 K-tiles (FIRST + the two hand-over tiles only)
+                                                 (1100, 1024, 256, 64, True, 1.0),       # + one K-tile of the LoRA tail, fp32 out (64 stores per wave behind the next tile's pieces)
+                                                 (2049, 768, 512, 256, False, 0.5),      # 9 x 3 = 27 tiles (3.4 per workgroup), ragged last row tile, alpha epilogue, 4 tail K-tiles
+                                                 (4096, 2048, 1024, 0, False, 1.0),      # 128 tiles = 16 per workgroup, N <= 16 column tiles -> B pieces first
+                                                 (700, 5120, 320, 128, True, 1.0)])      # 3 x 20 tiles, N > 16 column tiles -> A pieces first, K1 = 5
+def test_gemm_nt_streaming_kernel_equals_one_tile_per_workgroup(L, M, N, K1, K2, f32, alpha):
+    """gemm_nt_w4s_kernel (round 5: one workgroup walks many output tiles with the K-tile pipeline kept full across them) against the
+    one-tile-per-workgroup kernel (variant 31) and the 128x128 kernel (variant 4): same k order -> BIT-identical, for every way a walk
+    can go - first tile / middle tiles / last tile of a workgroup, with and without the second operand pair, the shortest K that streams
+    (3 K-tiles), fp32 and bf16 stores, workgroups with different tile counts, both piece orders.  opadpo_set_flags use_tr bit 10 runs the walk on
+    8 workgroups so that these small problems stream at all (>= 2 tiles per workgroup); repeated to catch a schedule race."""
+    lib = L.load()
+    a1, b1 = rnd(M, K1, seed=31), rnd(N, K1, scale=0.05, seed=32)
+    a2, b2 = (rnd(M, K2, seed=33), rnd(N, K2, scale=0.05, seed=34)) if K2 else (None, None)
+    dt = torch.float32 if f32 else BF
+    outs = {}
+    try:
+        for rep in range(3):
+            for key, variant, flags in (("stream8", 10, 1 | 1024), ("one_tile", 31, 1), ("k128", 4, 1)):
+                lib.opadpo_set_flags(variant, flags)
+                o = torch.full((M, N), 7.0, dtype=dt, device=dev())
+                L.gemm_nt(a1, b1, o, a2=a2, b2=b2, alpha=alpha)
+                torch.cuda.synchronize()
+                if key in outs:
+                    assert torch.equal(outs[key], o), f"{key} not reproducible (run {rep})"
+                outs[key] = o
+    finally:
+        lib.opadpo_set_flags(10, 1)
+    assert torch.equal(outs["stream8"], outs["one_tile"]) and torch.equal(outs["one_tile"], outs["k128"])
+    want = alpha * (a1.float() @ b1.float().t() + (a2.float() @ b2.float().t() if K2 else 0.0))
+    assert relerr(outs["stream8"].float(), want) < (2e-5 if f32 else 6e-3)
+
+
 @pytest.mark.parametrize("variant", [4, 17, 31, 10])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):
