@@ -304,7 +304,10 @@ def emit(slots, L, D, piece_ops, extra_valu=True, loop_label="1", count_reg="s39
 CPP_SETUP = r"""
   const int lane = threadIdx.x & 63, wave = rfl(threadIdx.x >> 6);
   int tm, tn; tile_of(tm, tn);
-  const u64 xb = (u64)(B + (size_t)tn * 256 * ld), yb = (u64)(A + (size_t)tm * 256 * ld);
+  // K-start stagger experiment: the low 7 bits of `ld` = K-tiles by which consecutive column tiles are shifted (0 = everyone starts at k = 0)
+  const int stag = ld & 127; ld &= ~127;
+  const size_t koff0 = (size_t)((tn & 7) * stag) * 128;
+  const u64 xb = (u64)(B + (size_t)tn * 256 * ld + koff0), yb = (u64)(A + (size_t)tm * 256 * ld + koff0);
   const unsigned xlo = rfl((int)xb), xhi = rfl((int)(xb >> 32)), ylo = rfl((int)yb), yhi = rfl((int)(yb >> 32));
   const int wr = wave >> 1, wc = wave & 1, srow = lane >> 3, spos = lane & 7, frow = lane & 15, fchk = lane >> 4, fsw = (frow >> 1) & 7;
 """
