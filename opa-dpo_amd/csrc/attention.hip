@@ -512,6 +512,9 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
   }
 }
 
+#ifndef OPADPO_ATTN_ABL
+#define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging
+#endif
 __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 128, TILE = 64 * HD * 2;            // 16 KiB per K or V tile; ring: [K0 | V0 | K1 | V1]
@@ -591,9 +594,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     const char* const Ks = smem + cur * 2 * TILE;
     const char* const Vs = Ks + TILE;
     const uint8_t* const Ms = ms_base + cur * 80;
-    __syncthreads();                                      // tile kt is in LDS for everyone; everyone has left the other buffer
+    if (!(OPADPO_ATTN_ABL & 8)) __syncthreads();          // tile kt is in LDS for everyone; everyone has left the other buffer
     char* const nb = smem + (cur ^ 1) * 2 * TILE;
-    if (nxt < n_kt) tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
+    if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
     // tiles none of this wave's rows can see: beyond its causal diagonal, or wholly inside the responses its rows exclude
     const bool dead = !wave_live || (p.causal && k0 > qhi) || (k0 >= xlo && k0 + 63 < xhi_first);
     f32x16_t sc[2];
@@ -617,18 +620,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
         for (int ks = 0; ks < 8; ++ks) {
           if (ks + PF < 8) { kfr[(ks + PF) % (PF + 1)][0] = kread(ks + PF, 0); kfr[(ks + PF) % (PF + 1)][1] = kread(ks + PF, 1); }
           __builtin_amdgcn_sched_barrier(0);
+          if (!(OPADPO_ATTN_ABL & 4)) {
           sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks % (PF + 1)][0], qf[ks], sc[0], 0, 0, 0);
           sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks % (PF + 1)][1], qf[ks], sc[1], 0, 0, 0);
+          } else { asm volatile("" :: "v"(kfr[ks % (PF + 1)][0]), "v"(kfr[ks % (PF + 1)][1])); }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (nxt < n_kt) {                                     // the other buffer is free since this iteration's barrier
+    if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) {          // the other buffer is free since this iteration's barrier
       tile_commit_k32(nb, kreg, tid);
       tile_fetch<HD>(kreg, vsrc, p.ld, nxt * 64);
     }
     if (!dead) {
       // sc[kb][r] = S^T[key = k0 + kb*32 + 8*(r >> 2) + 4*hi + (r & 3)][q = qpos], raw (unscaled) scores
+      if (!(OPADPO_ATTN_ABL & 1)) {
       const bool clean = !Ms[64] && (!p.causal || k0 + 63 <= qlo) && (k0 + 63 < xlo || k0 >= xhi_last);
       float mx = -INFINITY;
       if (clean) {
@@ -689,6 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           ps2 += e;
         }
       l_run += ps2[0] + ps2[1];
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -703,11 +710,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
             union { bf16x8_t v; s16x4_t hh[2]; } vf;
             vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r0, c16) + sub));
             vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r1, c16) + sub));
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+            if (!(OPADPO_ATTN_ABL & 2)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+            else asm volatile("" :: "v"(vf.v), "v"(pf.v));
           }
         }
     }
-    if (nxt < n_kt) {
+    if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) {
       tile_commit_v(nb + TILE, kreg, tid);
       stage_mask(ms_base + (cur ^ 1) * 80, p.key_mask, ge.row0, L, nxt * 64, tid);
     }

@@ -8,8 +8,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 python $R/opa-dpo_amd/build.py > /dev/null || exit 1
 for spec in "$@"; do
   n=${spec%%:*}; f=${spec#*:}
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $f -c $R/opa-dpo_amd/csrc/gemm.hip -o /tmp/gemm_$n.o 2>/dev/null || { echo "compile failed: $n"; exit 1; }
-    OBJS=$(ls $R/opa-dpo_amd/build/*.o | grep -v gemm.hip.o)
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $f -c $R/opa-dpo_amd/csrc/${DIAG_SRC:-gemm}.hip -o /tmp/gemm_$n.o 2>/dev/null || { echo "compile failed: $n"; exit 1; }
+    OBJS=$(ls $R/opa-dpo_amd/build/*.o | grep -v ${DIAG_SRC:-gemm}.hip.o)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/opa-dpo_amd/lib/libopadpo_hip_$n.so /tmp/gemm_$n.o $OBJS && echo "built libopadpo_hip_$n.so ($f)" ) &
 done
 wait
