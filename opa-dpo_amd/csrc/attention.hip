@@ -513,7 +513,7 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
 }
 
 #ifndef OPADPO_ATTN_ABL
-#define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging
+#define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
 #endif
 __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -612,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
         constexpr int PF = 2;
         bf16x8_t kfr[PF + 1][2];
         auto kread = [&](int ks, int kb) {
+          if (OPADPO_ATTN_ABL & 32) return qf[ks];
           return *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
         };
 #pragma unroll
@@ -708,8 +709,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           for (int db = 0; db < 4; ++db) {
             const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;      // 16-byte chunk of column db*32 + vgrp*16 + (a & 3)*4, byte inside it
             union { bf16x8_t v; s16x4_t hh[2]; } vf;
+            if (!(OPADPO_ATTN_ABL & 64)) {
             vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r0, c16) + sub));
             vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r1, c16) + sub));
+            } else vf.v = pf.v;
             if (!(OPADPO_ATTN_ABL & 2)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[db], 0, 0, 0);
             else asm volatile("" :: "v"(vf.v), "v"(pf.v));
           }
