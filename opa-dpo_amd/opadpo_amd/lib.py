@@ -152,7 +152,7 @@ def load() -> C.CDLL:
 
 def set_flags(use_glds=10, use_tr: bool = True) -> None:
     """Process-default kernel variants for the op-level entry points (a context carries its own: opadpo_ctx_set_flags).
-    gemm_nt: 10 (default) auto = 4-wave 256x256 long-lead kernel (w4) from 320 blocks or when one round fills >= 88 % of the CUs,
+    gemm_nt: 10 (default) auto = 4-wave 256x256 kernel (w4; streaming form w4s for plain products with >= 2 tiles per CU) from 320 blocks or when one round fills >= 88 % of the CUs,
     128x128 kernel otherwise (bias / activation problems: 8-wave kernel from 320 blocks); 4 the 128x128 kernel everywhere,
     17 the 8-wave 4-phase 256x256 kernel (p8), 31 the 4-wave kernel forced, 15 force the M <= 64 streaming kernel.  True -> default.
     use_tr: bit 0 = ds_read_b64_tr_b16 transposed LDS reads, bit 1 = attention forward through a direct-to-LDS double-buffered K/V
