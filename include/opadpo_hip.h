@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define OPADPO_ABI_VERSION 2      /* 2 (round 5): + opadpo_ctx_wgrad_deterministic; opadpo_gemm_tn_group_workspace_bytes is 0 for MIXED lists too */
+#define OPADPO_ABI_VERSION 2      /* 2 (round 5): + opadpo_ctx_wgrad_deterministic, opadpo_allreduce_grads / _reduce_scatter_grads / _all_gather_params; opadpo_gemm_tn_group_workspace_bytes is 0 for MIXED lists too */
 #define OPADPO_ACT_NONE 0
 #define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
@@ -217,6 +217,18 @@ int opadpo_sumsq(const float* g, size_t n, float* out, void* stream);  /* out[0]
 int opadpo_adamw(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, size_t n, double lr, double beta1,
                  double beta2, double eps, double weight_decay, int step, const float* sumsq, double max_norm,
                  double grad_div, void* stream);
+
+/* ---- gradient exchange without torch.distributed (SURVEY.md section 8b "opadpo_allreduce_grads"; reference: accelerate / DDP behind
+ * rl_trainer.py:155-175, which never syncs - Quirk Q1 - while north_star mandates the exchange) ------------------------------------------------
+ * For a binder that owns its ncclComm_t (one process per GPU, ncclCommInitRank with the RCCL already loaded in the process; the library does
+ * NOT link RCCL - it resolves the three collectives with dlsym at first use, librccl.so by name as the fall-back).  dtype 0 = fp32, 1 = bf16 (the
+ * wire format of the Python host's ZeRO-1 path); SUM over the ranks, in place for the all-reduce; divide by the world size in opadpo_adamw's
+ * grad_div.  ZeRO-1 = opadpo_reduce_scatter_grads (flat [world * shard_count] -> this rank's shard) -> opadpo_sumsq + scalar all-reduce through
+ * opadpo_allreduce_grads(count = 1) -> opadpo_adamw on the shard -> opadpo_all_gather_params.  Asynchronous on `stream`; return code = the
+ * RCCL result (0 = ncclSuccess), text through opadpo_last_error.  The Python host of this repository keeps using torch.distributed (same RCCL). */
+int opadpo_allreduce_grads(void* nccl_comm, void* flat_grad, size_t count, int dtype, void* stream);
+int opadpo_reduce_scatter_grads(void* nccl_comm, const void* flat_grad, void* shard, size_t shard_count, int dtype, void* stream);
+int opadpo_all_gather_params(void* nccl_comm, const void* shard, void* flat, size_t shard_count, int dtype, void* stream);
 
 /* ---- rollout (online_generator.py:292-323: policy.generate(do_sample=True, top_k, top_p, temperature)) ----
  * KV cache layout is head-major: k_cache / v_cache [B, nh, max_ctx, hd] (one (sequence, head) = one contiguous stream).

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "kernels.h"
+#include <dlfcn.h>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -335,6 +336,48 @@ int opadpo_sample(const float* logits, int ldl, int rows, int V, float temperatu
   return done(launch_sample(logits, ldl, rows, V, temperature, top_k, top_p, seed, step, step_ptr, finished, pad_id, eos_id, out,
                             history, S(stream)),
               "opadpo_sample");
+}
+
+// ---- gradient exchange for binders that do not go through torch.distributed (opadpo_allreduce_grads) -----------------------
+// The collective library is NOT linked: the entry points resolve ncclAllReduce / ncclReduceScatter / ncclAllGather at first use from whatever RCCL the
+// process has loaded (dlsym on the global scope; librccl.so by name as the fall-back), so a host that already carries an RCCL - PyTorch ships its own -
+// keeps exactly one copy.  comm is the caller's ncclComm_t; one process per GPU, every call asynchronous on `stream`.
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_reducescatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static void* rccl_sym(const char* name) {
+  void* f = dlsym(RTLD_DEFAULT, name);
+  if (!f) {
+    static void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h) f = dlsym(h, name);
+  }
+  return f;
+}
+static int rccl_dtype(int dtype) { return dtype == 0 ? 7 /* ncclFloat32 */ : dtype == 1 ? 9 /* ncclBfloat16 */ : -1; }
+int opadpo_allreduce_grads(void* nccl_comm, void* flat_grad, size_t count, int dtype, void* stream) {
+  static nccl_allreduce_fn fn = (nccl_allreduce_fn)rccl_sym("ncclAllReduce");
+  if (!fn) return bad("opadpo_allreduce_grads", "ncclAllReduce not found: no RCCL loaded in this process and librccl.so not on the loader path");
+  if (!nccl_comm || !flat_grad || rccl_dtype(dtype) < 0) return bad("opadpo_allreduce_grads", "null communicator / buffer, or dtype not 0 (fp32) / 1 (bf16)");
+  const int rc = fn(flat_grad, flat_grad, count, rccl_dtype(dtype), 0 /* ncclSum */, nccl_comm, S(stream));
+  if (rc != 0) { snprintf(g_err, sizeof(g_err), "opadpo_allreduce_grads: ncclAllReduce returned %d", rc); return rc; }
+  return 0;
+}
+int opadpo_reduce_scatter_grads(void* nccl_comm, const void* flat_grad, void* shard, size_t shard_count, int dtype, void* stream) {
+  static nccl_reducescatter_fn fn = (nccl_reducescatter_fn)rccl_sym("ncclReduceScatter");
+  if (!fn) return bad("opadpo_reduce_scatter_grads", "ncclReduceScatter not found: no RCCL loaded in this process and librccl.so not on the loader path");
+  if (!nccl_comm || !flat_grad || !shard || rccl_dtype(dtype) < 0) return bad("opadpo_reduce_scatter_grads", "null communicator / buffer, or dtype not 0 / 1");
+  const int rc = fn(flat_grad, shard, shard_count, rccl_dtype(dtype), 0, nccl_comm, S(stream));
+  if (rc != 0) { snprintf(g_err, sizeof(g_err), "opadpo_reduce_scatter_grads: ncclReduceScatter returned %d", rc); return rc; }
+  return 0;
+}
+int opadpo_all_gather_params(void* nccl_comm, const void* shard, void* flat, size_t shard_count, int dtype, void* stream) {
+  static nccl_allgather_fn fn = (nccl_allgather_fn)rccl_sym("ncclAllGather");
+  if (!fn) return bad("opadpo_all_gather_params", "ncclAllGather not found: no RCCL loaded in this process and librccl.so not on the loader path");
+  if (!nccl_comm || !shard || !flat || rccl_dtype(dtype) < 0) return bad("opadpo_all_gather_params", "null communicator / buffer, or dtype not 0 / 1");
+  const int rc = fn(shard, flat, shard_count, rccl_dtype(dtype), nccl_comm, S(stream));
+  if (rc != 0) { snprintf(g_err, sizeof(g_err), "opadpo_all_gather_params: ncclAllGather returned %d", rc); return rc; }
+  return 0;
 }
 
 }  // extern "C"

@@ -91,6 +91,9 @@ SIGNATURES.update({
     "opadpo_decode_run": [_p, _i, _i, _p],
     "opadpo_decode_all_finished": [_p, _p, _p],
     "opadpo_decode_end": [_p],
+    "opadpo_allreduce_grads": [_p, _p, _sz, _i, _p],
+    "opadpo_reduce_scatter_grads": [_p, _p, _p, _sz, _i, _p],
+    "opadpo_all_gather_params": [_p, _p, _p, _sz, _i, _p],
 })
 OTHER_SYMBOLS = ["opadpo_abi_version", "opadpo_last_error", "opadpo_set_flags", "opadpo_attn_decode_workspace_bytes", "opadpo_gemm_tn_group_workspace_bytes",
                  "opadpo_ctx_destroy", "opadpo_ctx_last_error", "opadpo_ctx_bytes_peak", "opadpo_ctx_wgrad_deterministic"]

@@ -138,3 +138,76 @@ def test_raw_c_binding_end_to_end():
     assert rc != 0 and b"adapter" in lib.opadpo_ctx_last_error(ctx)
     lib.opadpo_ctx_destroy(ctx)
     eng.close()
+
+
+def test_exchange_entry_points_on_a_callers_rccl_communicator():
+    """opadpo_allreduce_grads / _reduce_scatter_grads / _all_gather_params: the data-parallel exchange for a binder that owns its
+    ncclComm_t and never touches torch.distributed.  The library resolves the collectives from the RCCL already loaded in the process - here the
+    one PyTorch ships - so the test creates a communicator with THAT library through ctypes (world size 1: one GPU per box, RCCL refuses two ranks
+    per device) and drives the ZeRO-1 sequence of include/opadpo_hip.h through the raw symbols: reduce-scatter -> sum of squares -> AdamW on the
+    shard -> all-gather; at world 1 every collective is the identity, so the result must equal the plain opadpo_adamw step (to the summation order of the norm's fp32 atomics)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import glob
+    torch.zeros(1, device="cuda:0")                       # the HIP context exists
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = C.CDLL(cands[0], mode=C.RTLD_GLOBAL)
+
+    class UID(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UID(), vp()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UID)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(vp), ci, UID, ci]
+    rccl.ncclCommDestroy.argtypes = [vp]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    lib = C.CDLL(os.path.join(REPO, "opa-dpo_amd", "lib", "libopadpo_hip.so"))
+    lib.opadpo_last_error.restype = C.c_char_p
+    sz, dbl = C.c_size_t, C.c_double
+    lib.opadpo_allreduce_grads.argtypes = [vp, vp, sz, ci, vp]
+    lib.opadpo_reduce_scatter_grads.argtypes = [vp, vp, vp, sz, ci, vp]
+    lib.opadpo_all_gather_params.argtypes = [vp, vp, vp, sz, ci, vp]
+    lib.opadpo_sumsq.argtypes = [vp, sz, vp, vp]
+    lib.opadpo_adamw.argtypes = [vp, vp, vp, vp, vp, sz, dbl, dbl, dbl, dbl, dbl, ci, vp, dbl, dbl, vp]
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    try:
+        n = 1 << 20
+        g = torch.Generator(device="cpu").manual_seed(9)
+        grad = (torch.randn(n, generator=g) * 0.01).cuda()
+        p0 = (torch.randn(n, generator=g) * 0.02).cuda()
+
+        def check(rc):
+            assert rc == 0, lib.opadpo_last_error().decode()
+        # all-reduce, fp32 and bf16: the sum over ONE rank is the buffer itself; a vector of ones reads back the world size
+        for dt, t in ((0, grad.clone()), (1, grad.to(torch.bfloat16))):
+            want = t.clone()
+            check(lib.opadpo_allreduce_grads(comm, t.data_ptr(), n, dt, st))
+            torch.cuda.synchronize()
+            assert torch.equal(t, want)
+        ones = torch.ones(4, device="cuda")
+        check(lib.opadpo_allreduce_grads(comm, ones.data_ptr(), 4, 0, st))
+        torch.cuda.synchronize()
+        assert ones.tolist() == [1.0] * 4
+        # ZeRO-1 through the raw symbols against the plain step
+        def adamw(p, gr, m, v, w, ss):
+            check(lib.opadpo_adamw(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), w.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, ss.data_ptr(), 1.0, 1.0, st))
+        pa, ma, va, wa, ssa = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda"), torch.zeros(1, device="cuda")
+        check(lib.opadpo_sumsq(grad.data_ptr(), n, ssa.data_ptr(), st))
+        adamw(pa, grad, ma, va, wa, ssa)
+        pb, mb, vb, ssb = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1, device="cuda")
+        shard, wshard, wb = torch.empty(n, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda"), torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        check(lib.opadpo_reduce_scatter_grads(comm, grad.data_ptr(), shard.data_ptr(), n, 0, st))
+        check(lib.opadpo_sumsq(shard.data_ptr(), n, ssb.data_ptr(), st))
+        check(lib.opadpo_allreduce_grads(comm, ssb.data_ptr(), 1, 0, st))
+        adamw(pb, shard, mb, vb, wshard, ssb)
+        check(lib.opadpo_all_gather_params(comm, wshard.data_ptr(), wb.data_ptr(), n, 1, st))
+        torch.cuda.synchronize()
+        # (opadpo_sumsq adds its block sums with fp32 atomics: the two norms agree to summation order, not to the bit, and so does the clip factor)
+        assert abs(float(ssa) - float(ssb)) <= 1e-5 * float(ssa)
+        assert float((pa - pb).abs().max()) <= 1e-6 * float(pa.abs().max()) and float((wa.float() - wb.float()).abs().max()) <= 2.0 ** -7 * float(wa.float().abs().max())
+        assert not torch.equal(pa, p0)
+        # loud on misuse
+        assert lib.opadpo_allreduce_grads(None, grad.data_ptr(), n, 0, st) != 0 and b"null communicator" in lib.opadpo_last_error()
+        assert lib.opadpo_allreduce_grads(comm, grad.data_ptr(), n, 5, st) != 0
+    finally:
+        rccl.ncclCommDestroy(comm)
