@@ -54,7 +54,9 @@ const char* opadpo_last_error(void);
  * 1 = the LDS-ring kernel of rounds 2-4, 3 = the whole-line streaming kernel gemm_nt_dec64x = the library's choice; A/B runs and tests), bits 7-8 = weight rows per workgroup of that kernel (0 = by shape, 1 / 2 / 3 =
  * 48 / 64 / 128 rows; tests), bit 9 = opadpo_sample runs its full vocabulary sweeps instead of the one-wave tail on the kept tokens (identical draws; the
  * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree), bit 10 = the streaming 256x256 GEMM runs on 8
- * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count). */
+ * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count),
+ * bit 11 = head_dim-128 attention forward on the experimental 64-rows-per-wave kernel (one wave per SIMD, K / V tiles by LDS-DMA; round 5, measured slower
+ * than the shipped 32-rows-per-wave kernel - kept for the next round's work, profiles/r05g_attn_fwd64.txt; also OPADPO_ATTN64=1). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
