@@ -512,6 +512,9 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
   }
 }
 
+#ifndef ATTN_RESCALE_LOG2
+#define ATTN_RESCALE_LOG2 8.0f      // growth of a row maximum (in log2 units of the scaled scores) that moves the forward kernels' reference maximum; 0 = every change
+#endif
 #ifndef OPADPO_ATTN_ABL
 #define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
 #endif
@@ -672,7 +675,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other 32 keys of the tile for this q row
       const float m_new = fmaxf(m_run, mx);
-      if (__ballot(m_new != m_run)) {                     // lazy rescale: the running maximum settles after a few tiles
+      // lazy rescale with a threshold (round 5): the reference maximum m_run only moves when some row's maximum has grown by more than 2^8 in the
+      // exponent's units - until then P = 2^(s - m_run) <= 256 (bf16 has fp32's range, the accumulation is fp32) and O / l, lse = m_run + log2(l) do not
+      // depend on which reference was used.  With random inputs the plain rule (rescale whenever any of the wave's 32 maxima moves) fired in most tiles.
+      if (__ballot((m_new - m_run) * scale2 > ATTN_RESCALE_LOG2)) {
         const float alpha = fast_exp2((m_run - m_new) * scale2);
         l_run *= alpha;
 #pragma unroll
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       // exponent arguments and row sums two values per instruction (v_pk_fma_f32 / v_pk_add_f32: full rate on CDNA3+); the exp itself
       // is one quarter-rate v_exp_f32 per score.  exp2(-inf) = 0 for masked scores (m stays finite: NEG_BIG floor)
       typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
-      const f32x2v_t sc2 = {scale2, scale2}, mb2 = {-m_new * scale2, -m_new * scale2};
+      const f32x2v_t sc2 = {scale2, scale2}, mb2 = {-m_run * scale2, -m_run * scale2};
       f32x2v_t ps2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs p) {
         // lazy rescale with a threshold: O lives in the accumulator file (3 instructions per element to rescale), so the reference maximum m_run is only
         // moved when some row's maximum has grown by more than 2^8 in the exponent's units - until then P = 2^(s - m_run) <= 256 (exact in bf16's
         // range, fp32 accumulation), and the final O / l and lse = m_run + log2(l) do not care which reference was used
-        if (!(A64_ABL & 16) && __ballot((m_new - m_run[G]) * scale2 > 8.0f)) {
+        if (!(A64_ABL & 16) && __ballot((m_new - m_run[G]) * scale2 > ATTN_RESCALE_LOG2)) {
           nop12_a4(o[G][0], o[G][1], o[G][2], o[G][3]);
           const float alpha = fast_exp2((m_run[G] - m_new) * scale2);
           l_run[G] *= alpha;
