@@ -512,8 +512,11 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
   }
 }
 
+#ifndef ATTN32_RESCALE_LOG2
+#define ATTN32_RESCALE_LOG2 0.0f    // the shipped 32-row forward: every change of a row maximum rescales (see the kernel)
+#endif
 #ifndef ATTN_RESCALE_LOG2
-#define ATTN_RESCALE_LOG2 8.0f      // growth of a row maximum (in log2 units of the scaled scores) that moves the forward kernels' reference maximum; 0 = every change
+#define ATTN_RESCALE_LOG2 8.0f      // growth of a row maximum (in log2 units of the scaled scores) that moves the 64-row forward kernel's reference maximum; 0 = every change
 #endif
 #ifndef OPADPO_ATTN_ABL
 #define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
@@ -675,10 +678,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other 32 keys of the tile for this q row
       const float m_new = fmaxf(m_run, mx);
-      // lazy rescale with a threshold (round 5): the reference maximum m_run only moves when some row's maximum has grown by more than 2^8 in the
-      // exponent's units - until then P = 2^(s - m_run) <= 256 (bf16 has fp32's range, the accumulation is fp32) and O / l, lse = m_run + log2(l) do not
-      // depend on which reference was used.  With random inputs the plain rule (rescale whenever any of the wave's 32 maxima moves) fired in most tiles.
-      if (__ballot((m_new - m_run) * scale2 > ATTN_RESCALE_LOG2)) {
+      // lazy rescale: the running maximum settles after a few tiles.  A threshold form (reference maximum kept until some row's maximum has grown by more
+      // than 2^8 in the exponent's units; exact: O / l and lse do not depend on the reference) is -2.5 % per launch with random inputs, where the plain rule fires in
+      // most tiles (profiles/r05h_ab_attn_rescale.txt) - NOT shipped: the different rounding pattern moved the one-layer parity statistic from 9.87e-4 to 1.011e-3,
+      // across north_star's literal 1e-3 (tests/test_bench_config_parity_gpu.py); build with -DATTN32_RESCALE_LOG2=8.0f to get it.
+      if (__ballot((m_new - m_run) * scale2 > ATTN32_RESCALE_LOG2)) {
         const float alpha = fast_exp2((m_run - m_new) * scale2);
         l_run *= alpha;
 #pragma unroll
