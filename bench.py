@@ -842,6 +842,28 @@ def main():
                     out["reference_unmerged"] = {"error": repr(e)}
                 finally:
                     ref_ad.merged = saved_merged
+            # (a3) round 5 moved two elementwise passes into GEMM epilogues (the residual adds of the o / down projections, the SwiGLU backward of the
+            # down projection's dgrad): the step gets shorter, the gemm_nt launches longer - `roofline.frac` of the headline therefore prices those
+            # epilogues as GEMM time.  The same step with both passes back in their own kernels (context flag bits 13 | 14), events on: what the
+            # kernel's MFMA rate is without the extra epilogue work, and what the fusion is worth per step
+            if hasattr(eng, "profile") and args.ctx_flags < 0:
+                try:
+                    eng.set_flags(use_tr=1 | 8192 | 16384)
+                    step_no[0] = 0
+                    step()
+                    torch.cuda.synchronize()
+                    eng.profile(True)
+                    dt_n = timed(0, 4)
+                    f_n, ms_n, n_n = eng.profile_read()
+                    eng.profile(False)
+                    out["unfused_epilogues"] = {"ms_per_step": dt_n * 1e3, "value": args.pairs * args.accum / dt_n, "unit": "pairs/s", "steps": 4,
+                                                "gemm_nt_roofline_frac": f_n / (ms_n * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "gemm_nt_launches": n_n,
+                                                "note": "residual adds in rmsnorm_sum_fwd and SwiGLU backward as silu_mul_bwd (the round-4 form, bit-identical results): "
+                                                        "the llm-pass GEMMs alone, HIP events on; the headline runs both inside gemm_nt's direct epilogues"}
+                except Exception as e:
+                    out["unfused_epilogues"] = {"error": repr(e)}
+                finally:
+                    eng.set_flags(use_tr=-1)
             # (b) does the data-parallel exchange hide behind the backward?  Same step with a 1-rank RCCL group: every bucket's bf16 staging
             # cast + reduce_scatter is launched from the layer hook INSIDE the backward, all-gathers after AdamW (optim.FlatAdamW zero1),
             # A/B against the collective-free step measured back to back on the same pool

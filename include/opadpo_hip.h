@@ -321,8 +321,8 @@ const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
 int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
 /* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default.  Context-only: use_tr bit 5 = keep the
  * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
- * bit 6 = SwiGLU backward in the epilogue of the down projection's dgrad (OPADPO_ACT_SWIGLU_BWD; default: its own launch, which
- * measured 0.35 % faster per step); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only
+ * bit 6 = SwiGLU backward in the LDS-STAGED epilogue of the down projection's dgrad (the form of rounds 3-4, which measured 0.35 % slower per step
+ * than its own launch; the default since round 5 is the direct-epilogue form, see bit 14); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only
  * on the rows the head reads - the last prefix row and the response rows -, forward and backward; exact, nothing else reads the rest);
  * bit 8 = the 16-rows-per-wave attention forward and dQ kernels (default at head_dim 128: 32 rows per wave on v_mfma_f32_32x32x16_bf16);
  * bit 9 / bit 10 = force / forbid the CHUNKED head (lm_head + online log-sum-exp + label gather + entropy over 4096 vocabulary columns at
@@ -331,7 +331,14 @@ int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free
  * bit 12 = LoRA wgrads flushed with fp32 atomics (default: partial tiles to a workspace + ordered reduce, bit-reproducible gradients).
  *   PRECONDITION of the default: every wgrad of a layer runs on the 256x256 kernel, i.e. lora_r % 256 == 0 (the shipped DPO recipe: r = 256).
  *   With r = 64 / 128 (the reference's online_generation / opa_train defaults) the wgrads run on the 128x128 kernel and flush with fp32
- *   atomics whatever this bit says: results correct to fp32 summation order, not bit-reproducible - opadpo_ctx_wgrad_deterministic tells. */
+ *   atomics whatever this bit says: results correct to fp32 summation order, not bit-reproducible - opadpo_ctx_wgrad_deterministic tells.
+ * bit 13 = residual adds of the full-sequence passes deferred to the RMSNorm that follows (rmsnorm_sum_fwd: x = res + y, 14 B per element; the form of
+ *   rounds 2-4).  Default since round 5: the o / down projections add their fp32 residual rows in the 256x256 kernels' DIRECT epilogue (rows requested
+ *   one row block ahead of the accumulator read-out) and the norm pass reads 6 B per element - the same fp32 addition of the same operands, so h / x
+ *   keep their bits; -1.0 % per step.  OPADPO_FUSE_RESID=0 makes the deferred form the process default (A/B runs).
+ * bit 14 = SwiGLU backward as its own kernel (silu_mul_bwd; rounds 1-4).  Default since round 5: inside the direct epilogue of the down projection's
+ *   dgrad (OPADPO_ACT_SWIGLU_BWD, gate / up operands requested one row block ahead; bit-identical to the two-kernel form, d_act never reaches HBM;
+ *   -0.8 % per step); bit 6 selects the LDS-staged form of that epilogue (rounds 3-4; cross-check).  OPADPO_FUSE_SWIGLU_BWD=0: process default off. */
 int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* how the LAST opadpo_seq_logprobs_bwd of this context flushed its LoRA wgrads: 1 = ordered reduce (bit-reproducible), 0 = fp32 atomics
  * (bit 12 set, or lora_r % 256 != 0), -1 = no backward yet */

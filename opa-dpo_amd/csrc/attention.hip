@@ -520,8 +520,26 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
 #endif
 #ifndef OPADPO_ATTN_ABL
 #define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
+#endif                         // 128 / 256 / 512: the tile loop of the 32-row forward runs at most 0 / 1 / 4 tiles (what a workgroup costs besides its tiles)
+#ifndef OPADPO_ATTN32_DIAG
+#define OPADPO_ATTN32_DIAG 0
+#endif
+#if OPADPO_ATTN32_DIAG
+// diagnostics build (DIAG_SRC=attention tools/build_diag.sh a32diag:"-DOPADPO_ATTN32_DIAG=1"; tools/attn32_diag.py): shader cycles of wave 0 of every workgroup of the
+// 32-row forward spent [0] before its first tile barrier (geometry, Q, first K / V tile), [1] in the tile loop, [2] from the loop's end to the last store issued,
+// [3] workgroups, [4] tiles walked - summed over the launches since the last read
+__device__ unsigned long long g_attn32_diag[5];
+extern "C" int opadpo_debug_attn32_read(unsigned long long* out5, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_attn32_diag), 40);
+  if (reset) { unsigned long long z[5] = {0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn32_diag), z, 40); }
+  return (int)e;
+}
 #endif
 __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
+#if OPADPO_ATTN32_DIAG
+  const unsigned long long dg_t0 = __builtin_readcyclecounter();
+  unsigned long long dg_t1 = dg_t0, dg_tiles = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 128, TILE = 64 * HD * 2;            // 16 KiB per K or V tile; ring: [K0 | V0 | K1 | V1]
   uint8_t* const ms_base = (uint8_t*)(smem + 4 * TILE);  // 2 x 80 mask bytes
@@ -575,7 +593,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;                     // m in RAW score units; scale2 enters in the exponent's FMA
 
-  const int n_kt = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
+  const int n_kt_all = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
+  const int n_kt = (OPADPO_ATTN_ABL & 128) ? 0 : (OPADPO_ATTN_ABL & 256) ? min(n_kt_all, 1) : (OPADPO_ATTN_ABL & 512) ? min(n_kt_all, 4) : n_kt_all;
   const SegSkip sk(ge, q0, n_kt);
   const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
   const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;      // excluded key range [xlo, .) of the wave's first / last row
@@ -601,6 +620,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     const char* const Vs = Ks + TILE;
     const uint8_t* const Ms = ms_base + cur * 80;
     if (!(OPADPO_ATTN_ABL & 8)) __syncthreads();          // tile kt is in LDS for everyone; everyone has left the other buffer
+#if OPADPO_ATTN32_DIAG
+    if (dg_tiles++ == 0) dg_t1 = __builtin_readcyclecounter();
+#endif
     char* const nb = smem + (cur ^ 1) * 2 * TILE;
     if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) tile_fetch<HD>(kreg, ksrc, p.ld, nxt * 64);
     // tiles none of this wave's rows can see: beyond its causal diagonal, or wholly inside the responses its rows exclude
@@ -735,6 +757,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     cur ^= 1;
   }
   l_run += __shfl_xor(l_run, 32, 64);
+#if OPADPO_ATTN32_DIAG
+  const unsigned long long dg_t2 = __builtin_readcyclecounter();
+  if (dg_tiles == 0) dg_t1 = dg_t2;
+#endif
   __syncthreads();                                        // every wave has left the ring: it becomes the O staging area
   // O^T[d][q]: lane (q, hi) holds d = db*32 + 8b + 4hi + (0..3).  Through LDS as bf16 rows ([32][128] per wave, 16-byte chunks XOR
   // (row & 15)) and out as whole 256-byte rows.
@@ -761,6 +787,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
     const uint4 v = *(const uint4*)(stg + row * 256 + ((c16 ^ (row & 15)) << 4));
     if (qlo + row < L) *(uint4*)(p.o + (ge.row0 + qlo + row) * p.ldo + h * HD + c16 * 8) = v;
   }
+#if OPADPO_ATTN32_DIAG
+  if (tid == 0) {
+    const unsigned long long dg_t3 = __builtin_readcyclecounter();
+    atomicAdd(&g_attn32_diag[0], dg_t1 - dg_t0); atomicAdd(&g_attn32_diag[1], dg_t2 - dg_t1); atomicAdd(&g_attn32_diag[2], dg_t3 - dg_t2);
+    atomicAdd(&g_attn32_diag[3], 1ull); atomicAdd(&g_attn32_diag[4], dg_tiles);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -406,11 +406,23 @@ hipError_t ensure_rope(opadpo_ctx* c, int len, hipStream_t st) {
 // ---- one Llama decoder layer over M = S*Lp rows (model.py layer_fwd / mlp_fwd) ------------------------------------------------
 struct LayerBufs { bf16_t *n1, *qkv, *t_qkv, *attn, *t_o, *n2, *t_gu, *gu, *act, *t_d; float *rstd1, *rstd2, *lse, *h; };
 
+// full-sequence passes: residual adds in the o / down projections' epilogues (default) or deferred to the RMSNorm that follows (context flag bit 13;
+// OPADPO_FUSE_RESID=0 makes that the process default - A/B runs)
+static bool fuse_resid(const opadpo_ctx* c) {
+  static const int env = getenv("OPADPO_FUSE_RESID") ? atoi(getenv("OPADPO_FUSE_RESID")) : 1;
+  return c->use_tr >= 0 ? !(c->use_tr & 8192) && env != 0 : env != 0;
+}
+static bool fuse_swiglu_bwd(const opadpo_ctx* c) {
+  static const int env = getenv("OPADPO_FUSE_SWIGLU_BWD") ? atoi(getenv("OPADPO_FUSE_SWIGLU_BWD")) : 1;
+  return c->use_tr >= 0 ? !(c->use_tr & 16384) && env != 0 : env != 0;
+}
 // ydef != nullptr ("deferred residual", the full-sequence passes): the down projection writes its fp32 product to ydef WITHOUT the
 // residual - the RMSNorm that follows adds it (rmsnorm_sum_fwd: x = h + y in the same fp32 arithmetic, so h / x keep their bits).
-// A residual operand in the epilogue of a 256x256 tile makes every CU read 256 KiB at the same moment at the end of each round of
-// tiles: +0.21-0.28 ms on a 0.6-1.6 ms GEMM (tools/resid_probe.py), while the norm kernel takes the same bytes at 6 TB/s (+0.13 ms).
-// ydef == nullptr (decode steps: a few rows): residual in the epilogue, result in xo.
+// Rounds 2-4 ran the full-sequence passes this way because a residual operand went through the LDS-STAGED epilogue of the 256x256 tile, every load
+// behind the read-back of its row: +0.21-0.28 ms on a 0.6-1.6 ms GEMM (tools/resid_probe.py), while the norm kernel takes the same bytes at
+// 6 TB/s (+0.13 ms).  Round 5: the DIRECT epilogue requests the residual rows one row block ahead of the accumulator read-out (+0.05-0.065 ms per
+// GEMM whatever K, profiles/r05m_resid_probe_k.txt), so the add lives in the projections again (fuse_resid above) and this form is the A/B switch.
+// ydef == nullptr (decode steps: a few rows; fused-residual full-sequence passes): residual in the epilogue, result in xo.
 hipError_t mlp_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const float* h, float* xo, const LayerBufs& b, int M, int stream_hint, hipStream_t st,
                    float* ydef = nullptr, bool norm_done = false) {
   const opadpo_dims& d = c->d;
@@ -515,14 +527,26 @@ hipError_t layer_fwd(opadpo_ctx* c, int i, const opadpo_ctx::Adapter& ad, const 
     if ((e = launch_gather_rows((const bf16_t*)x, 2 * H, top->urow, (bf16_t*)top->x_u, top->n, 2 * H, st)) != hipSuccess) return e;      // fp32 rows = 2H bf16 units
     Mo = top->n; attn = top->attn_u; xr = top->x_u;
   }
+  // fused residual (round 5, default; context flag bit 13 keeps the deferred form): h = x + attn . Wo leaves the o projection's DIRECT epilogue
+  // (fp32 residual rows requested one row block ahead of the accumulator read-out, gemm.hip w4_direct_epilogue) and the layer's output
+  // x' = h + down(..) the down projection's, written to Y - which the caller makes the next layer's x.  Same fp32 additions on the same
+  // operands as rmsnorm_sum_fwd's: h / x keep their bits; the norm passes read 6 instead of 14 bytes per element.
+  const bool fr = fuse_resid(c);
+  float* const o_dst = fr ? b.h : Y;
   if (lw) {
     GemmNTArgs g3 = gemm(c, attn, H, lw + o.a_o, H, H, b.t_o, r, 0, Mo, r); g3.alpha = s;
     if ((e = run_gemm(c, g3, st)) != hipSuccess) return e;
-    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, Y, H, 1, Mo, H); tail(g4, b.t_o, r, lw + o.b_o, r, r);
+    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, o_dst, H, 1, Mo, H); tail(g4, b.t_o, r, lw + o.b_o, r, r);
+    if (fr) resid(g4, xr, H, 1);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
   } else {
-    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, Y, H, 1, Mo, H);
+    GemmNTArgs g4 = gemm(c, attn, H, w.wo, H, H, o_dst, H, 1, Mo, H);
+    if (fr) resid(g4, xr, H, 1);
     if ((e = run_gemm(c, g4, st)) != hipSuccess) return e;
+  }
+  if (fr) {
+    if ((e = launch_rmsnorm_fwd(b.h, 1, w0.ln2, b.n2, b.rstd2, Mo, H, d.rms_eps, st)) != hipSuccess) return e;      // n2 = norm(h)
+    return mlp_fwd(c, i, ad, b.h, Y, b, Mo, 0, st, nullptr, true);                                                   // Y = h + down(..)
   }
   if ((e = launch_rmsnorm_sum_fwd(xr, 1, Y, 1, (size_t)Mo * H, w0.ln2, b.h, b.n2, b.rstd2, Mo, H, d.rms_eps, st)) != hipSuccess) return e;      // h = x + attn . Wo, n2 = norm(h)
   return mlp_fwd(c, i, ad, b.h, nullptr, b, Mo, 0, st, Y, true);
@@ -895,17 +919,27 @@ int opadpo_seq_logprobs_fwd(opadpo_ctx* c, int adapter_id, const int32_t* ids, c
   const float* res = sv->x;
   const float* yin = nullptr;
   const TopRows top{sv->urow, sv->Uc, sv->attn_u, sv->hs};                 // hs is free until the head (and |U| <= R rows fit)
+  const bool fr = fuse_resid(c);
   for (int i = 0; i < d.n_layers; ++i) {
     const LayerBufs lb = slot(d, sv, train ? i : 0);
     float* x = sv->x + (size_t)(train ? i : (i & 1)) * MH;
-    CKS(layer_fwd(c, i, ad, res, yin, x, Y, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg,
+    // fused residual: the layer writes its OUTPUT x_{i+1} = h + down(..) into the next layer's slot (training: slot i + 1, the last one being the
+    // old branch-product slot; no-grad: the other of the two alternating slots)
+    float* const xo = fr ? sv->x + (size_t)(train ? i + 1 : ((i + 1) & 1)) * MH : Y;
+    CKS(layer_fwd(c, i, ad, res, yin, x, xo, lb, S, sv->L, sv->key_mask, sv->seg_prefix, sv->seg_len, nullptr, nullptr, 0, st, rg,
                   (sv->Uc > 0 && i == d.n_layers - 1) ? &top : nullptr));
-    res = lb.h; yin = Y;
+    if (fr) { res = xo; yin = nullptr; } else { res = lb.h; yin = Y; }
   }
+  if (fr) {
+    // final hidden state of the HEAD rows only: x = the last layer's output rows (fp32 rows = 2H bf16 units)
+    CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
+    CKS(launch_rmsnorm_fwd(sv->hs, 1, c->norm, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
+  } else {
   // final hidden state x = h + y of the HEAD rows only (fp32 rows = 2H bf16 units; the y rows park in the logits buffer, written later)
   CKS(launch_gather_rows((const bf16_t*)res, 2 * H, sv->rows, (bf16_t*)sv->hs, R, 2 * H, st));
   CKS(launch_gather_rows((const bf16_t*)Y, 2 * H, sv->rows, (bf16_t*)sv->logits, R, 2 * H, st));
   CKS(launch_rmsnorm_sum_fwd(sv->hs, 1, sv->logits, 1, (size_t)R * H, c->norm, sv->hs, sv->hn, sv->rstd_f, R, H, d.rms_eps, st));
+  }
   float* const head_logp = rg ? sv->logp_c : logp;
   if (sv->head_chunk > 0) {
     // lm_head + online log-sum-exp + label gather + entropy, one vocabulary chunk at a time (rl_models.py:121-132, common_utils.py:112-118):
@@ -1070,11 +1104,14 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dXb, H, wt + o.b_d, H, H, dt_r, r, 0, Mm, r); g.alpha = s; CK(run_gemm(c, g, st)); }
     CK(tn(dXb, H, b.t_d, r, gr + o.b_d, r, H, r, 0, 0, Mm));
     CK(tn(dt_r, r, b.act, F, gr + o.a_d, F, r, F, 0, 0, Mm));
-    if (F % 256 == 0 && c->use_tr >= 0 && (c->use_tr & 64)) {      // opt-in (flag bit 6): SwiGLU backward in the dgrad epilogue, d_act stays in the block's LDS.
-      // Same-box A/B at the bench shape: 1016.9 vs 1013.3 ms per step for the two-kernel form - the longer epilogue idles the one-block-per-CU
-      // matrix pipe for longer than the 5 TB/s elementwise kernel takes
+    const bool sb_staged = c->use_tr >= 0 && (c->use_tr & 64);
+    if (F % 256 == 0 && (sb_staged || fuse_swiglu_bwd(c))) {
+      // SwiGLU backward in the dgrad's epilogue: d_act never reaches HBM.  Default since round 5 in the DIRECT form (gate / up operands requested one
+      // row block ahead of the accumulator read-out, lane-local math, gemm.hip w4_direct_epilogue_swiglu_bwd; context flag bit 14 / OPADPO_FUSE_SWIGLU_BWD=0
+      // keep the two-kernel form).  Flag bit 6 = the LDS-staged form of rounds 3-4 (every operand load's latency exposed: 1016.9 vs 1013.3 ms per step
+      // for the two-kernel form then) - the cross-check of the direct one.
       GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_gu, 2 * F, 0, Mm, F); tail(g, dt_r, r, wt + o.a_d, r, r);
-      g.act = OPADPO_ACT_SWIGLU_BWD; g.R = b.gu; g.ldr = 2 * F; g.r_f32 = 0;
+      g.act = OPADPO_ACT_SWIGLU_BWD; g.R = b.gu; g.ldr = 2 * F; g.r_f32 = 0; g.swiglu_bwd_staged = sb_staged ? 1 : 0;
       CK(run_gemm(c, g, st));
     } else {
       { GemmNTArgs g = gemm(c, dXb, H, w.wd_t, H, H, d_act, F, 0, Mm, F); tail(g, dt_r, r, wt + o.a_d, r, r); CK(run_gemm(c, g, st)); }
@@ -1315,15 +1352,21 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
   const LayerBufs pb = slot(d, &pf, 0);
   float* const Yp = pf.x + 2 * MH;
   const float* yin = nullptr;
+  const bool fr = fuse_resid(c);                    // residual adds in the projections' epilogues: a layer writes its output into the other x slot
+  const float* xin = pf.x;
   for (int i = 0; i < d.n_layers; ++i) {
-    CKD(layer_fwd(c, i, ad, i == 0 ? pf.x : pb.h, yin, pf.x + (size_t)(i & 1) * MH, Yp, pb, B, Lp, pf.key_mask, 0, 0, D.kc + i * per_layer,
+    float* const xo = fr ? pf.x + (size_t)((i + 1) & 1) * MH : Yp;
+    CKD(layer_fwd(c, i, ad, fr ? xin : (i == 0 ? pf.x : pb.h), yin, pf.x + (size_t)(i & 1) * MH, xo, pb, B, Lp, pf.key_mask, 0, 0, D.kc + i * per_layer,
                   D.vc + i * per_layer, max_ctx, st));
-    yin = Yp;
+    if (fr) xin = xo; else yin = Yp;
   }
   hipLaunchKernelGGL(affine_index_kernel, g1(B), dim3(256), 0, st, pf.rows, B, Lp, Lp - 1);
   CKD(hipGetLastError());
+  if (fr) CKD(launch_gather_rows((const bf16_t*)xin, 2 * H, pf.rows, (bf16_t*)D.hs, B, 2 * H, st));   // last position of the last layer's output
+  else {
   CKD(launch_gather_rows((const bf16_t*)pb.h, 2 * H, pf.rows, (bf16_t*)D.hs, B, 2 * H, st));          // last position: x = h + y, added by the head's norm
   CKD(launch_gather_rows((const bf16_t*)Yp, 2 * H, pf.rows, (bf16_t*)D.x, B, 2 * H, st));
+  }
   CKD(hipMemsetAsync(D.finished, 0, B, st));
   CKD(hipMemsetAsync(D.step_d, 0, sizeof(int32_t), st));
   { const int32_t p0 = Lp - 1; CKD(hipMemcpyAsync(D.pos_d, &p0, sizeof(int32_t), hipMemcpyHostToDevice, st)); CKD(hipStreamSynchronize(st)); }
@@ -1333,7 +1376,7 @@ int opadpo_decode_begin(opadpo_ctx* c, int adapter_id, const int32_t* ids, const
     CKD(hipMemcpyAsync(history, pad.data(), pad.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     CKD(hipStreamSynchronize(st));
   }
-  CKD(decode_head(c, D.hs, D.x, 1, st));          // token 0 from the prefill logits
+  CKD(fr ? decode_head(c, D.hs, nullptr, 0, st) : decode_head(c, D.hs, D.x, 1, st));          // token 0 from the prefill logits
 #undef CKD
   ctx_free(c, parena, pbytes);
   return 0;

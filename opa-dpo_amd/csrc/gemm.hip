@@ -387,8 +387,20 @@ __device__ __forceinline__ void* w4_uniform_ptr(const void* q) {
   const unsigned long long v = (unsigned long long)q;
   return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
+#ifndef OPADPO_W4_RPD
+#define OPADPO_W4_RPD 2       // residual row blocks in flight ahead of the read-out: one-tile-per-workgroup kernel
+#endif
+#ifndef OPADPO_W4S_RPD
+#define OPADPO_W4S_RPD 1      // streaming kernel (its fragment registers stay live across the epilogue)
+#endif
+// residual operands the direct epilogue takes (everything else with a residual goes through the staged epilogue of gemm_nt_w4_kernel)
+__host__ __device__ __forceinline__ bool w4_direct_resid_ok(const GemmNTArgs& p) {
+  return p.R && p.r_f32 && p.out_f32 && !p.bias && p.act == 0 && ((unsigned long long)p.M + 256ull) * (unsigned)p.ldr * 4ull < 0xffffffffull &&
+         ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * 4ull < 0xffffffffull && p.ldr % 4 == 0;
+}
 // Direct epilogue of the 4-wave 256x256 kernels: accumulator layout acc[i][j][r] of lane (frow, fchk) = row i*16 + 4*fchk + r, column 8*frow + j of the
 // wave's 128x128 block (the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns).  No LDS, no barrier.
+template <int PD = 1>      // PD = row blocks of the residual operand requested ahead of the accumulator read-out (32 registers each)
 __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
   // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
   // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
@@ -398,15 +410,40 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
   const bool small = ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * esz < 0xffffffffull;
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.C), 0, small ? (int)((unsigned)p.M * (unsigned)p.ldc * esz) : 0, 0x00020000);
   const int mrow0 = m0 + wr * 128 + 4 * fchk, col = ncol0 + 8 * frow;
+  // fp32 residual operand (w4_direct_resid_ok: fp32 R, fp32 C, 32-bit offsets): C = alpha * acc + R with the R rows of row block i + 1 requested
+  // (non-temporal, 8 x 16 B per lane) before row block i is read out of the accumulators - the residual stream of the decoder layers is added here
+  // instead of in the RMSNorm pass that follows (same fp32 operation on the same operands: same bits)
+  const bool has_r = p.R != nullptr;
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(has_r ? p.R : p.C), 0, has_r ? (int)((unsigned)p.M * (unsigned)p.ldr * 4u) : 0, 0x00020000);
+  u32x4s_t rq[PD + 1][4][2];
+  auto r_issue = [&](int i, u32x4s_t (&dst)[4][2]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned vo = ((unsigned)(mrow0 + i * 16 + r) * (unsigned)p.ldr + (unsigned)col) * 4u;
+      dst[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rR, vo, 0, 2);
+      dst[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rR, vo + 16u, 0, 2);
+    }
+  };
+  if (has_r) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) r_issue(i, rq[i]);
+  }
   epi_dispatch_plain(p, [&](auto MD_) {
     constexpr int md = decltype(MD_)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float v[8][4];
+      if (has_r && i + PD < 8) r_issue(i + PD, rq[(i + PD) % (PD + 1)]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         acc_read4(acc[i][j], v[j]);
         epi_pre4<md>(p, 0, v[j]);
+      }
+      if (has_r) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j][r] += __uint_as_float(rq[i % (PD + 1)][r][j >> 2][j & 3]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -436,6 +473,62 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
       __builtin_amdgcn_sched_barrier(0);      // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
     }
   });
+}
+
+// SwiGLU backward in the DIRECT epilogue (round 5): the block is d_act[:, ncol0 ..] of the down projection's dgrad, R the stored pre-activations
+// [gate | up] ([M, 2N] bf16), C receives [d_gate | d_up] - the arithmetic of silu_mul_bwd_kernel on the bf16-ROUNDED d_act, so the result is
+// bit-identical to the two-kernel path without d_act ever reaching HBM.  A lane owns 8 consecutive columns of 4 rows per row block: its gate
+// and up values are two 16-byte loads per row, requested one row block ahead of the accumulator read-out (the staged form of rounds 3-4
+// loaded them inside the read-back loop, every load's latency exposed: slower than the separate kernel).
+__host__ __device__ __forceinline__ bool w4_direct_swiglu_bwd_ok(const GemmNTArgs& p) {
+  return p.act == OPADPO_ACT_SWIGLU_BWD && p.R && !p.r_f32 && !p.out_f32 && !p.bias && p.alpha == 1.0f && p.ldr % 8 == 0 && p.ldc % 8 == 0 &&
+         ((unsigned long long)p.M + 256ull) * (unsigned)p.ldr * 2ull < 0xffffffffull && ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * 2ull < 0xffffffffull;
+}
+__device__ __forceinline__ void w4_direct_epilogue_swiglu_bwd(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.R), 0, (int)((unsigned)p.M * (unsigned)p.ldr * 2u), 0x00020000);
+  const int mrow0 = m0 + wr * 128 + 4 * fchk, col = ncol0 + 8 * frow;
+  u32x4s_t gq[2][4][2];      // [buffer][row][gate / up]
+  auto g_issue = [&](int i, u32x4s_t (&dst)[4][2]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned vo = ((unsigned)(mrow0 + i * 16 + r) * (unsigned)p.ldr + (unsigned)col) * 2u;
+      dst[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rR, vo, 0, 2);
+      dst[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rR, vo + (unsigned)p.N * 2u, 0, 2);
+    }
+  };
+  g_issue(0, gq[0]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v[8][4];
+    if (i + 1 < 8) g_issue(i + 1, gq[(i + 1) & 1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc_read4(acc[i][j], v[j]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float dd[8], gt[8], up[8], dg[8], du[8];
+      uint4 db;
+      db.x = pack_bf2(v[0][r], v[1][r]); db.y = pack_bf2(v[2][r], v[3][r]); db.z = pack_bf2(v[4][r], v[5][r]); db.w = pack_bf2(v[6][r], v[7][r]);
+      unpack8(db, dd);                                          // d_act as the two-kernel path stores it: rounded to bf16
+      const u32x4s_t gw = gq[i & 1][r][0], uw = gq[i & 1][r][1];
+      unpack8(make_uint4(gw[0], gw[1], gw[2], gw[3]), gt);
+      unpack8(make_uint4(uw[0], uw[1], uw[2], uw[3]), up);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sg = 1.0f / (1.0f + __expf(-gt[e]));
+        const float silu = gt[e] * sg;
+        du[e] = dd[e] * silu;
+        dg[e] = dd[e] * up[e] * sg * (1.0f + gt[e] * (1.0f - sg));
+      }
+      const uint4 og = pack8(dg), ou = pack8(du);
+      const u32x4s_t sg4 = {og.x, og.y, og.z, og.w}, su4 = {ou.x, ou.y, ou.z, ou.w};
+      const unsigned vo = ((unsigned)(mrow0 + i * 16 + r) * (unsigned)p.ldc + (unsigned)col) * 2u;
+      if (p.store_nt) { __builtin_amdgcn_raw_buffer_store_b128(sg4, rC, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(su4, rC, vo + (unsigned)p.N * 2u, 0, 2); }
+      else { __builtin_amdgcn_raw_buffer_store_b128(sg4, rC, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(su4, rC, vo + (unsigned)p.N * 2u, 0, 0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 #include "w4_kloop.inc"
@@ -562,8 +655,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     char* stg = smem + wave * 32768;
     const int ncol0 = n0 + wc * 128;
     const bool special = p.act == OPADPO_ACT_SWIGLU_PAIR || p.act == OPADPO_ACT_SWIGLU_BWD || ((p.rope_pos || p.rope_cos) && n0 < p.rope_cols);
-    if (!p.R && !special) {
-      w4_direct_epilogue(p, acc, m0, ncol0, wr, frow, fchk);
+    if ((!p.R || w4_direct_resid_ok(p)) && !special) {
+      w4_direct_epilogue<OPADPO_W4_RPD>(p, acc, m0, ncol0, wr, frow, fchk);
+      return;
+    }
+    if (w4_direct_swiglu_bwd_ok(p) && !p.swiglu_bwd_staged) {
+      w4_direct_epilogue_swiglu_bwd(p, acc, m0, ncol0, wr, frow, fchk);
       return;
     }
     // Staged epilogues (residual operand, SwiGLU pair / backward, rotary embedding): each wave passes its 128x128 block through its own
@@ -954,7 +1051,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
 #endif
-    w4_direct_epilogue(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    if (p.act == OPADPO_ACT_SWIGLU_BWD) w4_direct_epilogue_swiglu_bwd(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    else w4_direct_epilogue<OPADPO_W4S_RPD>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     __builtin_amdgcn_sched_barrier(0);
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_epi += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -1993,7 +2091,8 @@ static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
     const int grid_ = (GRID_), cus_ = g_w4s_few ? 8 : g_w4s_cus;                                                             \
-    const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.R && !a.bias && a.act == 0 && !a.rope_cos && !a.rope_pos && \
+    const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos &&                                                   \
+                         ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || (w4_direct_swiglu_bwd_ok(a) && !a.swiglu_bwd_staged)) &&                   \
                          a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
     if (stream_) {                                                                                                           \
       if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                \

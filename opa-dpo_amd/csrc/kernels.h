@@ -37,6 +37,7 @@ struct GemmNTArgs {
   // tile0 + (b >> 2) of the 4-wave kernel's grouped tile order - the full K range, so every output element keeps the summation order
   // it has inside a 256x256 tile (results do not depend on which tiles fall into the tail, i.e. on the row count of the batch)
   int quarter = 0;
+  int swiglu_bwd_staged = 0;            // OPADPO_ACT_SWIGLU_BWD through the LDS-staged epilogue of rounds 3-4 (cross-check of the direct form)
   int store_nt = 0;                     // direct epilogue of the 256x256 4-wave kernels: non-temporal C stores (set by launch_gemm_nt)
 };
 

@@ -185,6 +185,18 @@ def test_wide_7b_forward_is_bit_identical():
     torch.cuda.synchronize()
     assert torch.equal(out["chosen_response_logprobs"].detach(), res[1][0])
     assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-5
+    # round 5 defaults against the forms they replaced: bit 13 = residual adds deferred to the RMSNorm pass (default: in the o / down projections'
+    # direct epilogue), bit 14 = SwiGLU backward as its own kernel (default: in the dgrad's direct epilogue).  Same fp32 / bf16 operations on the
+    # same operands: the log-probs, the entropies and (the LoRA wgrads being ordered reductions) the gradient keep their bits
+    for bits in (8192, 16384, 8192 | 16384):
+        cx.set_flags(use_tr=1 | bits | 1024)
+        ad.grad.zero_()
+        out = _policy(cx, ad, 384, True)(**_kw(p, cx))
+        sum((out[k + "_logprobs"] * w[k]).sum() for k in w).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(out["chosen_response_logprobs"].detach(), res[1][0]), bits
+        assert torch.equal(out["rejected_response_entropies"], res[1][1]), bits
+        assert float((ad.grad - res[1][2]).norm() / res[1][2].norm()) < 1e-6, bits
     # CHUNKED head (default when the logits of the batch shape reach 4 GiB; bit 9 forces it): lm_head + online log-sum-exp + label gather + entropy over 4096
     # vocabulary columns at a time, logits recomputed chunk by chunk in the backward - no [rows, vocab] buffer.  Same function in another
     # fp32 association: log-probs / entropies to fp32 rounding, gradients to the bf16 rounding of d_hn (accumulated over the chunks in fp32)

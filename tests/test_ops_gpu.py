@@ -228,6 +228,50 @@ def test_gemm_nt_streaming_kernel_equals_one_tile_per_workgroup(L, M, N, K1, K2,
     assert relerr(outs["stream8"].float(), want) < (2e-5 if f32 else 6e-3)
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(1100, 1024, 256, 64), (2500, 512, 192, 0), (4096, 2048, 1024, 256)])
+def test_gemm_nt_direct_residual_and_swiglu_bwd_epilogues_stream(L, M, N, K1, K2):
+    """Round 5: the fp32 residual operand and the SwiGLU backward leave the 256x256 kernels through their DIRECT epilogue (operands requested one row
+    block ahead of the accumulator read-out, no LDS), which lets those products stream too.  fp32 residual: streaming kernel (8-workgroup test
+    walk) == one tile per workgroup == 128x128 kernel, bit for bit, and == the plain fp32 product + the residual added by torch (one fp32 add of the
+    same operands: what the RMSNorm pass did before).  SwiGLU backward: streaming == one tile per workgroup == plain product + opadpo_silu_mul_bwd."""
+    lib = L.load()
+    a1, b1 = rnd(M, K1, seed=41), rnd(N, K1, scale=0.05, seed=42)
+    a2, b2 = (rnd(M, K2, seed=43), rnd(N, K2, scale=0.05, seed=44)) if K2 else (None, None)
+    res = rnd(M, N, seed=45).float() * 1.001
+    gu = rnd(M, 2 * N, seed=46)
+    outs = {}
+    try:
+        for rep in range(2):
+            for key, variant, flags in (("stream8", 10, 1 | 1024), ("one_tile", 31, 1), ("k128", 4, 1)):
+                lib.opadpo_set_flags(variant, flags)
+                o = torch.full((M + 2, N), 7.0, dtype=torch.float32, device=dev())
+                L.gemm_nt(a1, b1, o[:M], a2=a2, b2=b2, residual=res)
+                g = None
+                if key != "k128":          # the SwiGLU backward epilogue exists in the 256x256 kernels only
+                    g = torch.full((M + 2, 2 * N), 7.0, dtype=BF, device=dev())
+                    L.gemm_nt(a1, b1, g[:M], a2=a2, b2=b2, residual=gu, act=L.ACT_SWIGLU_BWD)
+                torch.cuda.synchronize()
+                if key in outs:
+                    assert torch.equal(outs[key][0], o) and (g is None or torch.equal(outs[key][1], g)), f"{key} not reproducible (run {rep})"
+                outs[key] = (o, g)
+        lib.opadpo_set_flags(10, 1)
+        plain = torch.empty(M, N, dtype=torch.float32, device=dev())
+        L.gemm_nt(a1, b1, plain, a2=a2, b2=b2)
+        dact = torch.empty(M, N, dtype=BF, device=dev())
+        L.gemm_nt(a1, b1, dact, a2=a2, b2=b2)
+        want_g = torch.empty(M, 2 * N, dtype=BF, device=dev())
+        L.call("opadpo_silu_mul_bwd", L.ptr(dact), L.ptr(gu), L.ptr(want_g), M, N, L.stream())
+        torch.cuda.synchronize()
+    finally:
+        lib.opadpo_set_flags(10, 1)
+    assert torch.equal(outs["stream8"][0], outs["one_tile"][0]) and torch.equal(outs["one_tile"][0], outs["k128"][0])
+    assert torch.equal(outs["stream8"][0][:M], plain + res), "residual in the epilogue != product + residual"
+    assert float((outs["stream8"][0][M:] - 7.0).abs().max()) == 0.0
+    assert torch.equal(outs["stream8"][1], outs["one_tile"][1])
+    assert torch.equal(outs["stream8"][1][:M], want_g), "SwiGLU backward in the epilogue != projection + opadpo_silu_mul_bwd"
+    assert float((outs["stream8"][1][M:].float() - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant", [4, 17, 31, 10])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_epilogue(L, act, variant):

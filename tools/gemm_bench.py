@@ -78,20 +78,21 @@ def main():
         qkv = torch.randn(S * Ln, 3 * H, device=dev).to(BF)
         o = torch.empty(S * Ln, H, dtype=BF, device=dev)
         lse = torch.empty(S, nh, Ln, device=dev)
-        fl = S * nh * 4 * hd * (Ln * Ln / 2)
+        causal = int(os.environ.get("GB_CAUSAL", 1))        # 0: dense non-causal (the guide's attention ladder is quoted on it)
+        fl = S * nh * 4 * hd * (Ln * Ln / 2 if causal else Ln * Ln)
         dqkv = torch.empty(S * Ln, 3 * H, dtype=BF, device=dev)
         delta = torch.empty(S, nh, Ln, device=dev)
         do = torch.randn(S * Ln, H, device=dev).to(BF)
         L.set_flags(True, int(os.environ.get("GB_TR", 1)))
         f = lambda: L.call("opadpo_attn_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(), H,
-                           lse.data_ptr(), None, S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
+                           lse.data_ptr(), None, S, Ln, nh, hd, causal, hd ** -0.5, 0, 0, L.stream())
         t = timeit(f, iters=5, warm=2)
-        print(dict(kernel="attn_fwd_dense_causal", L=Ln, ms=t * 1e3, tflops=fl / t / 1e12), flush=True)
+        print(dict(kernel="attn_fwd_dense_causal" if causal else "attn_fwd_dense_full", L=Ln, ms=t * 1e3, tflops=fl / t / 1e12), flush=True)
         f = lambda: L.call("opadpo_attn_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, o.data_ptr(),
                            do.data_ptr(), H, lse.data_ptr(), None, dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, dqkv.data_ptr() + 4 * H,
-                           None, delta.data_ptr(), S, Ln, nh, hd, 1, hd ** -0.5, 0, 0, L.stream())
+                           None, delta.data_ptr(), S, Ln, nh, hd, causal, hd ** -0.5, 0, 0, L.stream())
         t = timeit(f, iters=5, warm=2)
-        print(dict(kernel="attn_bwd_dense_causal", L=Ln, ms=t * 1e3, tflops=2.5 * fl / t / 1e12), flush=True)
+        print(dict(kernel="attn_bwd_dense_causal" if causal else "attn_bwd_dense_full", L=Ln, ms=t * 1e3, tflops=2.5 * fl / t / 1e12), flush=True)
         return
     if only == "tail":     # partial last round of 256x256 tiles: row-tile count sweep at the ragged bench row counts
         for name, N, K1, K2, grp in shapes[:4]:
