@@ -553,30 +553,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
   const Geo ge = load_geo(p, s);
   const int L = ge.L;
   if (q0 >= L) return;
-  // all-padding q tile (OPADPO_ATTN_SKIP_MASKED_Q): zeros, as the 16-row kernel
-  if ((p.causal & 2) && p.key_mask) {
-    const int a_ = q0 + lane, b_ = q0 + 64 + lane;
-    const uint8_t m0 = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0, m1 = b_ < L ? p.key_mask[ge.row0 + b_] : (uint8_t)0;
-    if (__ballot((m0 | m1) != 0) == 0) {
-      for (int i = tid; i < 128 * 16; i += 256) {
-        const int row = q0 + (i >> 4);
-        if (row < L) *(uint4*)(p.o + (ge.row0 + row) * p.ldo + h * HD + (i & 15) * 8) = make_uint4(0u, 0u, 0u, 0u);
-      }
-      if (tid < 128 && q0 + tid < L && p.lse) p.lse[stat_idx(p, ge, s, h, q0 + tid)] = NEG_BIG;
-      return;
-    }
-  }
+  // Prologue order (round 5; profiles/r05l_attn32_anatomy.txt: a workgroup spent 7.2 k cycles before its first tile, 1.7 tiles' worth, in three
+  // dependent memory round trips - padding checks, then Q, then K, then V): everything the first tile needs is REQUESTED first - the padding bytes of
+  // the q rows, Q, the first K tile and the first V tile (a second 16-register image that lives in the prologue only) - and only then waited for.
   const int qlo = q0 + w * 32, qhi = min(qlo + 31, L - 1);            // this wave's rows
-  bool wave_live = qlo < L, wave_pad = false;
-  if ((p.causal & 2) && p.key_mask && wave_live) {                    // 32 rows that are all masked as keys are padding too: zeros (o = 0, l = 0 below)
-    const int a_ = qlo + ql;
-    const uint8_t mq = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0;
-    wave_live = __ballot(mq != 0) != 0;
-    wave_pad = !wave_live;
-  }
   const int qpos = qlo + ql;
   const int qrow = min(qpos, L - 1);
-
+  const bool pad_check = (p.causal & 2) && p.key_mask;
+  uint8_t pm0 = 1, pm1 = 1, pmq = 1;
+  if (pad_check) {
+    const int a_ = q0 + lane, b_ = q0 + 64 + lane;
+    pm0 = a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0; pm1 = b_ < L ? p.key_mask[ge.row0 + b_] : (uint8_t)0;
+    pmq = qpos < L ? p.key_mask[ge.row0 + qpos] : (uint8_t)0;
+  }
   bf16x8_t qf[8];
   {
     const bf16_t* qp = p.q + (ge.row0 + qrow) * p.ld + h * HD + hi * 8;
@@ -586,28 +575,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       qf[ks] = *(const bf16x8_t*)&v;
     }
   }
+  const int n_kt_all = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
+  const int n_kt = (OPADPO_ATTN_ABL & 128) ? 0 : (OPADPO_ATTN_ABL & 256) ? min(n_kt_all, 1) : (OPADPO_ATTN_ABL & 512) ? min(n_kt_all, 4) : n_kt_all;
+  const SegSkip sk(ge, q0, n_kt);
+  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
+  // ONE 16-register staging image used twice per iteration (round 4): next K tile fetched at the top and written to the other ring buffer
+  // after the S^T phase, next V tile fetched there and written at the end (two images in flight held 32 registers across the iteration)
+  TileRegs<HD> kreg, vreg0;
+  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
+  tile_fetch<HD>(vreg0, vsrc, p.ld, sk.first() * 64);
+  // all-padding q tile (OPADPO_ATTN_SKIP_MASKED_Q): zeros, as the 16-row kernel
+  if (pad_check) {
+    if (__ballot((pm0 | pm1) != 0) == 0) {
+      for (int i = tid; i < 128 * 16; i += 256) {
+        const int row = q0 + (i >> 4);
+        if (row < L) *(uint4*)(p.o + (ge.row0 + row) * p.ldo + h * HD + (i & 15) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (tid < 128 && q0 + tid < L && p.lse) p.lse[stat_idx(p, ge, s, h, q0 + tid)] = NEG_BIG;
+      return;
+    }
+  }
+  bool wave_live = qlo < L, wave_pad = false;
+  if (pad_check && wave_live) {                                       // 32 rows that are all masked as keys are padding too: zeros (o = 0, l = 0 below)
+    wave_live = __ballot(pmq != 0) != 0;
+    wave_pad = !wave_live;
+  }
   f32x16_t o[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;                     // m in RAW score units; scale2 enters in the exponent's FMA
-
-  const int n_kt_all = p.causal ? (min(L, q0 + 128) + 63) / 64 : (L + 63) / 64;
-  const int n_kt = (OPADPO_ATTN_ABL & 128) ? 0 : (OPADPO_ATTN_ABL & 256) ? min(n_kt_all, 1) : (OPADPO_ATTN_ABL & 512) ? min(n_kt_all, 4) : n_kt_all;
-  const SegSkip sk(ge, q0, n_kt);
   const int xlo = seg_xlo(ge), xhi = seg_qstart(ge, qpos);
   const int xhi_first = seg_on(ge) ? seg_qstart(ge, min(qlo, L - 1)) : 0;      // excluded key range [xlo, .) of the wave's first / last row
   const int xhi_last = seg_on(ge) ? seg_qstart(ge, qhi) : 0;
   const float scale2 = p.scale * 1.4426950408889634f;
-  const TileSrc<HD> ksrc(p.k, p.ld, ge.row0, L, h, tid), vsrc(p.v, p.ld, ge.row0, L, h, tid);
-  // ONE 16-register staging image used twice per iteration (round 4): next K tile fetched at the top and written to the other ring buffer
-  // after the S^T phase, next V tile fetched there and written at the end (two images in flight held 32 registers across the iteration)
-  TileRegs<HD> kreg;
-  tile_fetch<HD>(kreg, ksrc, p.ld, sk.first() * 64);
   tile_commit_k32(smem, kreg, tid);
-  tile_fetch<HD>(kreg, vsrc, p.ld, sk.first() * 64);
-  tile_commit_v(smem + TILE, kreg, tid);
+  tile_commit_v(smem + TILE, vreg0, tid);
   stage_mask(ms_base, p.key_mask, ge.row0, L, sk.first() * 64, tid);
   int cur = 0;
   const int krow_off = ql * 256;                          // K fragment: row kb*32 + ql, 16-byte chunk ks*2 + hi, swizzle kswz32(row) (bit 4 of the row = bit 4 of ql)
