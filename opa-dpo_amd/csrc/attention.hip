@@ -521,6 +521,9 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
 #ifndef OPADPO_ATTN_ABL
 #define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
 #endif                         // 128 / 256 / 512: the tile loop of the 32-row forward runs at most 0 / 1 / 4 tiles (what a workgroup costs besides its tiles)
+#ifndef OPADPO_ATTN32_PRIO
+#define OPADPO_ATTN32_PRIO 0     // experiment: s_setprio 1 around the S^T (bit 0) / P V (bit 1) MFMA blocks of the 32-row forward (two waves per SIMD)
+#endif
 #ifndef OPADPO_ATTN32_DIAG
 #define OPADPO_ATTN32_DIAG 0
 #endif
@@ -642,6 +645,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
         // two accumulator chains interleaved (round 4).  Left to itself the compiler issued read -> s_waitcnt -> MFMA eight times in a row
         // for the first block (every MFMA behind the full LDS latency of the read in front of it) and then eight dependent MFMAs for the second.
         constexpr int PF = 2;
+#if OPADPO_ATTN32_PRIO & 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
         bf16x8_t kfr[PF + 1][2];
         auto kread = [&](int ks, int kb) {
           if (OPADPO_ATTN_ABL & 32) return qf[ks];
@@ -659,6 +665,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
           } else { asm volatile("" :: "v"(kfr[ks % (PF + 1)][0]), "v"(kfr[ks % (PF + 1)][1])); }
           __builtin_amdgcn_sched_barrier(0);
         }
+#if OPADPO_ATTN32_PRIO & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
     }
     if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) {          // the other buffer is free since this iteration's barrier
@@ -733,6 +742,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
         }
       l_run += ps2[0] + ps2[1];
       }
+#if OPADPO_ATTN32_PRIO & 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -753,6 +765,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
             else asm volatile("" :: "v"(vf.v), "v"(pf.v));
           }
         }
+#if OPADPO_ATTN32_PRIO & 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (nxt < n_kt && !(OPADPO_ATTN_ABL & 16)) {
       tile_commit_v(nb + TILE, kreg, tid);
