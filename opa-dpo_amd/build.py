@@ -47,12 +47,29 @@ def build(force: bool = False, verbose: bool = True) -> str:
         odig = _digest([src] + headers)
         if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == odig:
             return obj
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        guard = os.path.basename(src) == "gemm.hip"
+        cmd = [HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if guard else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        if guard:
+            # the 256x256 kernels run their K-loop as one asm block with physical registers: it knows nothing about a scratch descriptor, so an
+            # instantiation that SPILLS faults at run time (round 5: the bias / activation epilogue in the streaming kernel did) - refuse to build one
+            bad, cur = [], None
+            for ln in r.stderr.splitlines():
+                if "remark: Function Name:" in ln:
+                    cur = ln.split("Function Name:")[1].split("[")[0].strip()
+                elif cur and ("gemm_nt_w4" in cur or "gemm_tn_w4" in cur) and "ScratchSize [bytes/lane]:" in ln:
+                    if int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) != 0:
+                        bad.append(cur)
+            if bad:
+                os.remove(obj)
+                raise RuntimeError("these asm-K-loop kernels use scratch (register spills) and would fault at run time: " + ", ".join(bad))
+            r_stderr = "\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" not in ln)
+        else:
+            r_stderr = r.stderr
+        if verbose and r_stderr.strip():
+            print(r_stderr, file=sys.stderr)
         with open(ostamp, "w") as f:
             f.write(odig)
         return obj

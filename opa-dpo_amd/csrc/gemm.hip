@@ -394,13 +394,19 @@ __device__ __forceinline__ void* w4_uniform_ptr(const void* q) {
 #define OPADPO_W4S_RPD 1      // streaming kernel (its fragment registers stay live across the epilogue)
 #endif
 // residual operands the direct epilogue takes (everything else with a residual goes through the staged epilogue of gemm_nt_w4_kernel)
-__host__ __device__ __forceinline__ bool w4_direct_resid_ok(const GemmNTArgs& p) {
-  return p.R && p.r_f32 && p.out_f32 && !p.bias && p.act == 0 && ((unsigned long long)p.M + 256ull) * (unsigned)p.ldr * 4ull < 0xffffffffull &&
+__host__ __device__ __forceinline__ bool w4_direct_resid_ok(const GemmNTArgs& p, bool ba = false) {
+  return p.R && p.r_f32 && p.out_f32 && (ba || (!p.bias && p.act == 0)) && ((unsigned long long)p.M + 256ull) * (unsigned)p.ldr * 4ull < 0xffffffffull &&
          ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * 4ull < 0xffffffffull && p.ldr % 4 == 0;
+}
+// bias / activation problems the BA instantiations of the 256x256 kernels take (direct epilogue: alpha, bias of the lane's 8 columns, quick-GELU / GELU,
+// then an fp32 residual - the order of epilogue4, so every kernel of the library gives the same bits)
+__host__ __device__ __forceinline__ bool w4_direct_ba_ok(const GemmNTArgs& p) {
+  return (p.bias || p.act == OPADPO_ACT_QUICK_GELU || p.act == OPADPO_ACT_GELU) && (p.act == 0 || p.act == OPADPO_ACT_QUICK_GELU || p.act == OPADPO_ACT_GELU) &&
+         (!p.R || w4_direct_resid_ok(p, true)) && !p.rope_cos && !p.rope_pos;
 }
 // Direct epilogue of the 4-wave 256x256 kernels: accumulator layout acc[i][j][r] of lane (frow, fchk) = row i*16 + 4*fchk + r, column 8*frow + j of the
 // wave's 128x128 block (the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns).  No LDS, no barrier.
-template <int PD = 1>      // PD = row blocks of the residual operand requested ahead of the accumulator read-out (32 registers each)
+template <int PD = 1, bool BA = false>      // PD = row blocks of the residual operand requested ahead of the accumulator read-out (32 registers each); BA = bias / activation modes
 __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
   // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
   // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
@@ -428,7 +434,9 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
 #pragma unroll
     for (int i = 0; i < PD; ++i) r_issue(i, rq[i]);
   }
-  epi_dispatch_plain(p, [&](auto MD_) {
+  float bj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // BA: the bias of the lane's 8 consecutive columns
+  if constexpr (BA) { if (p.bias) unpack8(*(const uint4*)(p.bias + col), bj); }
+  auto body = [&](auto MD_) {
     constexpr int md = decltype(MD_)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -437,7 +445,19 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         acc_read4(acc[i][j], v[j]);
-        epi_pre4<md>(p, 0, v[j]);
+        if constexpr (BA) {          // epi_pre4's arithmetic with the COLUMN's bias (v[j][0..3] are four rows of column j)
+          if (md != 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t = v[j][r] * p.alpha;
+              if (md == 1 || (md >= 2 && p.bias)) t += bj[j];
+              if (md >= 2) t = act_apply(t, md == 2 ? OPADPO_ACT_QUICK_GELU : OPADPO_ACT_GELU);
+              v[j][r] = t;
+            }
+          }
+        } else {
+          epi_pre4<md>(p, 0, v[j]);
+        }
       }
       if (has_r) {
 #pragma unroll
@@ -472,7 +492,15 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
       }
       __builtin_amdgcn_sched_barrier(0);      // one row block at a time: 8, not 64, accumulator tuples live in VGPRs
     }
-  });
+  };
+  if constexpr (BA) {      // BA problems carry a bias or an activation: modes 1..3 only (three copies of the body, not five: the kernel must not spill -
+    // its K-loop is an asm block that does not know about a scratch descriptor)
+    if (p.act == OPADPO_ACT_QUICK_GELU) body(std::integral_constant<int, 2>{});
+    else if (p.act == OPADPO_ACT_GELU) body(std::integral_constant<int, 3>{});
+    else body(std::integral_constant<int, 1>{});
+  } else {
+    epi_dispatch_plain(p, body);
+  }
 }
 
 // SwiGLU backward in the DIRECT epilogue (round 5): the block is d_act[:, ncol0 ..] of the down projection's dgrad, R the stored pre-activations
@@ -532,7 +560,7 @@ __device__ __forceinline__ void w4_direct_epilogue_swiglu_bwd(const GemmNTArgs& 
 }
 
 #include "w4_kloop.inc"
-template <bool ORDER_B>
+template <bool ORDER_B, bool BA = false>      // BA: the instantiation for bias / activation problems (a separate code object: the hot kernel's epilogue stays two modes small)
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -655,8 +683,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     char* stg = smem + wave * 32768;
     const int ncol0 = n0 + wc * 128;
     const bool special = p.act == OPADPO_ACT_SWIGLU_PAIR || p.act == OPADPO_ACT_SWIGLU_BWD || ((p.rope_pos || p.rope_cos) && n0 < p.rope_cols);
-    if ((!p.R || w4_direct_resid_ok(p)) && !special) {
-      w4_direct_epilogue<OPADPO_W4_RPD>(p, acc, m0, ncol0, wr, frow, fchk);
+    if ((!p.R || w4_direct_resid_ok(p, BA)) && !special) {
+      w4_direct_epilogue<BA ? 1 : OPADPO_W4_RPD, BA>(p, acc, m0, ncol0, wr, frow, fchk);
       return;
     }
     if (w4_direct_swiglu_bwd_ok(p) && !p.swiglu_bwd_staged) {
@@ -940,7 +968,7 @@ extern "C" int opadpo_debug_w4s_read(unsigned long long* out4, int reset) {
   return (int)e;
 }
 #endif
-template <bool ORDER_B>
+template <bool ORDER_B, bool BA = false>
 __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1052,7 +1080,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
 #endif
     if (p.act == OPADPO_ACT_SWIGLU_BWD) w4_direct_epilogue_swiglu_bwd(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
-    else w4_direct_epilogue<OPADPO_W4S_RPD>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    else w4_direct_epilogue<OPADPO_W4S_RPD, BA>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     __builtin_amdgcn_sched_barrier(0);
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_epi += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -2102,6 +2130,15 @@ static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
     else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                            \
   } while (0)
 
+// the bias / activation instantiations (w4_direct_ba_ok problems: the vision tower and the projector): one tile per workgroup only - the streaming
+// kernel has no registers left for the bias / activation epilogue (it spills, and a kernel whose K-loop is an asm block must not touch scratch)
+#define W4_LAUNCH_BA(GRID_)                                                                                                  \
+  do {                                                                                                                       \
+    const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
+    if (ob_) hipLaunchKernelGGL((gemm_nt_w4_kernel<true, true>), dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                \
+    else hipLaunchKernelGGL((gemm_nt_w4_kernel<false, true>), dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                   \
+  } while (0)
+
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
   GemmNTArgs a = a_in;
@@ -2129,6 +2166,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     {
       int dev_ = 0; hipDeviceProp_t pr_;
       g_w4s_cus = (hipGetDevice(&dev_) == hipSuccess && hipGetDeviceProperties(&pr_, dev_) == hipSuccess) ? pr_.multiProcessorCount : 256;
@@ -2232,7 +2271,12 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // one 256x256 block per CU and round: below 1.25 rounds the big tile only pays when its last round fills the chip
   // (M = 32362: N = 512 -> 254 blocks, w4 1.10-1.18 PF/s vs 0.75-0.79 for the 128x128 kernel; N = 768 -> 381 blocks = 1.49
   // rounds, w4 1.10 vs 0.84; N = 256 -> 127 blocks, the 128x128 kernel wins 0.77 vs 0.63)
-  const bool plain = !a.bias && !a.act;                 // the 4-wave kernel is instantiated for alpha-only epilogues
+  // the 4-wave kernels' hot instantiations take alpha-only epilogues; bias / quick-GELU / GELU problems (+ an fp32 residual into an fp32 result) run on
+  // their BA instantiations (round 5: the vision tower's and the projector's GEMMs left the 8-wave kernel / the 128x128 kernel for them)
+  static const int env_ba = getenv("OPADPO_W4_BA") ? atoi(getenv("OPADPO_W4_BA")) : 1;
+  const bool ba = env_ba && (g_gemm_variant == 10 || g_gemm_variant == 31) && w4_direct_ba_ok(a) && a.N % P_BN == 0 && off32 &&
+                  (double)(a.M + 256) * a.ldc * (a.out_f32 ? 4 : 2) < 4.0e9;
+  const bool plain = (!a.bias && !a.act) || ba;
   const int pp_slots = ((pp_tiles + 255) / 256) * 256;
   // ragged rows (M ~ 24-26 k): N = 512 -> 188-200 blocks in ONE round, w4 0.088 / 0.256 ms (K = 4096 / 11008) vs 0.121 / 0.424 for the
   // 128x128 kernel; N = 768 -> 282-300 blocks: a tie; N = 256 -> 94-100 blocks: the 128x128 kernel keeps a 5-20 % lead
@@ -2240,7 +2284,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // well, and a deep-K one-round problem of <= 128 tiles (x . A_d^T: N = 256, K = 11008) runs as quarter tiles entirely (4x the blocks)
   const int pp_rem = pp_tiles % 256, pp_nt = (a.K1 + a.K2) / P_BK;
   const bool deep_small = plain && pp_tiles >= 64 && pp_tiles <= 128 && pp_nt >= 128;      // K = 4096 one-round problems measured no gain (0.085 vs 0.081 ms)
-  const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 ||
+  const bool big = g_gemm_variant == 17 || g_gemm_variant == 31 || (g_w4s_few && g_gemm_variant == 10 && plain && pp_tiles >= 16) ||      // (test switch: small problems stream on 8 workgroups)
                    (g_gemm_variant != 4 && (pp_tiles >= 320 || (plain && pp_tiles >= 150 && (pp_tiles <= 256 || pp_rem <= 128)) || deep_small ||
                                             (plain && pp_tiles >= 200 && pp_tiles * 100 >= pp_slots * 88)));
   if (big && pp_tiles > 0) {
@@ -2257,7 +2301,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
       // (964.4 vs 975.2 ms; no tail handling: 982.8) but re-associated the fp32 sums of the tail tiles, i.e. made a row's result depend on
       // the batch's row count; removed.
       if (g_gemm_variant != 31 && (full > 0 || deep_small) && rem > 0 && rem <= (deep_small && full == 0 ? 128 : 64)) {
-        if (full > 0) W4_LAUNCH(full);
+        if (full > 0) { if (ba) W4_LAUNCH_BA(full); else W4_LAUNCH(full); }
         GemmNTArgs t = a;
         t.quarter = 1; t.tile0 = full;
         // (a four-stage ring for these blocks - three K-tiles in flight, one block per CU - measured 973.1 vs 969.9 ms per step: no gain,
@@ -2274,7 +2318,7 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_nt_kernel_x<64, true, 2>), dim3(rem * 4), dim3(256), 65536, st, t);
         return hipGetLastError();
       }
-      W4_LAUNCH(pp_tiles);
+      if (ba) W4_LAUNCH_BA(pp_tiles); else W4_LAUNCH(pp_tiles);
     }
     else                                    // bias / activation epilogues (vision tower, projector): 8 waves x 128x64, 4 phases per K-tile
       hipLaunchKernelGGL(gemm_nt_p8_kernel, dim3(pp_tiles), dim3(512), 2 * P_STAGE, st, a);

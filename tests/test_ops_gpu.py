@@ -171,6 +171,39 @@ def test_gemm_nt_epilogue_large(L, variant):
     L.set_flags(10, True)
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 4096, 192), (12694, 1024, 1024), (10000, 1024, 256)])
+def test_gemm_nt_bias_activation_on_the_4wave_kernel(L, M, N, K):
+    """Round 5: bias / quick-GELU / GELU problems (+ an fp32 residual into an fp32 result) - the vision tower's and the projector's GEMMs - run on the BA
+    instantiations of the 4-wave 256x256 kernel (direct epilogue: alpha, the bias of the lane's 8 columns, activation, residual - epilogue4's order).
+    Default dispatch (variant 10) and the 256x256 kernel on every tile (31) == the 8-wave kernel (17) == the 128x128 kernel (4), bit for bit; rows >= M untouched."""
+    a, b = rnd(M, K, scale=0.5, seed=1), rnd(N, K, scale=0.1, seed=2)
+    bias, res32 = rnd(N, seed=3), torch.randn(M, N, device=dev())
+    outs = {}
+    try:
+        for v in (10, 31, 17, 4):
+            L.set_flags(v, True)
+            o1 = torch.full((M + 2, N), 7.0, dtype=BF, device=dev())
+            L.gemm_nt(a, b, o1[:M], bias=bias, act=1)
+            o2 = torch.full((M + 2, N), 7.0, dtype=torch.float32, device=dev())
+            L.gemm_nt(a, b, o2[:M], bias=bias, residual=res32, alpha=0.5)
+            o3 = torch.full((M + 2, N), 7.0, dtype=BF, device=dev())
+            L.gemm_nt(a, b, o3[:M], bias=bias, act=2)
+            torch.cuda.synchronize()
+            outs[v] = (o1, o2, o3)
+    finally:
+        L.set_flags(10, True)
+    for v in (31, 17, 4):
+        for k in range(3):
+            assert torch.equal(outs[10][k], outs[v][k]), f"variant 10 != variant {v} (output {k})"
+    want = a.float() @ b.float().t()
+    x1 = want + bias.float()
+    assert relerr(outs[10][0][:M], x1 * torch.sigmoid(1.702 * x1)) < 6e-3
+    assert relerr(outs[10][1][:M], 0.5 * want + bias.float() + res32) < 1e-5
+    assert relerr(outs[10][2][:M], torch.nn.functional.gelu(x1)) < 6e-3
+    for k in range(3):
+        assert float((outs[10][k][M:].float() - 7.0).abs().max()) == 0.0
+
+
 def test_gemm_nt_256_kernels_race_screen(L):
     """The two 256x256 kernels (4-wave long-lead w4 = 31 / default for large GEMMs, 8-wave 4-phase p8 = 17) accumulate every
     output in the same k order, so their results must be BIT-identical; repeated on a shape with many K-tiles, a LoRA tail, a ragged M
