@@ -758,7 +758,7 @@ def main():
                 tot_f, tot_ms, n_launch = tot_f + ctx_prof[0], tot_ms + ctx_prof[1], n_launch + ctx_prof[2]
             ach = tot_f / (tot_ms * 1e-3) / 1e12
             traffic, traffic_src = _pmc_traffic()
-            roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, K-loop as one generated asm block with the LDS-DMA pieces at a period of 4 MFMAs, streaming persistent form for the plain products / 128x128 for skinny N; LoRA tail fused by K-concatenation)",
+            roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, K-loop as one generated asm block with the LDS-DMA pieces at a period of 4 MFMAs, streaming persistent form for the plain products / 128x128 for skinny N; LoRA tail fused by K-concatenation; since round 5 the launches also carry the residual adds of the o / down projections and the SwiGLU backward of the down projection's dgrad in their direct epilogues - `unfused_epilogues` holds the rate without that work)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": tot_ms / n_launch,
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
