@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define OPADPO_ABI_VERSION 2      /* 2 (round 5): + opadpo_ctx_wgrad_deterministic, opadpo_allreduce_grads / _reduce_scatter_grads / _all_gather_params; opadpo_gemm_tn_group_workspace_bytes is 0 for MIXED lists too */
+#define OPADPO_ABI_VERSION 2      /* 2 (round 5): + opadpo_ctx_wgrad_deterministic, opadpo_allreduce_grads / _reduce_scatter_grads / _all_gather_params; opadpo_gemm_tn_group_workspace_bytes is 0 for MIXED lists too; context flag bits 13 / 14 (residual adds / SwiGLU backward as their own passes) and bit 6 = the STAGED SwiGLU-backward epilogue */
 #define OPADPO_ACT_NONE 0
 #define OPADPO_ACT_QUICK_GELU 1 /* CLIP MLP  (transformers activations.py quick_gelu) */
 #define OPADPO_ACT_GELU 2       /* mm_projector mlp2x_gelu (erf GELU) */
