@@ -503,6 +503,49 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
   }
 }
 
+// SwiGLU PAIR (merged no-grad pass; weight rows per 128 = [64 gate | 64 up]) in the DIRECT epilogue (round 5): in the accumulator layout the lanes frow 0..7 of a
+// 16-lane row hold gate columns 8 frow + j, the lanes frow 8..15 the up columns of the SAME output columns - lane ^ 8 is the partner (DPP row_ror:8, no LDS).
+// The gate lane finishes rows r = 0, 1 of a row block, the up lane rows 2, 3: each sends the partner the two values it does not finish itself (16 DPP moves
+// per row block), forms silu(gate) * up on the bf16-ROUNDED values with silu_mul_fwd_kernel's formula (bit-identical to projection + silu_mul_fwd and to the
+// staged epilogue) and stores 8 consecutive output columns of its two rows.  No LDS, no barrier: the product streams (gemm_nt_w4s_kernel).
+__host__ __device__ __forceinline__ bool w4_direct_swiglu_pair_ok(const GemmNTArgs& p) {
+  return p.act == OPADPO_ACT_SWIGLU_PAIR && !p.R && !p.bias && !p.out_f32 && p.alpha == 1.0f && p.ldc % 8 == 0 &&
+         ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * 2ull < 0xffffffffull;
+}
+__device__ __forceinline__ void w4_direct_epilogue_swiglu_pair(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * 2u), 0x00020000);
+  const bool is_up = frow >= 8;
+  const int mrow0 = m0 + wr * 128 + 4 * fchk + (is_up ? 2 : 0);           // this lane's two rows of every row block
+  const int ocol = ncol0 / 2 + 8 * (frow & 7);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc_read4(acc[i][j], v[j]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float gt[8], up[8], o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float mine = is_up ? v[j][2 + k] : v[j][k];                   // the value of MY row that I hold (gate lane: gate, up lane: up)
+        const float send = is_up ? v[j][k] : v[j][2 + k];                   // the partner's row
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));      // row_ror:8 = lane ^ 8 inside the 16-lane row
+        gt[j] = bf2f(f2bf(is_up ? recv : mine));
+        up[j] = bf2f(f2bf(is_up ? mine : recv));
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = gt[e] / (1.0f + __expf(-gt[e])) * up[e];
+      const uint4 oa = pack8(o);
+      const u32x4s_t st4 = {oa.x, oa.y, oa.z, oa.w};
+      const unsigned vo = ((unsigned)(mrow0 + i * 16 + k) * (unsigned)p.ldc + (unsigned)ocol) * 2u;
+      if (p.store_nt) __builtin_amdgcn_raw_buffer_store_b128(st4, rC, vo, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(st4, rC, vo, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // SwiGLU backward in the DIRECT epilogue (round 5): the block is d_act[:, ncol0 ..] of the down projection's dgrad, R the stored pre-activations
 // [gate | up] ([M, 2N] bf16), C receives [d_gate | d_up] - the arithmetic of silu_mul_bwd_kernel on the bf16-ROUNDED d_act, so the result is
 // bit-identical to the two-kernel path without d_act ever reaching HBM.  A lane owns 8 consecutive columns of 4 rows per row block: its gate
@@ -689,6 +732,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
     }
     if (w4_direct_swiglu_bwd_ok(p) && !p.swiglu_bwd_staged) {
       w4_direct_epilogue_swiglu_bwd(p, acc, m0, ncol0, wr, frow, fchk);
+      return;
+    }
+    if (w4_direct_swiglu_pair_ok(p) && !p.swiglu_bwd_staged) {      // (swiglu_bwd_staged doubles as "staged epilogues": cross-check of the direct forms)
+      w4_direct_epilogue_swiglu_pair(p, acc, m0, ncol0, wr, frow, fchk);
       return;
     }
     // Staged epilogues (residual operand, SwiGLU pair / backward, rotary embedding): each wave passes its 128x128 block through its own
@@ -968,7 +1015,7 @@ extern "C" int opadpo_debug_w4s_read(unsigned long long* out4, int reset) {
   return (int)e;
 }
 #endif
-template <bool ORDER_B, bool BA = false>
+template <bool ORDER_B, int EPI = 0>      // EPI 0: plain / fp32 residual / SwiGLU backward epilogues (the hot instantiation, at its register limit); 2: SwiGLU pair only (its own code object)
 __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1079,8 +1126,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
 #endif
-    if (p.act == OPADPO_ACT_SWIGLU_BWD) w4_direct_epilogue_swiglu_bwd(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
-    else w4_direct_epilogue<OPADPO_W4S_RPD, BA>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    if constexpr (EPI == 2) w4_direct_epilogue_swiglu_pair(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    else if (p.act == OPADPO_ACT_SWIGLU_BWD) w4_direct_epilogue_swiglu_bwd(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    else w4_direct_epilogue<OPADPO_W4S_RPD, false>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     __builtin_amdgcn_sched_barrier(0);
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_epi += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -2120,9 +2168,12 @@ static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
     const int grid_ = (GRID_), cus_ = g_w4s_few ? 8 : g_w4s_cus;                                                             \
     const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos &&                                                   \
-                         ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || (w4_direct_swiglu_bwd_ok(a) && !a.swiglu_bwd_staged)) &&                   \
+                         ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || ((w4_direct_swiglu_bwd_ok(a) || w4_direct_swiglu_pair_ok(a)) && !a.swiglu_bwd_staged)) && \
                          a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
-    if (stream_) {                                                                                                           \
+    if (stream_ && a.act == OPADPO_ACT_SWIGLU_PAIR) {                                                                        \
+      if (ob_) hipLaunchKernelGGL((gemm_nt_w4s_kernel<true, 2>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);           \
+      else hipLaunchKernelGGL((gemm_nt_w4s_kernel<false, 2>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);              \
+    } else if (stream_) {                                                                                                    \
       if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                \
       else hipLaunchKernelGGL(gemm_nt_w4s_kernel<false>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                   \
     }                                                                                                                        \
@@ -2166,6 +2217,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     {

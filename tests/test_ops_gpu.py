@@ -1119,7 +1119,7 @@ def test_errors_are_loud(L):
         L.gemm_nt(a, b, out)
 
 
-@pytest.mark.parametrize("M,F,K", [(700, 256, 128), (3000, 1408, 192), (40, 128, 64)])
+@pytest.mark.parametrize("M,F,K", [(700, 256, 128), (3000, 1408, 192), (40, 128, 64), (2600, 1024, 256)])
 def test_gemm_nt_swiglu_pair(L, M, F, K):
     """ACT_SWIGLU_PAIR: weight rows arranged per 128 as [64 gate | 64 up]; the projection's epilogue writes silu(gate) * up
     ([M, F]) - bit-identical to the projection followed by opadpo_silu_mul_fwd (same bf16 rounding of the pre-activations)."""
@@ -1138,6 +1138,19 @@ def test_gemm_nt_swiglu_pair(L, M, F, K):
     assert float((got[M:].float() - 7.0).abs().max()) == 0.0
     ref = torch.nn.functional.silu(x.float() @ wgu[:F].float().t()) * (x.float() @ wgu[F:].float().t())
     assert relerr(got[:M], ref) < 2e-2
+    # round 5: the pair epilogue is DIRECT (gate and up lanes exchange through DPP, no LDS) and streams - the 8-workgroup test walk and the 256x256 kernel on
+    # every tile give the same bits
+    lib = L.load()
+    try:
+        for variant, flags in ((10, 1 | 1024), (31, 1)):
+            lib.opadpo_set_flags(variant, flags)
+            g2 = torch.full((M + 2, F), 7.0, dtype=BF, device=dev())
+            L.gemm_nt(x, w_sw, g2[:M], act=L.ACT_SWIGLU_PAIR)
+            torch.cuda.synchronize()
+            assert torch.equal(g2[:M], want), (variant, flags)
+            assert float((g2[M:].float() - 7.0).abs().max()) == 0.0
+    finally:
+        lib.opadpo_set_flags(10, 1)
 
 
 @pytest.mark.parametrize("R,K,r,mode", [(17, 4096, 0, "bf16"), (17, 4096, 256, "f32"), (18, 4096, 256, "bf16_res"), (19, 2048, 0, "f32_res"),
