@@ -406,7 +406,7 @@ __host__ __device__ __forceinline__ bool w4_direct_ba_ok(const GemmNTArgs& p) {
 }
 // Direct epilogue of the 4-wave 256x256 kernels: accumulator layout acc[i][j][r] of lane (frow, fchk) = row i*16 + 4*fchk + r, column 8*frow + j of the
 // wave's 128x128 block (the 8 fragments j of one (i, r) are 8 CONSECUTIVE columns).  No LDS, no barrier.
-template <int PD = 1, bool BA = false>      // PD = row blocks of the residual operand requested ahead of the accumulator read-out (32 registers each); BA = bias / activation modes
+template <int PD = 1, bool BA = false, bool NORES = false>      // PD = row blocks of the residual operand requested ahead of the accumulator read-out (32 registers each); BA = bias / activation modes; NORES = no residual support compiled in
 __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
   // DIRECT epilogue (plain and alpha-scaled products, bf16 or fp32): 16-byte stores straight from the accumulators, one instruction =
   // 4 rows x 256 contiguous bytes (bf16) - no LDS round trip, no barrier.  (Round 1 staged every block through LDS because a fragment
@@ -419,7 +419,7 @@ __device__ __forceinline__ void w4_direct_epilogue(const GemmNTArgs& p, f32x4_t 
   // fp32 residual operand (w4_direct_resid_ok: fp32 R, fp32 C, 32-bit offsets): C = alpha * acc + R with the R rows of row block i + 1 requested
   // (non-temporal, 8 x 16 B per lane) before row block i is read out of the accumulators - the residual stream of the decoder layers is added here
   // instead of in the RMSNorm pass that follows (same fp32 operation on the same operands: same bits)
-  const bool has_r = p.R != nullptr;
+  const bool has_r = !NORES && p.R != nullptr;
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(has_r ? p.R : p.C), 0, has_r ? (int)((unsigned)p.M * (unsigned)p.ldr * 4u) : 0, 0x00020000);
   u32x4s_t rq[PD + 1][4][2];
   auto r_issue = [&](int i, u32x4s_t (&dst)[4][2]) {
@@ -544,6 +544,58 @@ __device__ __forceinline__ void w4_direct_epilogue_swiglu_pair(const GemmNTArgs&
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// Table-free rotary embedding (rope_pos) in the DIRECT epilogue (round 5, streaming kernel's EPI = 3 instantiation): a wave's 128 columns are one head, the
+// rotation partners d and d + 64 sit in lanes l and l ^ 8 of a 16-lane row (as the SwiGLU pair's gate / up).  The low lane finishes rows r = 0, 1 of a row block
+// for BOTH partner columns, the high lane rows 2, 3: 16 DPP moves per row block, one sin / cos pair per (row, frequency) - half the transcendental work of the
+// staged form, where both partner lanes evaluate the same angle - and two 16-byte stores per row.  Arithmetic of the staged epilogue / rope_kernel on the
+// bf16-ROUNDED projection: out[d] = x[d] cos - x[d+64] sin, out[d+64] = x[d+64] cos + x[d] sin, angle = fract(pos * theta^(-2i/128) / 2 pi) revolutions.
+__device__ __forceinline__ void w4_direct_epilogue_rope_pos(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int m0, int ncol0, int wr, int frow, int fchk) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(w4_uniform_ptr(p.C), 0, (int)((unsigned)p.M * (unsigned)p.ldc * 2u), 0x00020000);
+  const bool is_hi = frow >= 8;
+  const int gh = frow & 7;
+  const int mrow0 = m0 + wr * 128 + 4 * fchk + (is_hi ? 2 : 0);
+  const int col_lo = ncol0 + 8 * gh;
+  float frev[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) frev[e] = __builtin_amdgcn_exp2f(-(float)(2 * (gh * 8 + e)) * (1.0f / 128.0f) * p.rope_l2theta) * 0.15915494309189535f;
+  int posn[2] = {p.rope_pos[min(mrow0, p.M - 1)], p.rope_pos[min(mrow0 + 1, p.M - 1)]};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v[8][4];
+    const int pos2[2] = {posn[0], posn[1]};
+    if (i + 1 < 8) { posn[0] = p.rope_pos[min(mrow0 + (i + 1) * 16, p.M - 1)]; posn[1] = p.rope_pos[min(mrow0 + (i + 1) * 16 + 1, p.M - 1)]; }      // next row block's positions
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc_read4(acc[i][j], v[j]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float posf = (float)pos2[k];
+      float olo[8], ohi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float mine = is_hi ? v[j][2 + k] : v[j][k];
+        const float send = is_hi ? v[j][k] : v[j][2 + k];
+        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));      // row_ror:8 = lane ^ 8
+        const float xlo = bf2f(f2bf(is_hi ? recv : mine)), xhi = bf2f(f2bf(is_hi ? mine : recv));
+        const float x = __builtin_amdgcn_fractf(posf * frev[j]);
+        const float cs = __builtin_amdgcn_cosf(x), sn = __builtin_amdgcn_sinf(x);
+        olo[j] = xlo * cs + -1.0f * (xhi * sn);
+        ohi[j] = xhi * cs + 1.0f * (xlo * sn);
+      }
+      const uint4 a = pack8(olo), b = pack8(ohi);
+      const u32x4s_t sa = {a.x, a.y, a.z, a.w}, sb = {b.x, b.y, b.z, b.w};
+      const unsigned vo = ((unsigned)(mrow0 + i * 16 + k) * (unsigned)p.ldc + (unsigned)col_lo) * 2u;
+      if (p.store_nt) { __builtin_amdgcn_raw_buffer_store_b128(sa, rC, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(sb, rC, vo + 128u, 0, 2); }
+      else { __builtin_amdgcn_raw_buffer_store_b128(sa, rC, vo, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(sb, rC, vo + 128u, 0, 0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__host__ __device__ __forceinline__ bool w4_direct_rope_pos_ok(const GemmNTArgs& p) {
+  return p.rope_pos && !p.rope_cos && !p.R && !p.bias && p.act == 0 && !p.out_f32 && p.alpha == 1.0f && p.rope_cols % 128 == 0 && p.ldc % 8 == 0 &&
+         ((unsigned long long)p.M + 256ull) * (unsigned)p.ldc * 2ull < 0xffffffffull;
 }
 
 // SwiGLU backward in the DIRECT epilogue (round 5): the block is d_act[:, ncol0 ..] of the down projection's dgrad, R the stored pre-activations
@@ -1015,7 +1067,7 @@ extern "C" int opadpo_debug_w4s_read(unsigned long long* out4, int reset) {
   return (int)e;
 }
 #endif
-template <bool ORDER_B, int EPI = 0>      // EPI 0: plain / fp32 residual / SwiGLU backward epilogues (the hot instantiation, at its register limit); 2: SwiGLU pair only (its own code object)
+template <bool ORDER_B, int EPI = 0>      // EPI 0: plain / fp32 residual / SwiGLU backward epilogues (the hot instantiation, at its register limit); 2: SwiGLU pair only; 3: table-free rotary embedding (own code objects)
 __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1127,6 +1179,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
 #endif
     if constexpr (EPI == 2) w4_direct_epilogue_swiglu_pair(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    else if constexpr (EPI == 3) {
+      if (n0 + wc * 128 < p.rope_cols) w4_direct_epilogue_rope_pos(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+      else w4_direct_epilogue<1, false, true>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
+    }
     else if (p.act == OPADPO_ACT_SWIGLU_BWD) w4_direct_epilogue_swiglu_bwd(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     else w4_direct_epilogue<OPADPO_W4S_RPD, false>(p, acc, m0, n0 + wc * 128, wr, frow, fchk);
     __builtin_amdgcn_sched_barrier(0);
@@ -2163,6 +2219,7 @@ static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B fir
 // Streaming form (gemm_nt_w4s_kernel, round 5) for the plain products whenever every workgroup gets at least two tiles: one workgroup per CU walks
 // the tile list and keeps its K-tile pipeline full across output tiles.  OPADPO_W4S=0 / variant 31: one tile per workgroup (A/B, cross-check).
 static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
+static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("OPADPO_ROPE_DIRECT")) : 1;      // 0: table-free rotary embedding through the staged epilogue (rounds 3-4; A/B)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
@@ -2170,7 +2227,10 @@ static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
     const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos &&                                                   \
                          ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || ((w4_direct_swiglu_bwd_ok(a) || w4_direct_swiglu_pair_ok(a)) && !a.swiglu_bwd_staged)) && \
                          a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
-    if (stream_ && a.act == OPADPO_ACT_SWIGLU_PAIR) {                                                                        \
+    if (g_w4s > 0 && g_gemm_variant != 31 && env_rope_direct_ && w4_direct_rope_pos_ok(a) && a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_) { \
+      if (ob_) hipLaunchKernelGGL((gemm_nt_w4s_kernel<true, 3>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);           \
+      else hipLaunchKernelGGL((gemm_nt_w4s_kernel<false, 3>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);              \
+    } else if (stream_ && a.act == OPADPO_ACT_SWIGLU_PAIR) {                                                                 \
       if (ob_) hipLaunchKernelGGL((gemm_nt_w4s_kernel<true, 2>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);           \
       else hipLaunchKernelGGL((gemm_nt_w4s_kernel<false, 2>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);              \
     } else if (stream_) {                                                                                                    \
@@ -2217,6 +2277,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);

@@ -1331,6 +1331,22 @@ def test_gemm_nt_rope_pos(L, lora):
            L.ptr(got2), got2.stride(0), M + sh, 3 * H, L.ptr(pos2), 10000.0, 2 * H, L.stream())
     torch.cuda.synchronize()
     assert torch.equal(got2[sh:], got[:M])
+    # round 5: on the streaming kernel the rotation runs in the DIRECT epilogue (partner columns d / d + 64 meet through DPP, one sin / cos pair per (row,
+    # frequency)); the 8-workgroup test walk sends this small problem there - same bits as the staged epilogue above
+    lib = L.load()
+    try:
+        lib.opadpo_set_flags(10, 1 | 1024)
+        got3 = torch.full((M + 1, 3 * H), 7.0, dtype=BF, device=dev())
+        L.call("opadpo_gemm_nt_rope_pos", L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), K, L.ptr(a2), a2.stride(0) if lora else 0,
+               L.ptr(b2), b2.stride(0) if lora else 0, r if lora else 0, kw.get("a2_group_n", 0), kw.get("a2_group_stride", 0),
+               L.ptr(got3), got3.stride(0), M, 3 * H, L.ptr(row_pos), 10000.0, 2 * H, L.stream())
+        torch.cuda.synchronize()
+    finally:
+        lib.opadpo_set_flags(10, 1)
+    assert float((got3[M:].float() - 7.0).abs().max()) == 0.0
+    d3 = (got3[:M, :2 * H].float() - want).abs()
+    assert bool((d3 <= tol).all()), f"direct epilogue: max excess {(d3 - tol).max().item()}"
+    assert torch.equal(got3[:M], got[:M]), f"direct != staged rotary epilogue on {int((got3[:M] != got[:M]).sum())} elements"
 
 
 @pytest.mark.parametrize("M", [64, 50, 33, 16, 5])
