@@ -66,6 +66,33 @@ def _parity_record():
     return None
 
 
+def _parity_in_run():
+    """The same record PRODUCED IN THIS RUN (round 6): a child process runs tests/test_fullsize_gpu.py::test_p7_full_depth_32_layers_against_the_oracle on this
+    GPU after the timed region (HIP product path vs three oracle passes - fp32, bf16-emulating, merged - all evaluated in the child; ~1 min
+    with its import and weight initialisation) and its report gpurun_out/parity_fulldepth.json is read back.  The oracle is the CHECKER here, never
+    part of what is timed.  Falls back to the committed record (source says which) when the child fails."""
+    import subprocess
+    rep = os.path.join(REPO, "gpurun_out", "parity_fulldepth.json")
+    t0 = time.time()
+    try:
+        if os.path.exists(rep):
+            os.remove(rep)
+        env = dict(os.environ, GRAFT_REPO_ROOT=REPO)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                            os.path.join(REPO, "tests", "test_fullsize_gpu.py") + "::test_p7_full_depth_32_layers_against_the_oracle"],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+        j = json.load(open(rep))
+        out = dict(j["bench_line"])
+        out.update({"source": "this run (child process: tests/test_fullsize_gpu.py::test_p7_full_depth_32_layers_against_the_oracle)",
+                    "assertions_passed": r.returncode == 0, "oracle_device": j.get("oracle_device"), "child_wall_s": time.time() - t0,
+                    "oracle_seconds": {k: j[k] for k in ("oracle_fp32_seconds", "oracle_emu_bf16_seconds", "oracle_emu_merged_seconds") if k in j}})
+        return out
+    except Exception as e:
+        out = _parity_record() or {}
+        out["in_run_error"] = repr(e)[:200]
+        return out
+
+
 def _cpu_full_record():
     """The oracle timed DIRECTLY at full depth on the GPU box's host cores (tools/cpu_baseline_full.py: one whole pair, 32 layers, nothing
     extrapolated; minutes of CPU work, so it is a committed record - newest profiles/r*_cpu_baseline_full.json - not part of this run)."""
@@ -265,18 +292,18 @@ def rollout_leg(eng, d, dev, batches=(8, 64), steps=64):
 def extra_config(which):
     """Sub-records of the default line for the BASELINE.json configurations the headline does not cover (measured AFTER the timed region,
     in a child process on the same GPU; never part of `value`):
-      thirteen_b : configs[3]'s model at 1 GPU - LLaVA-1.5-13B LoRA DPO, 12 packed pairs per step, 3 timed steps (this file, --model 13b);
+      thirteen_b : configs[3]'s model at 1 GPU - LLaVA-1.5-13B LoRA DPO, 12 packed pairs per step, 6 timed steps (this file, --model 13b);
       recipe     : the reference's NATIVE unit at the shipped recipe's lengths (run/train_opa_dpo.sh:39-50: query 128, response 896, 3 responses
                    per sample + 2 on the CoPO-masked image, AncPO; DPOTrainer.step() of the product, tools/sample_bench.py) - samples/s."""
     import subprocess
     env = dict(os.environ)
     try:
         if which == "thirteen_b":
-            cmd = [sys.executable, os.path.abspath(__file__), "--model", "13b", "--steps", "3", "--warmup", "1", "--batch-pool", "3",
+            cmd = [sys.executable, os.path.abspath(__file__), "--model", "13b", "--steps", "6", "--warmup", "1", "--batch-pool", "3",
                    "--no-cpu-baseline", "--no-rollout", "--no-side-legs", "--no-exchange-probe", "--no-extra-configs"]
         else:
             cmd = [sys.executable, os.path.join(REPO, "tools", "sample_bench.py")]
-            env.update(SB_T="896", SB_BATCH=env.get("OPADPO_BENCH_RECIPE_BATCH", "4"), SB_STEPS="3")
+            env.update(SB_T="896", SB_BATCH=env.get("OPADPO_BENCH_RECIPE_BATCH", "4"), SB_STEPS="6")
         t0 = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -357,9 +384,44 @@ def rank_info(rank, local, use_gpu=True):
     info = {"rank": rank, "local_rank": local, "pid": os.getpid(), "device": "cpu"}
     if use_gpu and torch.cuda.is_available():
         pr = torch.cuda.get_device_properties(local)
-        info.update({"device": pr.name, "uuid": str(getattr(pr, "uuid", "")), "arch": getattr(pr, "gcnArchName", ""),
+        # the device's identity as the runtime reports it: the UUID, else its PCI address, else the ordinal (never empty: check_dist_record counts
+        # distinct identities over the ranks, and a missing attribute on some torch build must not cost the first unattended N > 1 run its line)
+        uid = str(getattr(pr, "uuid", "") or "")
+        if not uid:
+            uid = "pci:%s:%s:%s" % (getattr(pr, "pci_domain_id", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "pci_device_id", "?")) \
+                if hasattr(pr, "pci_bus_id") else f"ordinal:{local}"
+        info.update({"device": pr.name, "uuid": uid, "arch": getattr(pr, "gcnArchName", "") or "unknown",
                      "compute_units": pr.multi_processor_count, "hbm_GB": pr.total_memory / 1e9})
     return info
+
+
+DIST_FIELDS = ("backend", "collective_library", "world_size", "allreduce_of_ones", "ranks", "ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks")
+RANK_FIELDS = ("rank", "local_rank", "pid", "device")
+RANK_FIELDS_GPU = ("uuid", "arch", "compute_units", "hbm_GB")
+
+
+def check_dist_record(rec, world, on_gpu):
+    """Schema of the `dist` record of an N > 1 line (real run and --dry-run print the SAME fields; tests/test_bench_launcher_cpu.py): a SCALE line must
+    not come back without the all-reduce of ones (= the world size, through the collective library itself) and what every rank was bound to (on GPUs:
+    the device UUIDs, all different).  Raises ValueError - rank 0 then fails the run loudly instead of printing an unverifiable line."""
+    miss = [k for k in DIST_FIELDS if k not in rec]
+    if miss:
+        raise ValueError(f"dist record lacks {miss}")
+    if rec["world_size"] != world or float(rec["allreduce_of_ones"]) != float(world):
+        raise ValueError(f"dist record: world_size {rec['world_size']} / all-reduce of ones {rec['allreduce_of_ones']} for a {world}-rank launch")
+    ranks = rec["ranks"]
+    if len(ranks) != world or sorted(x.get("rank", -1) for x in ranks) != list(range(world)):
+        raise ValueError(f"dist record: ranks {[x.get('rank') for x in ranks]} for world size {world}")
+    for x in ranks:
+        need = RANK_FIELDS + (RANK_FIELDS_GPU if on_gpu else ())
+        m = [k for k in need if k not in x or x[k] in (None, "")]
+        if m:
+            raise ValueError(f"dist record: rank {x.get('rank')} lacks {m}")
+    if len({x["pid"] for x in ranks}) != world:
+        raise ValueError("dist record: ranks share a pid")
+    if on_gpu and world > 1 and len({x["uuid"] for x in ranks}) != world and os.environ.get("OPADPO_BENCH_SHARE_DEVICE") != "1":
+        raise ValueError(f"dist record: {world} ranks on {len({x['uuid'] for x in ranks})} distinct device UUID(s)")
+    return True
 
 
 def preflight(world, dev, backend):
@@ -502,6 +564,7 @@ def dry_run(args, world, rank, local):
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
+        check_dist_record(out["dist"], world, use_gpu)
         print(json.dumps(out), flush=True)
     return 0 if ok else 3
 
@@ -773,7 +836,10 @@ def main():
                           "rows": (f"ragged: padding positions (left pad of the query, right pad of each response) are not rows of any kernel; {rows_per_pair:.0f} rows per pair "
                                    f"and pass on average instead of {q_len + d.n_patches - 1 + 2 * t_len}; the top decoder layer's o-projection / MLP only on the rows the head reads" if (ragged and pack) else "padded: every position is a row, like the reference computes it"),
                           "reference_adapter": ("frozen adapter merged into a second bf16 copy of the LLM projections at load (no LoRA GEMMs in the no-grad pass)"
-                                                if not args.no_merge_ref else "unmerged (K-concatenated LoRA in the no-grad pass)"),
+                                                " - NOT the trainer CLI's default: opadpo_train runs --merge_ref_adapter 0 out of the box, whose step is the"
+                                                " `reference_unmerged` record of this line (~4 % slower); --merge_ref_adapter 1 selects this form"
+                                                if not args.no_merge_ref else "unmerged (K-concatenated LoRA in the no-grad pass; the trainer CLI's default)"),
+                          "headline_is_trainer_cli_default": bool(args.no_merge_ref),
                           "pairs_per_microbatch_per_gpu": args.pairs, "grad_accum": args.accum,
                           "global_pairs_per_step": pairs_per_step, "seq_len": q_len + t_len,
                           "parallelism": f"dp{world}" + ("+zero1" if args.optimizer_mode == "zero1" and world > 1 else ""),
@@ -799,10 +865,12 @@ def main():
                                 "samples": len(ok), "sample_errors": len(sampler.samples) - len(ok) if sampler else 0,
                                 "trace": ok[::max(1, len(ok) // 60)]}
         if dist_rec is not None:
+            check_dist_record(dist_rec, world, True)
             out["dist"] = dist_rec
-        par = _parity_record()
-        if par is not None and args.model == "7b":
-            out["parity"] = par
+        if args.model == "7b" and (world > 1 or args.no_extra_configs):      # default N = 1 line: measured in this run, below (after the state is released)
+            par = _parity_record()
+            if par is not None:
+                out["parity"] = par
         if world == 1 and not args.no_side_legs and not args.op_level:
             def timed(n_warm, n, **kw):
                 for _ in range(n_warm):
@@ -905,7 +973,14 @@ def main():
                                                         ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r, lora_alpha=d.lora_alpha), q_len, t_len)
                 full = _cpu_full_record()
                 if full is not None:
-                    out["cpu_baseline"]["full_depth_measured"] = full
+                    # `value` is the DIRECTLY MEASURED figure (one whole pair at the full 32-layer depth on the host cores, tools/cpu_baseline_full.py;
+                    # minutes of CPU work, hence a committed record of an earlier box); the bounded sample timed in THIS run (one decoder layer,
+                    # scaled by the depth) rides beside it as `in_run_extrapolation` - it leaves out the head, the vision tower and the memory
+                    # effects of a full-depth graph and reads ~1.5 x higher
+                    extrap = out["cpu_baseline"]
+                    out["cpu_baseline"] = {"value": full["value"], "unit": full["unit"], "cores": full["cores"], "kind": "port", "extrapolated": False,
+                                           "sample": full["sample"], "source": full["source"], "seconds_per_pair": full["seconds_per_pair"],
+                                           "in_run_extrapolation": extrap}
                 try:
                     out["cpu_baseline"]["config_p_direct"] = cpu_baseline_config_p(dict(
                         hidden=d.hidden, n_layers=d.n_layers, n_heads=d.n_heads, head_dim=d.head_dim, ffn=d.ffn, vocab=d.vocab, lora_r=d.lora_r,
@@ -939,6 +1014,7 @@ def main():
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
+                out["parity"] = _parity_in_run()
                 out["thirteen_b"] = extra_config("thirteen_b")
                 out["recipe"] = extra_config("recipe")
     else:

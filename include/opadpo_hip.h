@@ -319,7 +319,10 @@ int opadpo_ctx_create(const opadpo_dims* dims, int device, opadpo_ctx** out);
 void opadpo_ctx_destroy(opadpo_ctx* ctx);
 const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
 int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
-/* gemm_variant / use_tr as in opadpo_set_flags, for this context only; -1 = process default.  Context-only: use_tr bit 5 = keep the
+/* gemm_variant as in opadpo_set_flags, for this context only; -1 = process default.  use_tr is a SEPARATE bit space from the process flags: only
+ * bits 0-4 mean what they mean in opadpo_set_flags (passed on to the kernels of this context); bits 5-14 are the context switches listed here
+ * (process bits 5-11 - decode GEMM kernel, sampler sweep, 8-workgroup walk, attn64 - have no per-context form and are NOT read from this value).
+ * Context bits: use_tr bit 5 = keep the
  * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
  * bit 6 = SwiGLU backward in the LDS-STAGED epilogue of the down projection's dgrad (the form of rounds 3-4, which measured 0.35 % slower per step
  * than its own launch; the default since round 5 is the direct-epilogue form, see bit 14); bit 7 = top decoder layer on every row (default on ragged rows: its o-projection and MLP run only

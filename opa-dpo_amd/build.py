@@ -33,7 +33,8 @@ def _digest(paths):
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    # everything a translation unit can #include or is generated from: headers, the generated asm K-loops (*.inc) and their generators (*_gen.py)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc", "_gen.py"))]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "opadpo_hip.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     stamp = os.path.join(OBJDIR, "stamp")

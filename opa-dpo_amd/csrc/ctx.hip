@@ -1034,8 +1034,9 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     cv.take<float>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>(MH); cv.take<bf16_t>((size_t)M * F); cv.take<bf16_t>((size_t)M * 2 * F); cv.take<bf16_t>(MH);
     cv.take<bf16_t>((size_t)M * 3 * H); cv.take<float>((size_t)S * nh * Lp); cv.take<bf16_t>((size_t)M * r); cv.take<bf16_t>((size_t)M * 2 * r);
     cv.take<bf16_t>((size_t)M * 3 * r); cv.take<bf16_t>((size_t)M * r); cv.take<float>(sv->Uc > 0 ? MH : 1); cv.take<float>(tn_ws_floats); need = cv.off; }
-  if (R == 0) return 0;                               // no valid response token: every gradient of this pass is exactly zero
   const bool first = layer_hi == d.n_layers - 1;
+  if (first) c->wgrad_det = 1;                        // of THIS backward: cleared below by any grouped wgrad launch that fell back to fp32 atomics
+  if (R == 0) return 0;                               // no valid response token: every gradient of this pass is exactly zero (nothing flushed: trivially reproducible)
   if (!first && (c->ws_bytes < need || !c->ws)) return cbad(c, __func__, "ranged backward must start at the top layer");
   void* base = ctx_ws(c, need, st);
   if (!base) return cfail(c, hipErrorOutOfMemory, __func__);
@@ -1049,7 +1050,6 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
   bf16_t* dt_ra = cv.take<bf16_t>((size_t)M * r);        // dT of the o projection (dt_r keeps the down projection's until the grouped wgrad)
   float* d_full = cv.take<float>(sv->Uc > 0 ? MH : 1);   // compact top layer: its residual gradient scattered back to every row
   float* tn_ws = cv.take<float>(tn_ws_floats);
-  c->wgrad_det = tn_ws_floats > 1 ? 1 : 0;
   const LoraOff o = lora_off(d);
   if (first) {
     if (!dlogp) return cbad(c, __func__, "null dlogp");
@@ -1151,7 +1151,9 @@ int opadpo_seq_logprobs_bwd(opadpo_ctx* c, opadpo_saved* sv, const float* dlogp,
     { GemmNTArgs g = gemm(c, dqkv, 3 * H, wt + o.b_qkv, H, H, dt_3r, 3 * r, 0, M, 3 * r); g.alpha = s; g.a1_group_n = r; g.a1_group_stride = H; CK(run_gemm(c, g, st)); }
     CK(tn(dqkv, 3 * H, b.t_qkv, 3 * r, gr + o.b_qkv, r, 3 * H, r, H, r, M));
     CK(tn(dt_3r, 3 * r, b.n1, H, gr + o.a_qkv, H, 3 * r, H, 0, 0, M));
-    CK(launch_gemm_tn_group(wg, nwg, st, tn_ws_floats > 1 ? tn_ws : nullptr, tn_ws_floats > 1 ? tn_ws_floats * sizeof(float) : 0));
+    { int ord = 1;      // what the launches of THIS list actually did (not a synthetic shape list): ordered reduce for every problem, or atomics somewhere
+      CK(launch_gemm_tn_group(wg, nwg, st, tn_ws_floats > 1 ? tn_ws : nullptr, tn_ws_floats > 1 ? tn_ws_floats * sizeof(float) : 0, &ord));
+      if (!ord) c->wgrad_det = 0; }
     if (i > 0 || d_feats) {          // layer-0 input is the frozen embedding / image features: no further dgrad in the DPO stage
       { GemmNTArgs g = gemm(c, dqkv, 3 * H, w.wqkv_t, 3 * H, 3 * H, d_n, H, 0, M, H); tail(g, dt_3r, 3 * r, wt + o.a_qkv, 3 * r, 3 * r); CK(run_gemm(c, g, st)); }
       const float* dres = d_h;

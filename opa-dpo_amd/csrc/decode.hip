@@ -702,8 +702,9 @@ hipError_t launch_rope_kv_append(bf16_t* qkv, int ld, const float* cosb, const f
 }
 
 // 1 (default): one-wave tail on the kept tokens after the top-k threshold; 0: the full vocabulary sweeps (identical draws; the exactness test's yardstick)
-static int g_sample_compact = getenv("OPADPO_SAMPLE_COMPACT") ? atoi(getenv("OPADPO_SAMPLE_COMPACT")) : 1;
-void opadpo_set_sample_compact(bool on) { g_sample_compact = on ? 1 : 0; }
+static const int env_sample_compact_ = getenv("OPADPO_SAMPLE_COMPACT") ? atoi(getenv("OPADPO_SAMPLE_COMPACT")) : 1;
+static int g_sample_compact = env_sample_compact_;
+void opadpo_set_sample_compact(int on) { g_sample_compact = on < 0 ? env_sample_compact_ : (on ? 1 : 0); }      // -1: the environment decides (as for attn64)
 hipError_t launch_sample(const float* logits, int ldl, int rows, int V, float temperature, int top_k, float top_p,
                          uint64_t seed, uint64_t step, const int32_t* step_ptr, uint8_t* finished, int pad_id, int eos_id,
                          int32_t* out, int32_t* history, hipStream_t st) {

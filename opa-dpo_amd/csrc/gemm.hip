@@ -2208,7 +2208,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
-  opadpo_set_sample_compact((use_tr & 512) == 0);
+  opadpo_set_sample_compact((use_tr & 512) ? 0 : -1);      // bit 9 forces the diagnostic sampler; otherwise OPADPO_SAMPLE_COMPACT decides
   g_w4s_few = (use_tr & 1024) != 0;
   g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
@@ -2455,7 +2455,7 @@ static void tn_w4_geometry(GemmTNGroup& G, int& n_runs, int& smax) {
   const long long per = (total + n_runs - 1) / n_runs;
   smax = (int)((per - 1) / chunk_len) + 2;                       // units a run of `per` consecutive K-steps can touch
 }
-static hipError_t tn_w4_launch(GemmTNGroup& G, hipStream_t st, void* ws, size_t ws_bytes) {
+static hipError_t tn_w4_launch(GemmTNGroup& G, hipStream_t st, void* ws, size_t ws_bytes, bool* ordered = nullptr) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
@@ -2465,6 +2465,7 @@ static hipError_t tn_w4_launch(GemmTNGroup& G, hipStream_t st, void* ws, size_t 
   tn_w4_geometry(G, n_runs, smax);
   const size_t need = (size_t)n_runs * smax * 65536 * sizeof(float);
   const bool det = ws && ws_bytes >= need;
+  if (ordered) *ordered = det;
   G.ws = det ? (float*)ws : nullptr;
   G.smax = det ? smax : 0;
   hipLaunchKernelGGL(gemm_tn_w4_kernel, dim3(n_runs), dim3(256), 2 * P_STAGE, st, G);
@@ -2853,7 +2854,9 @@ int gemm_nt_dec64_splits(int N, int K, int splits) {
   return splits > nt ? nt : splits;
 }
 
-hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace, size_t workspace_bytes) {
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace, size_t workspace_bytes, int* all_ordered) {
+  // *all_ordered (optional) = 1 when EVERY problem of this call left through the ordered reduce (bit-reproducible), 0 when any took fp32 atomics
+  if (all_ordered) *all_ordered = 1;
   if (n <= 0) return hipSuccess;
   bool ok = n <= 8;
   for (int i = 0; i < n && ok; ++i) ok = tn_w4_ok(list[i], list[0].M);
@@ -2864,9 +2867,12 @@ hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, v
         GemmTNGroup G;
         G.g[0] = list[i]; G.n = 1;
         G.tile_end[0] = (list[i].N1 / 256) * (list[i].N2 / 256);
-        e = tn_w4_launch(G, st, workspace, workspace_bytes);      // launches of one stream run in order: the workspace is free again
+        bool ord = false;
+        e = tn_w4_launch(G, st, workspace, workspace_bytes, &ord);      // launches of one stream run in order: the workspace is free again
+        if (all_ordered && !ord) *all_ordered = 0;
       } else {
         e = launch_gemm_tn(list[i], st);
+        if (all_ordered && list[i].M > 0) *all_ordered = 0;
       }
       if (e != hipSuccess) return e;
     }
@@ -2880,5 +2886,8 @@ hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, v
     tiles += (list[i].N1 / 256) * (list[i].N2 / 256);
     G.tile_end[i] = tiles;
   }
-  return tn_w4_launch(G, st, workspace, workspace_bytes);
+  bool ord = false;
+  const hipError_t e = tn_w4_launch(G, st, workspace, workspace_bytes, &ord);
+  if (all_ordered && !ord) *all_ordered = 0;
+  return e;
 }

@@ -101,8 +101,8 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
 // all problems must share M and be eligible for the 256x256 kernel (N1, N2 % 256 == 0, q_group_n1 % 256 == 0); otherwise the
 // problems are launched one by one
-void opadpo_set_sample_compact(bool on);
-hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0);
+void opadpo_set_sample_compact(int on);      // 1 / 0 force, -1 = OPADPO_SAMPLE_COMPACT (default 1)
+hipError_t launch_gemm_tn_group(const GemmTNArgs* list, int n, hipStream_t st, void* workspace = nullptr, size_t workspace_bytes = 0, int* all_ordered = nullptr);
 // bytes of workspace that make a grouped launch of these problems deterministic (0: the problems do not run on the 256x256 kernel)
 size_t gemm_tn_group_workspace_bytes(const GemmTNArgs* list, int n);
 

@@ -284,7 +284,7 @@ def main():
     ins = [f'"{{s{52 + p}}}"(w4k_pcx[{p}])' for p in range(8)] + [f'"{{s{60 + p}}}"(w4k_pcy[{p}])' for p in range(8)] + ['"{s37}"(w4k_has2)']
     ins += [f'[vo2_{p}] "v"(w4k_vo2[{p}])' for p in range(16)]
     ins += [f'[dx2_{q}] "s"(w4k_dx2[{q}])' for q in range(4)] + [f'[dy2_{q}] "s"(w4k_dy2[{q}])' for q in range(4)] + ['[koff2] "s"(w4k_koff2)']
-    clob = [f'"v{i}"' for i in range(4, 132)] + ['"memory"', '"scc"']
+    clob = [f'"v{i}"' for i in range(4, 132)] + ['"m0"', '"memory"', '"scc"']
 
     def wrap(name, items):
         L.append(f"#define {name} \\")
@@ -300,7 +300,7 @@ def main():
     s_ins = [x for x in ins if "koff2" not in x] + ['"{s36}"(w4k_first)']
     s_ins += [f'[vo3_{p}] "v"(w4k_vo3[{p}])' for p in range(16)]
     s_ins += [f'[dx3_{q}] "s"(w4k_dx3[{q}])' for q in range(4)] + [f'[dy3_{q}] "s"(w4k_dy3[{q}])' for q in range(4)]
-    s_clob = [f'"v{i}"' for i in range(68, 132)] + ['"s35"', '"memory"', '"scc"']
+    s_clob = [f'"v{i}"' for i in range(68, 132)] + ['"s35"', '"m0"', '"memory"', '"scc"']
     wrap("W4S_OUTS", s_outs)
     wrap("W4S_INS", s_ins)
     wrap("W4S_CLOBBERS", s_clob)

@@ -89,3 +89,42 @@ def test_dry_run_records_what_each_rank_is_bound_to():
     ds = json.loads(r.stdout.strip().splitlines()[-1])["dist"]
     assert len({x["pid"] for x in ds["ranks"]}) == 2 and all("device" in x for x in ds["ranks"])
     assert "collective_library" in ds
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_dist_record_schema_is_the_same_for_dry_and_real_runs():
+    """Round 6: an N > 1 line cannot come back without `allreduce_of_ones` / what each rank was bound to.  bench.check_dist_record is
+    called on rank 0 before EITHER line is printed; here: the dry run's record passes it, and records a SCALE line must never carry are refused."""
+    import copy
+    B = _load_bench()
+    r = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--model", "tiny", "--steps", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    ds = json.loads(r.stdout.strip().splitlines()[-1])["dist"]
+    for k in B.DIST_FIELDS:
+        assert k in ds, k
+    assert B.check_dist_record(ds, 2, False)
+    gpu = copy.deepcopy(ds)                     # the same record as a GPU run would print it: per-rank device UUIDs are mandatory there
+    with pytest.raises(ValueError, match="uuid"):
+        B.check_dist_record(gpu, 2, True)
+    for i, x in enumerate(gpu["ranks"]):
+        x.update(uuid=f"GPU-{i}", arch="gfx950", compute_units=256, hbm_GB=288.0)
+    assert B.check_dist_record(gpu, 2, True)
+    same = copy.deepcopy(gpu)
+    same["ranks"][1]["uuid"] = same["ranks"][0]["uuid"]
+    with pytest.raises(ValueError, match="distinct device UUID"):
+        B.check_dist_record(same, 2, True)
+    for drop in ("allreduce_of_ones", "ranks", "collective_library"):
+        bad = {k: v for k, v in gpu.items() if k != drop}
+        with pytest.raises(ValueError):
+            B.check_dist_record(bad, 2, True)
+    short = copy.deepcopy(gpu)
+    short["allreduce_of_ones"] = 1.0
+    with pytest.raises(ValueError):
+        B.check_dist_record(short, 2, True)

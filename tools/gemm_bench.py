@@ -221,7 +221,9 @@ def main():
         torch.cuda.synchronize()
         return
     vlist = [int(v) for v in os.environ["GB_VARIANTS"].split(",")] if (only == "gemm" and os.environ.get("GB_VARIANTS")) else None
-    for glds in (vlist if vlist else ((31, 17, 4) if not only else ((31, 17, 4) if only == "gemm" else ((17, 31) if only == "pp" else ())))):
+    # variant 10 = the DEFAULT dispatch (what ships: streaming w4s where the launcher chooses it) is the FIRST row of every campaign, so the per-shape
+    # vs-vendor table measures the shipped kernel choice; 31 / 17 / 4 force one kernel (31 also disables streaming)
+    for glds in (vlist if vlist else ((10, 31, 17, 4) if not only else ((10, 31, 17, 4) if only == "gemm" else ((17, 31) if only == "pp" else ())))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
