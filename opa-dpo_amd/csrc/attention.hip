@@ -513,7 +513,7 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
 }
 
 #ifndef ATTN32_RESCALE_LOG2
-#define ATTN32_RESCALE_LOG2 0.0f    // the shipped 32-row forward: every change of a row maximum rescales (see the kernel)
+#define ATTN32_RESCALE_LOG2 8.0f    // shipped since round 6: the reference maximum moves when some row's maximum grew by more than 2^8 (see the kernel); 0.0f = every change rescales (rounds 3-5)
 #endif
 #ifndef ATTN_RESCALE_LOG2
 #define ATTN_RESCALE_LOG2 8.0f      // growth of a row maximum (in log2 units of the scaled scores) that moves the 64-row forward kernel's reference maximum; 0 = every change
@@ -713,10 +713,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other 32 keys of the tile for this q row
       const float m_new = fmaxf(m_run, mx);
-      // lazy rescale: the running maximum settles after a few tiles.  A threshold form (reference maximum kept until some row's maximum has grown by more
-      // than 2^8 in the exponent's units; exact: O / l and lse do not depend on the reference) is -2.5 % per launch with random inputs, where the plain rule fires in
-      // most tiles (profiles/r05h_ab_attn_rescale.txt) - NOT shipped: the different rounding pattern moved the one-layer parity statistic from 9.87e-4 to 1.011e-3,
-      // across north_star's literal 1e-3 (tests/test_bench_config_parity_gpu.py); build with -DATTN32_RESCALE_LOG2=8.0f to get it.
+      // lazy rescale, THRESHOLD form (shipped since round 6): the reference maximum is kept until some row's maximum has grown by more than 2^8 in the
+      // exponent's units (exact: O / l and lse do not depend on the reference; P <= 2^8 keeps bf16's relative precision, the row sums are fp32).  With random
+      // inputs the plain rule (every change rescales, -DATTN32_RESCALE_LOG2=0.0f: rounds 3-5) fires in most tiles: -2.5 % per launch (profiles/r05h_ab_attn_rescale.txt).
+      // Round 5 withheld it because it moved the one-layer parity statistic from 9.87e-4 to 1.011e-3, across north_star's literal 1e-3 - but at that
+      // scale the ORACLE's own bf16 emulation reads 9.99e-4 / 1.009e-3 (its two realisations): the statistic is the arithmetic's floor.  Judged against that
+      // floor (tests/test_bench_config_parity_gpu.py::test_north_star_1e3_literal..., round 6) this form reads 1.002 x the floor at std 0.02 and 0.96 x at
+      // std 0.01 (3.1e-4, where the literal 1e-3 is asserted), the plain form 0.98 x / 0.99 x (profiles/r06a_literal_floor.json).
       if (__ballot((m_new - m_run) * scale2 > ATTN32_RESCALE_LOG2)) {
         const float alpha = fast_exp2((m_run - m_new) * scale2);
         l_run *= alpha;
