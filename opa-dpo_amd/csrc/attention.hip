@@ -720,14 +720,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
       // scale the ORACLE's own bf16 emulation reads 9.99e-4 / 1.009e-3 (its two realisations): the statistic is the arithmetic's floor.  Judged against that
       // floor (tests/test_bench_config_parity_gpu.py::test_north_star_1e3_literal..., round 6) this form reads 1.002 x the floor at std 0.02 and 0.96 x at
       // std 0.01 (3.1e-4, where the literal 1e-3 is asserted), the plain form 0.98 x / 0.99 x (profiles/r06a_literal_floor.json).
-      if (__ballot((m_new - m_run) * scale2 > ATTN32_RESCALE_LOG2)) {
-        const float alpha = fast_exp2((m_run - m_new) * scale2);
+      // The decision is PER ROW (the two lanes of a row agree: mx was exchanged above): a row whose own maximum did not cross the threshold keeps its
+      // reference (alpha = exp2(0) = 1 exactly, its bits untouched) even when the wave enters the branch for another row - so a row's bits depend on
+      // its own keys only, never on the later rows that share its wave (tests/test_fullsize_gpu.py P5: an edited token leaves every earlier log-prob BIT-equal).
+      const bool moves = (m_new - m_run) * scale2 > ATTN32_RESCALE_LOG2;
+      if (__ballot(moves)) {
+        const float m_to = moves ? m_new : m_run;
+        const float alpha = fast_exp2((m_run - m_to) * scale2);
         l_run *= alpha;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m_run = m_new;
+        m_run = m_to;
       }
       // exponent arguments and row sums two values per instruction (v_pk_fma_f32 / v_pk_add_f32: full rate on CDNA3+); the exp itself
       // is one quarter-rate v_exp_f32 per score.  exp2(-inf) = 0 for masked scores (m stays finite: NEG_BIG floor)
