@@ -346,7 +346,7 @@ int opadpo_ctx_set_flags(opadpo_ctx* ctx, int gemm_variant, int use_tr);
 /* how the LAST opadpo_seq_logprobs_bwd of this context flushed its LoRA wgrads: 1 = ordered reduce (bit-reproducible), 0 = fp32 atomics
  * (bit 12 set, or lora_r % 256 != 0), -1 = no backward yet */
 int opadpo_ctx_wgrad_deterministic(const opadpo_ctx* ctx);
-/* return cached arenas and the workspace to the allocator */
+/* return cached arenas and the workspace to the allocator, and forget the largest-arena-so-far hints (the next pass sizes its arena for its own batch) */
 int opadpo_ctx_trim(opadpo_ctx* ctx);
 size_t opadpo_ctx_bytes_peak(const opadpo_ctx* ctx);
 /* live measurement of the dominant kernel: while enabled every gemm_nt launch of the context is bracketed by HIP events on the launch

@@ -665,6 +665,9 @@ int opadpo_ctx_trim(opadpo_ctx* c) {
   for (auto& b : c->cache) (void)hipFree(b.p);
   c->cache.clear();
   if (c->ws) { if (c->alloc) c->dealloc(c->ws, c->alloc_user); else (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+  // the "largest activation arena seen so far" hints go too: after a trim the next pass sizes its arena for ITS batch shape (round 6: a 22-pair
+  // training forward followed by a 2-pair one kept asking for the 22-pair arena - 155 GB at 7B - next to whatever else the host had allocated since)
+  for (auto& row : c->arena_hint) for (auto& h : row) h = 0;
   return 0;
 }
 
