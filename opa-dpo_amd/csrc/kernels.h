@@ -113,6 +113,7 @@ hipError_t launch_rmsnorm_fwd(const void* x, int x_f32, const bf16_t* w, bf16_t*
 hipError_t launch_rmsnorm_sum_fwd(const void* resid, int resid_f32, const float* partials, int n_partials, size_t partial_stride, const bf16_t* w,
                                   float* x_out, bf16_t* y, float* rstd, int rows, int H, float eps, hipStream_t st);
 hipError_t launch_gemm_nt_dec64(const GemmNTArgs& a, int mode, int splits, hipStream_t st);
+int gemm_nt_dec64_splits(int N, int K, int splits);
 hipError_t launch_rmsnorm_bwd(const bf16_t* dy, const void* x, int x_f32, const bf16_t* w, const float* rstd, const void* dres,
                               int dres_f32, float* dx_f32, bf16_t* dx_bf16, int rows, int H, hipStream_t st);
 hipError_t launch_layernorm_fwd(const void* x, const bf16_t* w, const bf16_t* b, void* y, int rows, int H, float eps, hipStream_t st, int x_f32 = 0, int y_f32 = 0);
