@@ -703,10 +703,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   // clamped to M - 1).  No vector ALU work per piece in the loop: the K position is the scalar offset, the descriptor sits in SGPRs.
   auto calc_voff = [&](bool second, unsigned (&vo)[16]) {
     const unsigned lda = (unsigned)(second ? p.lda2 : p.lda1) * 2u, ldb = (unsigned)(second ? p.ldb2 : p.ldb1) * 2u;
+    // K-folded problem (GemmNTArgs::b1_fold_n): column group g of the output reads rows 0 .. fold_n - 1 of B1 from column g * b1_fold_koff on
+    const unsigned fold_g = (!second && p.b1_fold_n > 0) ? (unsigned)(n0 / p.b1_fold_n) : 0u;
+    const unsigned bn0 = (unsigned)n0 - fold_g * (unsigned)(p.b1_fold_n > 0 ? p.b1_fold_n : 0), bkoff = fold_g * (unsigned)p.b1_fold_koff * 2u;
 #pragma unroll
     for (int pi = 0; pi < 8; ++pi) {
       vo[8 + pi] = min((unsigned)m0 + lrow + pi * 8u, m_last) * lda + csw[pi & 1];
-      vo[pi] = ((unsigned)n0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb + (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16);
+      vo[pi] = (bn0 + (unsigned)(wave * 64 + (pi >> 1) * 16 + (pi & 1)) + lrowB_lo) * ldb + (unsigned)((spos ^ ((wave * 4 + (pi >> 1)) & 7)) * 16) + bkoff;
     }
   };
   unsigned vo1[16], vo2[16];
@@ -2224,7 +2227,7 @@ static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
     const int grid_ = (GRID_), cus_ = g_w4s_few ? 8 : g_w4s_cus;                                                             \
-    const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos &&                                                   \
+    const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos && a.b1_fold_n == 0 &&                               \
                          ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || ((w4_direct_swiglu_bwd_ok(a) || w4_direct_swiglu_pair_ok(a)) && !a.swiglu_bwd_staged)) && \
                          a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
     if (g_w4s > 0 && g_gemm_variant != 31 && env_rope_direct_ && w4_direct_rope_pos_ok(a) && a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_) { \
@@ -2250,8 +2253,55 @@ static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("
     else hipLaunchKernelGGL((gemm_nt_w4_kernel<false, true>), dim3(GRID_), dim3(256), 2 * P_STAGE, st, a);                   \
   } while (0)
 
+// ---- K-folded r-wide products (round 6) ---------------------------------------------------------------------------------------------
+// The N = lora_r = 256 products of the LoRA path (t = s x A^T for the o / down projections, dT = s dY B for their dgrads: four per layer and pass) are ONE
+// column of 256x256 tiles: 96 workgroups on 256 CUs at the bench row count (the 128x128 kernel ran them at 0.4-0.55 PF/s, the quarter-tile form of the
+// K = 11008 one at 0.55: profiles/r05zz_step_by_grid.txt - 17 ms of the step at 3 x their HBM floor).  Here the K range is cut in TWO halves that run as
+// two column groups of one launch of the 256x256 kernel (192 workgroups, fp32 partial products side by side in a workspace; GemmNTArgs::b1_fold_n), and a
+// small pass adds the halves in slice order, scales and rounds: C = bf16(alpha (P0 + P1)).  The rule depends on N and K only, never on M, and every row is
+// summed the same way whatever the batch around it (P3: bit-equal), but it IS a different fp32 association than one pass over K (half sums, then their sum).
+namespace {
+__global__ __launch_bounds__(256) void gemm_fold2_reduce_kernel(const float* __restrict__ ws, bf16_t* __restrict__ C, int ldc, int M, int N, float alpha) {
+  const int per_row = N >> 3;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)M * per_row) return;
+  const int m = (int)(idx / per_row), c = (int)(idx % per_row) << 3;
+  const float* p0 = ws + (size_t)m * 2 * N + c;
+  const float4 a0 = *(const float4*)p0, a1 = *(const float4*)(p0 + 4), b0 = *(const float4*)(p0 + N), b1 = *(const float4*)(p0 + N + 4);
+  const float v[8] = {(a0.x + b0.x) * alpha, (a0.y + b0.y) * alpha, (a0.z + b0.z) * alpha, (a0.w + b0.w) * alpha,
+                      (a1.x + b1.x) * alpha, (a1.y + b1.y) * alpha, (a1.z + b1.z) * alpha, (a1.w + b1.w) * alpha};
+  *(uint4*)(C + (size_t)m * ldc + c) = pack8(v);
+}
+}  // namespace
+static float* g_fold_ws = nullptr;
+static size_t g_fold_ws_bytes = 0;      // one buffer per process = per GPU, used in stream order (grown on demand: a device-synchronising hipFree + hipMalloc, first steps only)
+static bool gemm_nt_kfold_ok(const GemmNTArgs& a, int variant) {
+  static const int env_fold = getenv("OPADPO_KFOLD") ? atoi(getenv("OPADPO_KFOLD")) : 1;      // 0: the r-wide products in one pass over K (rounds 1-5; A/B)
+  return env_fold && (variant == 10 || variant == 31) && !(a.act & OPADPO_GEMM_STREAM) && (a.act & 0xff) == 0 && a.N == 256 && a.K2 == 0 && !a.bias && !a.R &&
+         !a.out_f32 && !a.rope_cos && !a.rope_pos && a.a1_group_n <= 0 && a.b1_fold_n == 0 && !a.quarter && a.K1 % 128 == 0 && a.K1 >= 1024 && a.ldc % 8 == 0 &&
+         a.lda1 % 8 == 0 && a.ldb1 % 8 == 0 && (double)a.M * a.lda1 * 2 < 4.0e9 && (double)a.N * a.ldb1 * 2 < 4.0e9 && (double)(a.M + 256) * 512 * 4 < 4.0e9;
+}
+
 hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   if (a_in.M <= 0) return hipSuccess;
+  if (gemm_nt_kfold_ok(a_in, a_in.variant >= 0 ? a_in.variant : ::g_gemm_variant)) {
+    const size_t need = (size_t)a_in.M * 512 * sizeof(float);
+    if (need > g_fold_ws_bytes) {
+      if (g_fold_ws) (void)hipFree(g_fold_ws);
+      g_fold_ws = nullptr; g_fold_ws_bytes = 0;
+      const size_t want = need + need / 4;
+      if (hipMalloc(&g_fold_ws, want) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+      g_fold_ws_bytes = want;
+    }
+    GemmNTArgs f = a_in;
+    f.N = 512; f.K1 = a_in.K1 / 2; f.a1_group_n = 256; f.a1_group_stride = a_in.K1 / 2; f.b1_fold_n = 256; f.b1_fold_koff = a_in.K1 / 2;
+    f.C = g_fold_ws; f.ldc = 512; f.out_f32 = 1; f.alpha = 1.0f;
+    hipError_t e = launch_gemm_nt(f, st);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)a_in.M * (256 / 8);
+    hipLaunchKernelGGL(gemm_fold2_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_fold_ws, (bf16_t*)a_in.C, a_in.ldc, a_in.M, 256, a_in.alpha);
+    return hipGetLastError();
+  }
   GemmNTArgs a = a_in;
   if (g_w4_order == -1) { const char* v = getenv("OPADPO_W4_ORDER"); g_w4_order = v ? atoi(v) : -2; }
   // C leaves the 4-wave 256x256 kernel's direct epilogue as NON-TEMPORAL stores (round 4): at the end of a round all 256 workgroups write
@@ -2293,6 +2343,12 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_tail64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     attr_set = true;
+  }
+  if (a.b1_fold_n > 0) {      // K-folded problem (built above): every tile on gemm_nt_w4_kernel, the only kernel that reads the folded B1
+    if (a.N % P_BN || a.K1 % P_BK || a.K2) return hipErrorInvalidValue;
+    const int tiles = ((a.M + P_BM - 1) / P_BM) * (a.N / P_BN);
+    W4_LAUNCH(tiles);
+    return hipGetLastError();
   }
   // Decode-sized weight streams with nothing fused (no LoRA tail, bias, residual or scale; plain or SwiGLU-pair epilogue) go to the whole-line
   // streaming kernel behind opadpo_gemm_nt_decode from 8 token rows up: the rollout's q|k|v, gate|up and lm_head at 8 sequences (decode step

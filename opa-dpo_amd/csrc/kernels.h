@@ -39,6 +39,10 @@ struct GemmNTArgs {
   int quarter = 0;
   int swiglu_bwd_staged = 0;            // OPADPO_ACT_SWIGLU_BWD through the LDS-staged epilogue of rounds 3-4 (cross-check of the direct form)
   int store_nt = 0;                     // direct epilogue of the 256x256 4-wave kernels: non-temporal C stores (set by launch_gemm_nt)
+  // K-FOLDED problem (set by launch_gemm_nt only; round 6): the product's K range is cut into N / b1_fold_n slices that run as column groups of ONE launch -
+  // output columns [g * b1_fold_n, (g + 1) * b1_fold_n) are the partial product of slice g: A1 columns from g * a1_group_stride (the grouped-A1 rule),
+  // B1 = rows 0 .. b1_fold_n - 1 of the caller's matrix read from column g * b1_fold_koff on.  gemm_nt_w4_kernel only.
+  int b1_fold_n = 0, b1_fold_koff = 0;
 };
 
 struct GemmTNArgs {

@@ -113,6 +113,35 @@ def test_gemm_nt_skinny(L, M, tr, N, K1, K2, groups):
     assert torch.equal(o5, o32)
 
 
+@pytest.mark.parametrize("K", [4096, 11008, 1024])
+def test_gemm_nt_r_wide_products_k_folded(L, K):
+    """Round 6: the N = lora_r = 256 products of the LoRA path (t = s x A^T, dT = s dY B; peft lora_A / lora_B forward and autograd, rl_models.py:120) run
+    K-FOLDED on the 256x256 kernel: two K halves as two column groups of one launch, then out = bf16(alpha (P0 + P1)).  Against torch fp32; against the
+    one-pass 128x128 kernel (variant 4: another fp32 association, same bf16 result up to an ulp); the rule depends on N and K only, so a row's bits do not
+    depend on the rows around it (a 700-row batch == its first 300 rows run alone == its last row run alone), strided operands, alpha."""
+    N, alpha = 256, 2.0
+    A = rnd(700, K + 64, scale=0.5, seed=1); W = rnd(N, K + 32, scale=0.05, seed=2)
+    a, w = A[:, 32:32 + K], W[:, 16:16 + K]
+    want = alpha * (a.float() @ w.float().t())
+    outs = {}
+    for variant in (10, 31, 4):
+        L.set_flags(variant, True)
+        O = torch.full((701, N + 16), 7.0, dtype=BF, device=dev())
+        L.gemm_nt(a, w, O[:700, 8:8 + N], alpha=alpha)
+        torch.cuda.synchronize()
+        outs[variant] = O[:700, 8:8 + N].clone()
+        assert relerr(outs[variant], want) < 6e-3
+        O[:700, 8:8 + N] = 7.0
+        assert float((O.float() - 7.0).abs().max()) == 0.0               # nothing outside the window written
+    assert torch.equal(outs[10], outs[31])
+    d4 = (outs[10].float() - outs[4].float()).abs()
+    assert float(d4.max()) <= 2.0 ** -7 * float(want.abs().max()) and float((d4 > 0).float().mean()) < 0.2      # the fold re-associates fp32 sums: rare one-ulp flips
+    L.set_flags(10, True)
+    o300 = torch.empty(300, N, dtype=BF, device=dev()); o1 = torch.empty(1, N, dtype=BF, device=dev()); again = torch.empty(700, N, dtype=BF, device=dev())
+    L.gemm_nt(a[:300], w, o300, alpha=alpha); L.gemm_nt(a[699:], w, o1, alpha=alpha); L.gemm_nt(a, w, again, alpha=alpha)
+    assert torch.equal(o300, outs[10][:300]) and torch.equal(o1, outs[10][699:]) and torch.equal(again, outs[10])
+
+
 @pytest.mark.parametrize("M", [2, 8, 13, 24, 31, 50])
 def test_gemm_nt_decode_strided_operands(L, M):
     """Decode-schedule kernels with every operand a column slice of a wider buffer (lda / ldb / ldc / ldr != logical width),
