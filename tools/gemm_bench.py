@@ -209,7 +209,8 @@ def main():
         return
     if only == "pmc":      # few launches of the two big shapes, default variant only (PMC passes serialize kernels)
         L.set_flags(int(os.environ.get("GB_VARIANT", 10)), True)
-        for name, N, K1, K2, grp in shapes[:2]:
+        pmc_shapes = [sh for sh in shapes if sh[0] in os.environ["GB_SHAPES"].split(",")] if os.environ.get("GB_SHAPES") else shapes[:2]
+        for name, N, K1, K2, grp in pmc_shapes:
             a1 = torch.randn(M, K1, device=dev).to(BF)
             b1 = (torch.randn(N, K1, device=dev) * 0.02).to(BF)
             out = torch.empty(M, N, dtype=BF, device=dev)
