@@ -594,8 +594,6 @@ def main():
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the 1-rank timing of the gradient exchange path")
     ap.add_argument("--no-merge-ref", action="store_true", help="keep the frozen reference adapter unmerged (K-concatenated LoRA in the no-grad pass too)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `thirteen_b` (BASELINE.json configs[3] at 1 GPU) and `recipe` (the reference's native unit: 3 responses, response_len 896, CoPO) sub-records (each runs in a child process after the 7B state is released)")
-    ap.add_argument("--overlap-ref", type=int, default=int(os.environ.get("OPADPO_BENCH_OVERLAP_REF", 0)),
-                    help="1: the no-grad reference pass runs on a SECOND stream (its own context, same borrowed weights) beside the policy forward - the two passes are independent until the loss; the tails of one pass's launches fill with the other's workgroups (experiment)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / exchange self-check without kernels (gloo on a box with fewer GPUs than ranks)")
     ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"], help="force the process-group backend (gloo: --dry-run on CPU, or the one-device test of the N > 1 path)")
     args = ap.parse_args()
@@ -665,13 +663,7 @@ def main():
         ref_ad.merge_into_base(base)
     torch.cuda.empty_cache()
     policy = AutoregressivePolicy(eng, pol_ad, t_len, pack_responses=pack)
-    eng_ref, ref_stream = eng, None
-    if args.overlap_ref and not args.op_level:
-        eng_ref = CtxEngine(base, ragged=not args.padded)      # its own workspace arena: the two passes run at the same time
-        if args.ctx_flags >= 0:
-            eng_ref.set_flags(use_tr=args.ctx_flags)
-        ref_stream = torch.cuda.Stream(device=dev)
-    ref_policy = AutoregressivePolicy(eng_ref, ref_ad, t_len, pack_responses=pack)
+    ref_policy = AutoregressivePolicy(eng, ref_ad, t_len, pack_responses=pack)
     opt = FlatAdamW(pol_ad.master, pol_ad.grad, pol_ad.work, lr=1e-6, max_grad_norm=1.0, mode=args.optimizer_mode,
                     bucket_bounds=layer_buckets(pol_ad.layer_numel, d.n_layers, 4))
 
@@ -704,20 +696,11 @@ def main():
             # anything back from the device
             kw = dict(queries=b["queries"], queries_attn_masks=b["queries_attn_masks"], image_feats=feats,
                       chosen_response=b["chosen"], rejected_response=b["rejected"], row_lead=b["row_lead"], row_lens=b["row_lens"])
-            if ref_stream is not None:
-                cur = torch.cuda.current_stream()
-                ref_stream.wait_stream(cur)
-                with torch.cuda.stream(ref_stream), torch.no_grad():
-                    r = ref_policy(**kw)
-                o = policy(**kw)
-                cur.wait_stream(ref_stream)
-                for v_ in r.values():
-                    if torch.is_tensor(v_):
-                        v_.record_stream(cur)
-            else:
-                with torch.no_grad():
-                    r = ref_policy(**kw)
-                o = policy(**kw)
+            # (round 6: the reference pass on a second stream beside the policy forward - the two are independent until the loss - measured 1.5 % SLOWER:
+            # the passes' one-tile-per-workgroup launches interleave on the CUs and halve each other's L2 share; profiles/r06b_ab_overlap_ref.txt)
+            with torch.no_grad():
+                r = ref_policy(**kw)
+            o = policy(**kw)
             loss, _, _ = pair_loss(largs, o["chosen_response_logprobs"], o["rejected_response_logprobs"],
                                    r["chosen_response_logprobs"], r["rejected_response_logprobs"])
             policy.layer_done_hook = hook if mi == len(batches) - 1 else None
