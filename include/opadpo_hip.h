@@ -55,8 +55,7 @@ const char* opadpo_last_error(void);
  * 48 / 64 / 128 rows; tests), bit 9 = opadpo_sample runs its full vocabulary sweeps instead of the one-wave tail on the kept tokens (identical draws; the
  * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree), bit 10 = the streaming 256x256 GEMM runs on 8
  * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count),
- * bit 11 = head_dim-128 attention forward on the experimental 64-rows-per-wave kernel (one wave per SIMD, K / V tiles by LDS-DMA; round 5, measured slower
- * than the shipped 32-rows-per-wave kernel - kept for the next round's work, profiles/r05g_attn_fwd64.txt; also OPADPO_ATTN64=1). */
+ * bit 11 = unused since round 6 (rounds 5: an experimental 64-rows-per-wave attention forward, measured slower and removed). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------
@@ -321,7 +320,7 @@ const char* opadpo_ctx_last_error(const opadpo_ctx* ctx);
 int opadpo_ctx_set_allocator(opadpo_ctx* ctx, opadpo_alloc_fn alloc, opadpo_free_fn free_fn, void* user);
 /* gemm_variant as in opadpo_set_flags, for this context only; -1 = process default.  use_tr is a SEPARATE bit space from the process flags: only
  * bits 0-4 mean what they mean in opadpo_set_flags (passed on to the kernels of this context); bits 5-14 are the context switches listed here
- * (process bits 5-11 - decode GEMM kernel, sampler sweep, 8-workgroup walk, attn64 - have no per-context form and are NOT read from this value).
+ * (process bits 5-10 - decode GEMM kernel, sampler sweep, 8-workgroup walk - have no per-context form and are NOT read from this value).
  * Context bits: use_tr bit 5 = keep the
  * 16/32-row streaming GEMMs for rollouts of 33..64 sequences (default there: the LDS-ring decode GEMM, opadpo_gemm_nt_decode);
  * bit 6 = SwiGLU backward in the LDS-STAGED epilogue of the down projection's dgrad (the form of rounds 3-4, which measured 0.35 % slower per step

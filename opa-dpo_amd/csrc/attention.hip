@@ -515,9 +515,6 @@ __device__ __forceinline__ void tile_commit_k32(char* dst, const TileRegs<128>& 
 #ifndef ATTN32_RESCALE_LOG2
 #define ATTN32_RESCALE_LOG2 8.0f    // shipped since round 6: the reference maximum moves when some row's maximum grew by more than 2^8 (see the kernel); 0.0f = every change rescales (rounds 3-5)
 #endif
-#ifndef ATTN_RESCALE_LOG2
-#define ATTN_RESCALE_LOG2 8.0f      // growth of a row maximum (in log2 units of the scaled scores) that moves the 64-row forward kernel's reference maximum; 0 = every change
-#endif
 #ifndef OPADPO_ATTN_ABL
 #define OPADPO_ATTN_ABL 0      // ablation builds (results WRONG, timing only): 1 no max / exp / row sums, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no barrier, 16 no tile staging, 32 no K fragment reads, 64 no V fragment reads
 #endif                         // 128 / 256 / 512: the tile loop of the 32-row forward runs at most 0 / 1 / 4 tiles (what a workgroup costs besides its tiles)
@@ -823,395 +820,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnArgs p) {
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// Forward, round 5 (head_dim 128): 64 q rows per wave, ONE wave per SIMD (512-register budget), block = 4 waves = 256 q rows.
-//
-// Why: the 32-row kernel above reads every K and V fragment of a 64-key tile once per 32 q rows - 32 KiB of LDS reads per wave and tile, 8 waves
-// per CU: 256 KiB + 64 KiB of tile commits per round of wave-tiles = 2560 cycles of the CU's 128 B/clk LDS pipe against 2048 cycles of MFMA on a
-// SIMD, and the build with every MFMA and the whole softmax removed still needs 2600 cycles of the kernel's 4000 (profiles/r05e_attn_fwd_ablation.txt):
-// the forward is bound by its LDS traffic, not by the matrix or vector pipes.  Here a wave owns TWO 32-row halves g = 0, 1 (same lane layout as the
-// 32-row kernel, so a row's arithmetic - and its bits - are unchanged) and every fragment is read ONCE for both: 16 KiB of fragment reads per 32 q rows.
-// With one wave per SIMD nothing else hides the softmax, so the halves are software-pipelined inside the wave and the MFMAs of one half are
-// interleaved in program order with the VALU work of the other:
-//   phase 0   S_0 = K . Q_0^T          16 MFMAs (the 16 K fragments stay in registers)
-//   phase 1   softmax_0 (VALU)     ||  S_1 = K . Q_1^T, 16 MFMAs from the held fragments
-//   phase 2   softmax_1 (VALU)     ||  O_0 += V^T . P_0^T, 16 MFMAs (the 16 V fragments, read here, stay in registers)
-//   phase 3   O_1 += V^T . P_1^T       16 MFMAs from the held fragments
-// Tile staging, swizzles, masks, dead-tile rules and the O epilogue are those of attn_fwd32_kernel.
-template <int I> struct IC { static constexpr int v = I; };
-template <int I, int N, typename F>
-__device__ __forceinline__ void sfor(F&& f) {
-  if constexpr (I < N) { f(IC<I>{}); sfor<I + 1, N>(f); }
-}
-
-// single-instruction VALU helpers for the one-wave-per-SIMD kernel (hipcc would SLP-pack adjacent f32 operations into v_pk_* - slower beside MFMAs -
-// and canonicalise fmaxf operands)
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-// volatile: keeps its place among the other volatile statements (the trans-use distance below is a property of the source order)
-__device__ __forceinline__ float vadd_keep(float a, float b) { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float vadd_nop(float a, float b) { float d; asm volatile("s_nop 0\n\tv_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ float vadd(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-
-// asm MFMAs with fixed register classes (hipcc pads no wait states around them: see the nop helpers).  S accumulates in arch VGPRs (A = K fragment in VGPRs,
-// B = Q fragment in the accumulator file), O in the accumulator file (A = V fragment, B = P fragment in VGPRs).
-__device__ __forceinline__ void mfma_s0(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b)); }
-__device__ __forceinline__ void mfma_s(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b)); }
-__device__ __forceinline__ void mfma_o(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
-__device__ __forceinline__ void nop12_v(f32x16_t& d) { asm volatile("s_nop 11" : "+v"(d)); }          // an MFMA's D -> a VALU reader: 12 states
-__device__ __forceinline__ void nop12_a4(f32x16_t& a, f32x16_t& b, f32x16_t& c, f32x16_t& d) { asm volatile("s_nop 11" : "+a"(a), "+a"(b), "+a"(c), "+a"(d)); }
-__device__ __forceinline__ void nop2_v(bf16x8_t& d) { asm volatile("s_nop 1" : "+v"(d)); }             // a VALU-written VGPR -> an MFMA operand
-__device__ __forceinline__ void keep_v(const bf16x8_t& a) { asm volatile("" :: "v"(a)); }
-__device__ __forceinline__ void lane32_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }   // a[32..63] <-> b[0..31]
-
-#ifndef A64_ABL
-#define A64_ABL 0      // ablation builds of attn_fwd64_kernel (results WRONG, timing only): 1 no softmax VALU, 2 no P V MFMAs, 4 no S^T MFMAs, 8 no cross-lane max, 16 no rescale, 32 no V fragment reads, 64 no K fragment reads, 128 no tile staging
-#endif
-__global__ __launch_bounds__(256) void attn_fwd64_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HD = 128, TILE = 64 * HD * 2, NST = 3;   // 16 KiB per K or V tile; ring of NST stages [K | V]
-  uint8_t* const ms_base = (uint8_t*)(smem + NST * 2 * TILE);  // NST x 80 mask bytes
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int ql = lane & 31, hi = lane >> 5;
-  const int n_qt = (p.L + 255) / 256;
-  int s, h, qi;
-  attn_block_map(p, n_qt, qi, h, s);
-  const int qt = n_qt - 1 - qi;                           // heavier (later) causal tiles first
-  const int q0 = qt * 256;
-  const Geo ge = load_geo(p, s);
-  const int L = ge.L;
-  if (q0 >= L) return;
-  const bool kmask = (p.causal & 2) && p.key_mask;
-  if (kmask) {                                            // all-padding q tile: zeros, as the other forward kernels
-    uint8_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int a_ = q0 + i * 64 + lane;
-      m |= a_ < L ? p.key_mask[ge.row0 + a_] : (uint8_t)0;
-    }
-    if (__ballot(m != 0) == 0) {
-      for (int i = tid; i < 256 * 16; i += 256) {
-        const int row = q0 + (i >> 4);
-        if (row < L) *(uint4*)(p.o + (ge.row0 + row) * p.ldo + h * HD + (i & 15) * 8) = make_uint4(0u, 0u, 0u, 0u);
-      }
-      if (q0 + tid < L && p.lse) p.lse[stat_idx(p, ge, s, h, q0 + tid)] = NEG_BIG;
-      return;
-    }
-  }
-  const int qlo = q0 + w * 64;                                        // this wave's 64 rows; half g = rows qlo + 32 g + ql
-  bool live[2], pad[2];
-  int qpos[2], xhi[2], xhi_first[2], xhi_last[2], qhi[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const int glo = qlo + 32 * g;
-    live[g] = glo < L; pad[g] = false;
-    qpos[g] = glo + ql;
-    qhi[g] = min(glo + 31, L - 1);
-    if (kmask && live[g]) {                                           // 32 rows that are all masked as keys are padding too: zeros
-      const uint8_t mq = qpos[g] < L ? p.key_mask[ge.row0 + qpos[g]] : (uint8_t)0;
-      live[g] = __ballot(mq != 0) != 0;
-      pad[g] = !live[g];
-    }
-    xhi[g] = seg_qstart(ge, qpos[g]);
-    xhi_first[g] = seg_on(ge) ? seg_qstart(ge, min(glo, L - 1)) : 0;  // excluded key range [xlo, .) of the half's first / last row
-    xhi_last[g] = seg_on(ge) ? seg_qstart(ge, qhi[g]) : 0;
-  }
-  const bool wave_live = live[0] || live[1];
-
-  bf16x8_t qf[2][8];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    const bf16_t* qp = p.q + (ge.row0 + min(qpos[g], L - 1)) * p.ld + h * HD + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const uint4 v = *(const uint4*)(qp + ks * 16);
-      qf[g][ks] = *(const bf16x8_t*)&v;
-    }
-  }
-  f32x16_t o[2][4];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[g][db][r] = 0.f;
-  float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};          // m in RAW score units; scale2 enters in the exponent's FMA
-
-  const int n_kt = p.causal ? (min(L, q0 + 256) + 63) / 64 : (L + 63) / 64;
-  const SegSkip sk(ge, q0, n_kt);
-  const int xlo = seg_xlo(ge);
-  const float scale2 = p.scale * 1.4426950408889634f;
-  // K / V tiles by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write), two tiles ahead of their use in a ring of three stages: with one
-  // workgroup per CU nothing else hides a tile's flight.  The DMA writes lane-linear (wave instruction j of wave w fills the 1-KiB piece 4 j + w = rows
-  // 16 j + 4 w + (lane >> 4), 16-byte chunk lane & 15), so the tiles' XOR swizzles are applied on the SOURCE side: the lane fetches the global chunk that
-  // belongs at its LDS position.  kswz32 depends on j only through bit 4 of the row (j & 1), vswz not at all: two per-lane offsets for K, one for V; the row
-  // group 16 j and the tile position ride in the scalar offset.  Rows past L read as zero (buffer extent).
-  // The pieces are asm statements: hipcc orders every LDS read behind a builtin LDS-DMA with vmcnt(0) (it cannot tell the stages apart), which would drain
-  // the tiles in flight at the first fragment read of every iteration; their completion is counted by hand (vmcnt(8) at the end of an iteration).
-  typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
-  const int w_u = __builtin_amdgcn_readfirstlane(w);
-  auto mkdesc = [&](const bf16_t* base) { const uint64_t a_ = (uint64_t)base; return u32x4v_t{(uint32_t)a_, (uint32_t)(a_ >> 32) & 0xffffu, (uint32_t)(L * p.ld * 2), 0x00020000u}; };
-  const u32x4v_t k_rs = mkdesc(p.k + ge.row0 * p.ld), v_rs = mkdesc(p.v + ge.row0 * p.ld);
-  int kvoff[2], vvoff;
-  {
-    const int l4 = lane >> 4, cp = lane & 15, r = w * 4 + l4;              // row inside a 16-row group
-    kvoff[0] = (r * p.ld + h * HD + (cp ^ kswz32(r)) * 8) * 2;             // even j: bit 4 of the row clear
-    kvoff[1] = (r * p.ld + h * HD + (cp ^ kswz32(r + 16)) * 8) * 2;
-    vvoff = (r * p.ld + h * HD + (((((cp >> 1) ^ vswz(r)) << 1) | (cp & 1))) * 8) * 2;
-  }
-  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)LDS_PTR(void, smem)) + (uint32_t)w_u * 1024u;
-  // piece i of a tile: (j, operand) = (i >> 1, i & 1): K rows 16 j + 4 w .. of the tile, then the same rows of V
-  auto dma_piece = [&](int st, int pos0, int i) __attribute__((always_inline)) {
-    const int j = i >> 1;
-    const uint32_t dst = lds0 + (uint32_t)(st * 2 * TILE + j * 4096 + (i & 1) * TILE);
-    const int so = (pos0 + j * 16) * p.ld * 2;
-    if (i & 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(vvoff), "s"(v_rs), "s"(so) : "memory");
-    else if (j & 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(kvoff[1]), "s"(k_rs), "s"(so) : "memory");
-    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(kvoff[0]), "s"(k_rs), "s"(so) : "memory");
-  };
-  auto dma_tile = [&](int st, int pos0) __attribute__((always_inline)) {
-    asm volatile("s_nop 4" ::: "memory");                  // scalar operands fresh from SALU / readfirstlane -> the buffer instruction
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(st, pos0, i);
-  };
-  // key-mask bytes of a tile: every wave loads them (so that all four count the same vector-memory operations), wave 0 files them
-  auto mask_load = [&](int kk0) __attribute__((always_inline)) {
-    const int kp = kk0 + lane;
-    return (uint8_t)((kp < L) ? (p.key_mask ? p.key_mask[ge.row0 + kp] : (uint8_t)1) : (uint8_t)0);
-  };
-  auto mask_store = [&](uint8_t* Msd, uint8_t m) __attribute__((always_inline)) {
-    if (w == 0) {
-      Msd[lane] = m;
-      const uint64_t deadk = __ballot(m == 0);
-      if (lane == 0) { Msd[64] = deadk != 0; *(uint64_t*)(Msd + 72) = ~deadk; }
-    }
-  };
-  {
-    const int t0 = sk.first(), t1 = t0 < n_kt ? sk.next(t0) : n_kt;
-    const uint8_t m0 = mask_load(t0 * 64);
-    dma_tile(0, t0 * 64);
-    uint8_t m1 = 0;
-    if (t1 < n_kt) { m1 = mask_load(t1 * 64); dma_tile(1, t1 * 64); }
-    mask_store(ms_base, m0);
-    if (t1 < n_kt) mask_store(ms_base + 80, m1);
-    if (t1 < n_kt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  int cur = 0;
-#if A64_DIAG
-  unsigned long long dg_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dg_last = __builtin_readcyclecounter();
-#define TS(i) { const unsigned long long t_ = __builtin_readcyclecounter(); dg_acc[i] += t_ - dg_last; dg_last = t_; }
-#else
-#define TS(i)
-#endif
-  const int krow_off = ql * 256;
-  const int kswz = kswz32(ql);
-  const int a4 = lane & 15, vgrp = (lane >> 4) & 1;
-  typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
-  for (int kt = sk.first(), nxt; kt < n_kt; kt = nxt) {
-    nxt = sk.next(kt);
-    const int k0 = kt * 64;
-    const char* const Ks = smem + cur * 2 * TILE;
-    const char* const Vs = Ks + TILE;
-    const uint8_t* const Ms = ms_base + cur * 80;
-    TS(10)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile kt has landed for everyone (each wave waited for its own pieces); everyone has left stage cur + 2.  Not __syncthreads(): its fence drains vmcnt, i.e. the tile in flight
-    TS(0)
-    const int st2 = cur == 0 ? 2 : cur - 1;               // (cur + 2) % 3: the stage of the tile before this one
-    const int nxt2 = nxt < n_kt ? sk.next(nxt) : n_kt;
-    uint8_t m2 = 0;
-    if (nxt2 < n_kt) { m2 = mask_load(nxt2 * 64); dma_tile(st2, nxt2 * 64); }
-    // tiles none of this wave's rows can see.  The halves are 32-aligned inside a 64-aligned wave, so the causal rule is the same for both; a tile only
-    // ONE half excludes (a response boundary or padding between the halves) runs for both and is masked to exact zeros for that half.
-    bool dead = !wave_live;
-    {
-      const bool d0 = !live[0] || (p.causal && k0 > qhi[0]) || (k0 >= xlo && k0 + 63 < xhi_first[0]);
-      const bool d1 = !live[1] || (p.causal && k0 > qhi[1]) || (k0 >= xlo && k0 + 63 < xhi_first[1]);
-      dead = dead || (d0 && d1);
-    }
-    // One wave per SIMD is ISSUE-bound (about 5 single-issue instructions hide under one 32-cycle MFMA, MI355X_MICROARCH.md), and a dependent MFMA that
-    // is neither back-to-back with its producer nor >= ~75 cycles behind it stalls (+43 cycles: the A64_ABL runs priced the S chains at 0.19 of 0.70 ms when
-    // softmax instructions sat between their links).  So: the tile's 64 keys go through as two sub-tiles of 32 keys; S of BOTH halves is one phase of 16
-    // MFMAs on two alternating accumulate chains (each K fragment read feeds both halves, nothing is held), the P V products run on four chains per half.
-    // The MFMAs are asm statements with fixed register classes - S in the arch VGPRs where the softmax works on it, Q and O in the accumulator file,
-    // no v_accvgpr_* copies - and the softmax is single-instruction helpers (v_max3 / v_fma / v_exp / v_add / v_cvt_pk / v_permlane32_swap), 4 issues per score.
-    const uint8_t tile_km = Ms[64];                       // block-uniform mask summary of the tile, requested here so that its latency hides under the K fragment reads
-    const uint64_t tile_vis = *(const uint64_t*)(Ms + 72);
-    auto subtile = [&](auto KB_) __attribute__((always_inline)) {
-      constexpr int kb = decltype(KB_)::v;
-      f32x16_t sc[2];
-      bf16x8_t vfr[8];
-      auto kread = [&](int ks) __attribute__((always_inline)) {
-        return *(const bf16x8_t*)(Ks + kb * 32 * 256 + krow_off + (((ks * 2 + hi) ^ kswz) << 4));
-      };
-      auto vread = [&](auto J_) __attribute__((always_inline)) {
-        constexpr int J = decltype(J_)::v, s2 = J >> 2, db = J & 3;
-        const int r0 = kb * 32 + s2 * 16 + hi * 4 + (a4 >> 2), r1 = r0 + 8;
-        const int c16 = db * 4 + vgrp * 2 + ((a4 & 3) >> 1), sub = ((a4 & 3) & 1) * 8;
-        union { bf16x8_t v; s16x4_t hh[2]; } vf;
-        if constexpr (A64_ABL & 32) { vfr[J] = qf[1][J]; return; }
-        vf.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r0, c16) + sub));
-        vf.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, Vs + off32<false>(r1, c16) + sub));
-        vfr[J] = vf.v;
-      };
-      // ---- phase A: S_0 / S_1 alternately from a rolling window of K fragments (KPF k-steps ahead); the sub-tile's 8 V fragments are requested in its gaps ----
-      {
-        constexpr int KPF = 3;
-        bf16x8_t kw[KPF + 1];
-#pragma unroll
-        for (int ks = 0; ks < KPF; ++ks) kw[ks] = (A64_ABL & 64) ? qf[0][ks] : kread(ks);
-        sfor<0, 8>([&](auto KS_) __attribute__((always_inline)) {
-          constexpr int ks = decltype(KS_)::v;
-          if constexpr (ks + KPF < 8) kw[(ks + KPF) % (KPF + 1)] = (A64_ABL & 64) ? qf[0][ks] : kread(ks + KPF);
-          if constexpr (!(A64_ABL & 4)) {
-            if constexpr (ks == 0) { mfma_s0(sc[0], kw[ks % (KPF + 1)], qf[0][ks]); mfma_s0(sc[1], kw[ks % (KPF + 1)], qf[1][ks]); }
-            else { mfma_s(sc[0], kw[ks % (KPF + 1)], qf[0][ks]); mfma_s(sc[1], kw[ks % (KPF + 1)], qf[1][ks]); }
-          } else { if constexpr (ks == 0) { for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; } } keep_v(kw[ks % (KPF + 1)]); }
-          vread(KS_);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-      TS(1 + kb * 5)
-      // softmax of half G over the sub-tile's 32 keys (sc[G] -> unnormalised P in place), with `hook(IC<i>)`, i = 0..7, called at 8 points spread over
-      // its VALU work: the caller puts one MFMA of the other half there
-      auto softmax = [&](auto G_, auto&& hook) __attribute__((always_inline)) {
-        constexpr int G = decltype(G_)::v;
-        if constexpr (A64_ABL & 1) { sfor<0, 8>([&](auto I_) { __builtin_amdgcn_sched_barrier(0); hook(I_); __builtin_amdgcn_sched_barrier(0); }); return; }
-        nop12_v(sc[G]);                                   // the chain's last MFMA -> its first VALU reader (12 states; hipcc pads nothing around asm MFMAs)
-        const int kq = k0 + kb * 32;
-        const bool clean = !tile_km && (!p.causal || kq + 31 <= qlo + 32 * G) && (kq + 31 < xlo || kq >= xhi_last[G]);
-        if (!clean) {
-          uint64_t vis = tile_vis;
-          if (p.causal) {
-            const int lim = qpos[G] - k0;                 // keys 0..lim of the tile are at or before the row
-            vis &= lim >= 63 ? ~0ull : lim < 0 ? 0ull : ((2ull << lim) - 1ull);
-          }
-          {
-            const int lo = min(max(xlo - k0, 0), 64), hx = min(max(xhi[G] - k0, 0), 64);      // excluded keys [lo, hx) of the tile
-            if (hx > lo) {
-              const uint64_t below_hx = hx >= 64 ? ~0ull : ((1ull << hx) - 1ull), below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
-              vis &= ~(below_hx & ~below_lo);
-            }
-          }
-          vis >>= 4 * hi;
-          const uint32_t vw = kb ? (uint32_t)(vis >> 32) : (uint32_t)vis;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[G][r] = (vw & (1u << (8 * (r >> 2) + (r & 3)))) ? sc[G][r] : -INFINITY;
-        }
-        float mx = vmax3(sc[G][0], sc[G][1], sc[G][2]);
-        mx = vmax3(mx, sc[G][3], sc[G][4]); mx = vmax3(mx, sc[G][5], sc[G][6]); mx = vmax3(mx, sc[G][7], sc[G][8]);
-        __builtin_amdgcn_sched_barrier(0); hook(IC<0>{}); __builtin_amdgcn_sched_barrier(0);
-        mx = vmax3(mx, sc[G][9], sc[G][10]); mx = vmax3(mx, sc[G][11], sc[G][12]); mx = vmax3(mx, sc[G][13], sc[G][14]);
-        float m_new;
-        if constexpr (!(A64_ABL & 8)) {
-          float xa = vmax3(mx, sc[G][15], sc[G][15]), xb = xa;                          // the other 16 keys of the sub-tile for this q row: lanes l and l ^ 32
-#if A64_BPERM
-          xb = __shfl_xor(xa, 32, 64);
-#else
-          lane32_swap(xa, xb);
-#endif
-          m_new = vmax3(m_run[G], xa, xb);
-        } else m_new = vmax3(m_run[G], mx, sc[G][15]);
-        __builtin_amdgcn_sched_barrier(0); hook(IC<1>{}); __builtin_amdgcn_sched_barrier(0);
-        // lazy rescale with a threshold: O lives in the accumulator file (3 instructions per element to rescale), so the reference maximum m_run is only
-        // moved when some row's maximum has grown by more than 2^8 in the exponent's units - until then P = 2^(s - m_run) <= 256 (exact in bf16's
-        // range, fp32 accumulation), and the final O / l and lse = m_run + log2(l) do not care which reference was used
-        if (!(A64_ABL & 16) && __ballot((m_new - m_run[G]) * scale2 > ATTN_RESCALE_LOG2)) {
-          nop12_a4(o[G][0], o[G][1], o[G][2], o[G][3]);
-          const float alpha = fast_exp2((m_run[G] - m_new) * scale2);
-          l_run[G] *= alpha;
-#pragma unroll
-          for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[G][db][r] *= alpha;
-          m_run[G] = m_new;
-        }
-        const float mb = -m_run[G] * scale2;
-        float ps0 = 0.f, ps1 = 0.f;
-        // v_exp_f32 is a transcendental: its result must not be read by the NEXT instruction (gfx940+ trans-use hazard; hipcc pads it for its own
-        // instructions but not for an asm consumer - measured as row sums wrong in half of the lanes).  The row-sum add of score r runs two scores later.
-        sfor<0, 16>([&](auto R_) __attribute__((always_inline)) {
-          constexpr int r = decltype(R_)::v;
-          sc[G][r] = fast_exp2(vfma(sc[G][r], scale2, mb));
-          if constexpr (r >= 2) { if constexpr (r & 1) ps1 = vadd_keep(ps1, sc[G][r - 2]); else ps0 = vadd_keep(ps0, sc[G][r - 2]); }
-          if constexpr (r == 1 || r == 4 || r == 7 || r == 9 || r == 12 || r == 14) {
-            __builtin_amdgcn_sched_barrier(0);
-            hook(IC<r == 1 ? 2 : r == 4 ? 3 : r == 7 ? 4 : r == 9 ? 5 : r == 12 ? 6 : 7>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        });
-        ps0 = vadd_nop(ps0, sc[G][14]); ps1 = vadd_nop(ps1, sc[G][15]);     // hipcc may sink the last v_exp down to here: own wait state
-        l_run[G] += ps0 + ps1;
-      };
-      // P fragment (B operand) of keys kb*32 + s2*16 .. of half G; the trailing nop covers VALU write -> MFMA operand read
-      auto pfrag = [&](auto G_, auto S2_) __attribute__((always_inline)) {
-        constexpr int G = decltype(G_)::v, s2 = decltype(S2_)::v;
-        union { bf16x8_t v; uint32_t u[4]; } pf;
-        pf.u[0] = pack_bf2(sc[G][8 * s2 + 0], sc[G][8 * s2 + 1]); pf.u[1] = pack_bf2(sc[G][8 * s2 + 2], sc[G][8 * s2 + 3]);
-        pf.u[2] = pack_bf2(sc[G][8 * s2 + 4], sc[G][8 * s2 + 5]); pf.u[3] = pack_bf2(sc[G][8 * s2 + 6], sc[G][8 * s2 + 7]);
-        nop2_v(pf.v);
-        return pf.v;
-      };
-      // ---- phase B: softmax_0 alone (its MFMA partner will be the previous sub-tile's O_1 product) ----
-      softmax(IC<0>{}, [&](auto I_) __attribute__((always_inline)) {});
-      TS(2 + kb * 5)
-      // ---- phase C: softmax_1 || O_0 += V^T P_0^T; V fragment j = (s2, db) = (j >> 2, j & 3) ----
-      bf16x8_t pcur;
-      softmax(IC<1>{}, [&](auto J_) __attribute__((always_inline)) {
-        constexpr int J = decltype(J_)::v, s2 = J >> 2, db = J & 3;
-        if constexpr (db == 0) pcur = pfrag(IC<0>{}, IC<s2>{});
-        if constexpr (!(A64_ABL & 2)) mfma_o(o[0][db], vfr[J], pcur); else { keep_v(vfr[J]); keep_v(pcur); }
-      });
-      TS(3 + kb * 5)
-      // ---- phase D: O_1 += V^T P_1^T ----
-      sfor<0, 8>([&](auto J_) __attribute__((always_inline)) {
-        constexpr int J = decltype(J_)::v, s2 = J >> 2, db = J & 3;
-        if constexpr (db == 0) pcur = pfrag(IC<1>{}, IC<s2>{});
-        if constexpr (!(A64_ABL & 2)) mfma_o(o[1][db], vfr[J], pcur); else { keep_v(vfr[J]); keep_v(pcur); }
-      });
-      TS(4 + kb * 5)
-    };
-    if (!dead) subtile(IC<0>{});
-    TS(5)
-    if (!dead) subtile(IC<1>{});
-    if (nxt2 < n_kt) mask_store(ms_base + st2 * 80, m2);
-    // the next tile's pieces (issued one iteration ago) must have landed before this wave arrives at the barrier; the 8 pieces just issued stay in flight
-    if (nxt < n_kt) { if (nxt2 < n_kt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    cur = cur == 2 ? 0 : cur + 1;
-  }
-#if A64_DIAG
-  if (blockIdx.x == gridDim.x / 2 && lane == 0) { float* dg = p.lse + (size_t)p.S * p.nh * p.L + w * 16; for (int i = 0; i < 12; ++i) dg[i] = (float)dg_acc[i]; dg[12] = (float)n_kt; }
-#endif
-  __syncthreads();                                        // every wave has left the ring: it becomes the O staging area (4 waves x 2 halves x 8 KiB)
-  nop12_a4(o[0][0], o[0][1], o[0][2], o[0][3]); nop12_a4(o[1][0], o[1][1], o[1][2], o[1][3]);
-#pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    float l = l_run[g] + __shfl_xor(l_run[g], 32, 64);
-    if (!live[g]) l = 0.f;                                // a half of padding rows next to a live half went through the loop: zeros, as if skipped
-    char* const stg = smem + (w * 2 + g) * 8192;
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        uint2 v;
-        if (live[g]) {
-          v.x = pack_bf2(o[g][db][b * 4 + 0] * inv, o[g][db][b * 4 + 1] * inv);
-          v.y = pack_bf2(o[g][db][b * 4 + 2] * inv, o[g][db][b * 4 + 3] * inv);
-        } else { v.x = 0u; v.y = 0u; }
-        const int d = db * 32 + b * 8 + hi * 4;             // first of the lane's 4 consecutive columns
-        *(uint2*)(stg + ql * 256 + ((((d >> 3) ^ (ql & 15))) << 4) + (d & 7) * 2) = v;
-      }
-    if (hi == 0 && qpos[g] < L && p.lse)
-      p.lse[stat_idx(p, ge, s, h, qpos[g])] = l > 0.f ? (m_run[g] * scale2 + log2f(l)) * 0.6931471805599453f : (pad[g] ? -NEG_BIG : NEG_BIG);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own rows only: no barrier needed
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 4 + (lane >> 4), c16 = lane & 15;  // row 0..63 of the wave: half row >> 5
-    const uint4 v = *(const uint4*)(smem + (w * 2 + (row >> 5)) * 8192 + (row & 31) * 256 + ((c16 ^ (row & 15)) << 4));
-    if (qlo + row < L) *(uint4*)(p.o + (ge.row0 + qlo + row) * p.ldo + h * HD + c16 * 8) = v;
-  }
-}
+// (Round 5 built a 64-rows-per-wave forward here - one wave per SIMD, 512-register budget, S in arch VGPRs, Q / O in the accumulator file through asm MFMAs,
+// K / V by asm LDS-DMA into a three-stage ring - to parity; compiler-scheduled it ran 39 % slower than the 32-row kernel above (0.581 vs 0.417 ms; per-phase
+// cycle anatomy: profiles/r05g_attn_fwd64.txt) and was removed in round 6: the structure pays only as generated text with a register plan.)
 
 // delta[s,h,pos] = sum_d dO * O.  HD/8 lanes per (row, head), 16 bytes of dO and of O per lane (a wave covers 64 / (HD/8) heads of
 // one row: 512 contiguous bytes per operand at HD = 128), shuffle reduction inside the lane group.
@@ -1765,26 +1376,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
 static bool g_attn_dma = false;   // measured: the 64-KiB ring allows 2 blocks/CU, the 32-KiB register-staged kernel 3 -> 0.92 vs 1.01 ms
 void opadpo_set_attn_dma(bool on) { g_attn_dma = on; }
 
-static int g_attn64 = -1;         // -1: OPADPO_ATTN64 decides (default off); 0 / 1: set by opadpo_set_flags
-void opadpo_set_attn64(int on) { g_attn64 = on; }
 static int g_attn32 = -1;         // 1 (default): head_dim-128 forward on the 32-rows-per-wave kernel; OPADPO_ATTN32=0 keeps the 16-row kernel (A/B)
 hipError_t launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (a.S <= 0 || a.L <= 0) return hipSuccess;
   if (a.hd != 128 && a.hd != 64) return hipErrorInvalidValue;
   if (g_attn32 < 0) { const char* v = getenv("OPADPO_ATTN32"); g_attn32 = (v && v[0] == '0') ? 0 : 1; }
   const bool legacy = a.use_tr >= 0 && (a.use_tr & 256);      // per-call: context flag bit 8 = the 16-row forward kernel
-  // experimental (round 5, measured SLOWER than the 32-row kernel: profiles/r05g_attn_fwd64.txt): head_dim-128 forward on the 64-rows-per-wave kernel
-  // (one wave per SIMD); OPADPO_ATTN64=1 or opadpo_set_flags use_tr bit 11
-  static int env64 = -1;
-  if (env64 < 0) { const char* v = getenv("OPADPO_ATTN64"); env64 = (v && v[0] == '1') ? 1 : 0; }
-  const int use64 = g_attn64 >= 0 ? g_attn64 : env64;
-  if (a.hd == 128 && g_attn32 && use64 && !legacy && (double)a.L * a.ld * 2 < 2.0e9) {
-    static bool attr64 = false;
-    if (!attr64) { (void)hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 64 * 128 * 2 + 256); attr64 = true; }
-    const dim3 grid64((unsigned)(((a.L + 255) / 256) * a.nh * a.S));
-    hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), 6 * 64 * 128 * 2 + 256, st, a);
-    return hipGetLastError();
-  }
   if (a.hd == 128 && g_attn32 && !legacy && (double)a.L * a.ld * 2 < 2.0e9) {
     static bool attr32 = false;
     if (!attr32) { (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 128 * 2 + 160); attr32 = true; }

@@ -2207,7 +2207,6 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
   opadpo_set_attn_dma((use_tr & 2) != 0);
-  opadpo_set_attn64((use_tr & 2048) ? 1 : -1);
   g_tn_w4 = (use_tr & 8) == 0;
   g_skinny8 = (use_tr & 16) == 0;
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;

@@ -99,7 +99,6 @@ struct GemmTNGroup {
 void opadpo_set_flags_impl(int use_glds, int use_tr);
 bool opadpo_flag_tr();
 void opadpo_set_attn_dma(bool on);
-void opadpo_set_attn64(int on);      // 1: head_dim-128 attention forward on the experimental 64-rows-per-wave kernel, -1: OPADPO_ATTN64 decides (default off)
 
 hipError_t launch_gemm_nt(const GemmNTArgs& a, hipStream_t st);
 hipError_t launch_gemm_tn(const GemmTNArgs& a, hipStream_t st);
