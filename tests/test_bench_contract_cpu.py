@@ -33,6 +33,12 @@ def test_bench_line_fields():
         if k in d:
             assert "error" not in d[k], d[k]
             assert d[k]["unit"] == unit and d[k]["value"] > 0 and d[k]["ms_per_step"] > 0
+    if "in_run_extrapolation" in c:      # round 6: `value` is the directly measured full-depth figure, the bounded in-run sample rides beside it
+        assert c["extrapolated"] is False and c["source"].endswith("_cpu_baseline_full.json") and c["seconds_per_pair"] > 0
+        assert c["in_run_extrapolation"]["extrapolated"] is True and c["in_run_extrapolation"]["value"] > 0
+    par = d.get("parity")
+    if par is not None and str(par.get("source", "")).startswith("this run"):      # round 6: produced by the run itself (child process), not read from a committed file
+        assert par["assertions_passed"] is True and par["layers"] == 32 and 0 < par["mean"] < 5e-3 and par["oracle_bf16_vs_fp32"]["mean"] > 0
     full = c.get("full_depth_measured")
     if full is not None:
         assert full["extrapolated"] is False and full["value"] > 0 and full["cores"] >= 1 and full["source"].endswith("_cpu_baseline_full.json")

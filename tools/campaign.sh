@@ -30,3 +30,9 @@ python tools/sample_bench.py > $O/sample_bench.txt 2>&1      # native OPA-DPO un
 python tools/sft_bench.py > $O/sft_bench.txt 2>&1            # OPA LoRA-SFT step
 fi
 cp $R/gpurun_out/parity_bench_config.json $O/ 2>/dev/null
+# rollout (BASELINE configs[4]): per-kernel stats of the decode steps at 8 and 64 sequences per device
+for RB in 8 64; do
+  RB_BATCH=$RB bash tools/prof.sh ${TAG}_rollout_b$RB python $R/tools/rollout_bench.py > $O/prof_rollout_b$RB.log 2>&1
+  cp $R/gpurun_out/${TAG}_rollout_b${RB}_kernel_stats.csv $O/rollout_b${RB}_kernel_stats.csv 2>/dev/null
+done
+GB_ONLY=attn2 GB_ITERS=60 python tools/gemm_bench.py > $O/attn_bench.txt 2>/dev/null      # attention kernels at the packed bench shape
