@@ -826,6 +826,9 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_nt (256x256x64 tile, 4 waves x 128x128 with 256 AGPR accumulators, K-loop as one generated asm block with the LDS-DMA pieces at a period of 4 MFMAs, streaming persistent form for the plain products / 128x128 for skinny N; LoRA tail fused by K-concatenation; since round 5 the launches also carry the residual adds of the o / down projections and the SwiGLU backward of the down projection's dgrad in their direct epilogues - `unfused_epilogues` holds the rate without that work)",
                     "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": tot_ms / n_launch,
+                    # side note (round 6, profiles/r06o_mfma_power.txt): a BARE v_mfma_f32_16x16x32_bf16 loop with random bf16 operands sustains 1971 TF/s at the socket's
+                    # ~1.37-kW limit (2.22 GHz) - the 2.5-PF `peak` above is reachable with zero operands only.  `frac` stays priced against the guide's peak.
+                    "bare_mfma_random_operands_TFLOPs": 1971.0, "frac_of_bare_mfma_at_power_limit": ach / 1971.0,
                     "gemm_time_share_of_step": tot_ms * 1e-3 / dt}
         out = {"metric": "preference-pairs/sec LLaVA-1.5-7B LoRA DPO seq512", "value": value, "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
