@@ -1963,7 +1963,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     for (int h = 0; h < 2; ++h) {
       const int row = fg * 8 + h * 4 + (fc >> 2);
       offP[f][h] = tn3_off(row, wr * 128 + f * 16 + (fc & 3) * 4);
-      offQ[f][h] = P_TILE + tn3_off(row, wc * 128 + f * 16 + (fc & 3) * 4);
+      offQ[f][h] = 2 * P_TILE + tn3_off(row, wc * 128 + f * 16 + (fc & 3) * 4);
     }
   const int c = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(void, smem);
@@ -2005,11 +2005,18 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
       voff[8 + q] = (unsigned)r * (unsigned)p.ldq * 2u + (unsigned)(n2_0 + sc * 8) * 2u;
     }
     const unsigned stepP = 64u * (unsigned)p.ldp * 2u, stepQ = 64u * (unsigned)p.ldq * 2u;
+    // K-steps past the end of the segment are issued as EMPTY pieces (descriptor of zero records: no memory traffic, zeros land in a dead stage): the loop body
+    // needs no "has a next / next-but-one K-step" variants - every K-step issues 16 pieces and waits with the same counts (round 6: with the two-K-steps-per-trip
+    // loop the six body variants of the peeled form spilled)
+    i32x4_t rPz = rP, rQz = rQ;
+    rPz[2] = 0; rQz[2] = 0;
     auto issue_piece = [&](int t, int q) {      // K-step t of this run; q = 0..7: P pieces, 8..15: Q pieces
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (t & 1) * P_STAGE + (q < 8 ? 0 : P_TILE) + (wave * 8 + (q & 7)) * 1024));
+      const bool real = t < nt;
+      const i32x4_t dP = real ? rP : rPz, dQ = real ? rQ : rQz;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (t & 1) * P_TILE + (q < 8 ? 0 : 2 * P_TILE) + (wave * 8 + (q & 7)) * 1024));
       const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(ks0 + t) * (q < 8 ? stepP : stepQ)));
-      if (q < 8) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(rP), "s"(soff), "s"(dst) : "memory");
-      else asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(rQ), "s"(soff), "s"(dst) : "memory");
+      if (q < 8) asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(dP), "s"(soff), "s"(dst) : "memory");
+      else asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(voff[q]), "s"(dQ), "s"(soff), "s"(dst) : "memory");
     };
 
     f32x4_t acc[8][8];
@@ -2020,8 +2027,12 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     bf16x8_t fa[2][8], fb[2][8];
     // fragment r of set kk (m 32*kk..) of K-step t: r = 0..7 -> Q fragments, 8..15 -> P fragments.  The two 64-bit halves are
     // joined as a register sequence (a union would be assembled with moves right behind the loads).
-    auto read_frag = [&](int t, int kk, int r) {
-      const char* st = smem + (t & 1) * P_STAGE + kk * (32 * 512);
+    // LDS image (round 6): [P stage 0 | P stage 1 | Q stage 0 | Q stage 1], 32 KiB each - the stage and the k-half of a fragment read are COMPILE-TIME terms
+    // (PAR = parity of the K-step, the loop below runs two K-steps per trip) that fit the 16-bit offset field of ds_read_b64_tr_b16 next to the lane's one base
+    // register per (fragment, half).  Rounds 4-5 kept [P | Q] per stage 64 KiB apart and chose the stage at run time: one v_add_u32 in front of every one of the
+    // 64 reads of a K-step - 0.75 VALU instructions per MFMA in a loop whose NT sibling issues 0.08 (profiles/r06p_pmc_tn.txt).
+    auto read_frag = [&](auto PAR, int kk, int r) {
+      const char* st = smem + decltype(PAR)::value * P_TILE + kk * (32 * 512);
       typedef __attribute__((ext_vector_type(8))) short s16x8_t;
       const int o0 = r < 8 ? offQ[r][0] : offP[r - 8][0], o1 = r < 8 ? offQ[r][1] : offP[r - 8][1];
       const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, st + o0));
@@ -2038,79 +2049,64 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
       }
     };
-    auto tile_body = [&](int t, auto HAS_NEXT, auto HAS_NEXT2) {
-      constexpr bool has_next = decltype(HAS_NEXT)::value, has_next2 = decltype(HAS_NEXT2)::value;
+    auto tile_body = [&](int t, auto PAR) {
+      using NPAR = std::integral_constant<int, 1 - decltype(PAR)::value>;
       // m 0..39: the 16 fragments of set 1, one per 2 / 3 MFMAs
 #pragma unroll
       for (int g2 = 0; g2 < 16; ++g2) {
         mfma_run(0, (g2 * 5) / 2, ((g2 + 1) * 5) / 2 - (g2 * 5) / 2);
         W4_PIN();
-        read_frag(t, 1, g2);
+        read_frag(PAR, 1, g2);
         W4_PIN();
       }
       mfma_run(0, 40, 7);
       W4_PIN();
-      if constexpr (has_next2) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W4_PIN(); mfma_run(0, 47, 1); W4_PIN();
-        __builtin_amdgcn_s_barrier();            // the stage of K-step t is dead: it takes K-step t+2
-        W4_PIN();
-      } else {
-        mfma_run(0, 47, 1);
-        W4_PIN();
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W4_PIN(); mfma_run(0, 47, 1); W4_PIN();
+      __builtin_amdgcn_s_barrier();            // the stage of K-step t is dead: it takes K-step t+2
+      W4_PIN();
       // m 48..78: DMA pieces 0..7 of K-step t+2, one per 4 MFMAs (after m = 50, 54, ... 78)
 #pragma unroll
       for (int m = 48; m < 79; ++m) {
         mfma_run(m >> 6, m & 63, 1);
         if ((m - 48) % 4 == 2) {
           W4_PIN();
-          if constexpr (has_next2) issue_piece(t + 2, (m - 48) / 4);
+          issue_piece(t + 2, (m - 48) / 4);
           W4_PIN();
         }
       }
       W4_PIN();
-      if constexpr (has_next) {
-        if constexpr (has_next2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces above stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W4_PIN(); mfma_run(1, 15, 1); W4_PIN();
-        __builtin_amdgcn_s_barrier();            // K-step t+1 has landed for everyone
-      } else {
-        mfma_run(1, 15, 1);
-      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // the 8 pieces above stay in flight
+      W4_PIN(); mfma_run(1, 15, 1); W4_PIN();
+      __builtin_amdgcn_s_barrier();            // K-step t+1 has landed for everyone
       W4_PIN();
-      // m 80..127: the 16 fragments of set 0 of K-step t+1 (one per 3 MFMAs), DMA pieces 8..15 (one per 6)
+      // m 80..127: the 16 fragments of set 0 of K-step t+1 (one per 3 MFMAs; stale bytes after the last K-step: never used), DMA pieces 8..15 (one per 6)
 #pragma unroll
       for (int g2 = 0; g2 < 16; ++g2) {
         mfma_run(1, 16 + g2 * 3, 3);
         W4_PIN();
-        if constexpr (has_next) read_frag(t + 1, 0, g2);
-        if constexpr (has_next2) { if (g2 & 1) { W4_PIN(); issue_piece(t + 2, 8 + (g2 >> 1)); } }
+        read_frag(NPAR{}, 0, g2);
+        if (g2 & 1) { W4_PIN(); issue_piece(t + 2, 8 + (g2 >> 1)); }
         W4_PIN();
       }
     };
-    using T_ = std::true_type; using F_ = std::false_type;
 
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue_piece(0, q);
-    if (nt > 1) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) issue_piece(1, q);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    for (int q = 0; q < 16; ++q) issue_piece(1, q);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     W4_PIN();
+    using P0_ = std::integral_constant<int, 0>; using P1_ = std::integral_constant<int, 1>;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
+    for (int r = 0; r < 16; ++r) read_frag(P0_{}, 0, r);
     W4_PIN();
-    {
-      int t = 0;
-      for (; t + 2 < nt; ++t) tile_body(t, T_{}, T_{});
-      if (t + 1 < nt) { tile_body(t, T_{}, F_{}); ++t; }
-      tile_body(t, F_{}, F_{});
+    for (int t = 0; t < nt; t += 2) {              // even K-steps live in stage 0, odd ones in stage 1
+      tile_body(t, P0_{});
+      if (t + 1 < nt) tile_body(t + 1, P1_{});
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the empty pieces behind the last K-step
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     W4_PIN();
 #undef W4_PIN

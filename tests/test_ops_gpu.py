@@ -1530,6 +1530,7 @@ def test_gemm_tn_group_deterministic_form(L, M):
     M = 130: fewer K-steps than K-chunks.  The same call on one problem at a time (the compact top layer's fallback) agrees bit for bit with
     itself over repeats too; a too-small workspace and a problem the 256x256 kernel cannot take are refused."""
     import ctypes as C
+    L.set_flags(True, True)          # the process switches of an earlier test (use_tr bit 3 = the 128x128 wgrad kernel) must not decide what this one measures
     H, F, r = 1024, 2816, 256
     g = torch.Generator().manual_seed(5)
     mk = lambda n: (torch.randn(M, n, generator=g) * 0.3).to(BF).to(dev())
