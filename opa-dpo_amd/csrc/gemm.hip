@@ -2049,6 +2049,56 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
       }
     };
+#ifndef OPADPO_TN_SCHED
+#define OPADPO_TN_SCHED 1      // 1 (round 6): early stage release + all 16 pieces at a period of 4 + late landing wait; 0: the schedule of rounds 4-5 (A/B builds)
+#endif
+#if OPADPO_TN_SCHED == 1
+    // Schedule of one K-step, round 6 (MFMA index m = 0..127).  The grouped launch is bound by its two-stage ring against the loaded HBM latency (a K-step cannot be
+    // requested before its stage is free: profiles/r06q_tn_static_offsets.txt), so what counts is the window between a piece's issue and the landing wait:
+    //   m 0..30  : the 16 fragments of set 1 (rows 32..63 of this K-step), one per 2 MFMAs            | lgkmcnt(0) + barrier at 32: the stage is dead
+    //   m 34..94 : ALL 16 DMA pieces of K-step t+2, one per 4 MFMAs
+    //   m 99     : vmcnt(16) + barrier: K-step t+1 has landed for everyone (the 16 pieces above stay in flight)
+    //   m 100..127: the 16 fragments of set 0 of K-step t+1
+    // window of a piece: 134..194 MFMA slots (rounds 4-5: stage released at 48, pieces at 50..125, landing wait at 79: 82..157 slots).
+    auto tile_body = [&](int t, auto PAR) {
+      using NPAR = std::integral_constant<int, 1 - decltype(PAR)::value>;
+      // (small fully unrolled loops: one 128-trip loop over m is not unrolled by hipcc, and fa / fb indexed by a run-time m go to scratch)
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) {             // m 0..31
+        mfma_run(0, 2 * g2, 1);
+        W4_PIN(); read_frag(PAR, 1, g2); W4_PIN();
+        mfma_run(0, 2 * g2 + 1, 1);
+      }
+      mfma_run(0, 32, 1);
+      W4_PIN();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // the stage of K-step t is dead: it takes K-step t+2
+      W4_PIN();
+      mfma_run(0, 33, 1);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {                // m 34..97: piece q behind MFMA 34 + 4 q
+        const int m = 34 + 4 * q;
+        mfma_run(m >> 6, m & 63, 1);
+        W4_PIN(); issue_piece(t + 2, q); W4_PIN();
+#pragma unroll
+        for (int e = 1; e < 4; ++e) mfma_run((m + e) >> 6, (m + e) & 63, 1);
+      }
+      mfma_run(1, 34, 2);                           // m 98, 99
+      W4_PIN();
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // K-step t+1 has landed for everyone
+      W4_PIN();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {                // m 100..127: fragment k behind MFMA 100 + (7 k) / 4  (100, 101, 103, 105, 107, 108, ...)
+        const int m0 = 100 + (7 * k) / 4, m1 = k < 15 ? 100 + (7 * (k + 1)) / 4 : 128;
+        mfma_run(1, m0 - 64, 1);
+        W4_PIN(); read_frag(NPAR{}, 0, k); W4_PIN();
+#pragma unroll
+        for (int m = m0 + 1; m < m1; ++m) mfma_run(1, m - 64, 1);
+      }
+      W4_PIN();
+    };
+#else
     auto tile_body = [&](int t, auto PAR) {
       using NPAR = std::integral_constant<int, 1 - decltype(PAR)::value>;
       // m 0..39: the 16 fragments of set 1, one per 2 / 3 MFMAs
@@ -2091,6 +2141,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
       }
     };
 
+#endif
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue_piece(0, q);
 #pragma unroll
