@@ -224,6 +224,13 @@ def main():
     vlist = [int(v) for v in os.environ["GB_VARIANTS"].split(",")] if (only == "gemm" and os.environ.get("GB_VARIANTS")) else None
     # variant 10 = the DEFAULT dispatch (what ships: streaming w4s where the launcher chooses it) is the FIRST row of every campaign, so the per-shape
     # vs-vendor table measures the shipped kernel choice; 31 / 17 / 4 force one kernel (31 also disables streaming)
+    if not os.environ.get("GB_NO_WARM"):      # the first timed row must not also be the process's first kernels (r06n: qkv read 1370 TF/s there, 1489-1510 in tools/ab_stream.py)
+        wa, wb = torch.randn(M, 4096, device=dev).to(BF), (torch.randn(4096, 4096, device=dev) * 0.02).to(BF)
+        wo = torch.empty(M, 4096, dtype=BF, device=dev)
+        for _ in range(400):
+            L.gemm_nt(wa, wb, wo)
+        torch.cuda.synchronize()
+        del wa, wb, wo
     for glds in (vlist if vlist else ((10, 31, 17, 4) if not only else ((10, 31, 17, 4) if only == "gemm" else ((17, 31) if only == "pp" else ())))):
         L.set_flags(glds, True)
         for name, N, K1, K2, grp in shapes:
