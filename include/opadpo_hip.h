@@ -55,7 +55,9 @@ const char* opadpo_last_error(void);
  * 48 / 64 / 128 rows; tests), bit 9 = opadpo_sample runs its full vocabulary sweeps instead of the one-wave tail on the kept tokens (identical draws; the
  * exactness test's yardstick; a process switch, so eager and graph-captured launches always agree), bit 10 = the streaming 256x256 GEMM runs on 8
  * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count),
- * bit 11 = unused since round 6 (rounds 5: an experimental 64-rows-per-wave attention forward, measured slower and removed). */
+ * bit 11 = the gemm_nt products of >= 128 K-tiles (down projection, the dgrads) keep the default K-loop text of the 256x256 kernel; clear (default since round 6):
+ * they run its DEEP text - another placement of the same loads, barriers and MFMAs, bit-identical results, +2-3 % there (OPADPO_W4_DEEP=0: process default off).
+ * (Round 5 used bit 11 for an experimental 64-rows-per-wave attention forward, measured slower and removed.) */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------

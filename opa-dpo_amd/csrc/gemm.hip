@@ -654,8 +654,13 @@ __device__ __forceinline__ void w4_direct_epilogue_swiglu_bwd(const GemmNTArgs& 
   }
 }
 
-#include "w4_kloop.inc"
-template <bool ORDER_B, bool BA = false>      // BA: the instantiation for bias / activation problems (a separate code object: the hot kernel's epilogue stays two modes small)
+#ifndef W4K_INC
+#define W4K_INC "w4_kloop.inc"      // experiment builds (tools/build_kloop_exp.sh) name another file emitted by the same generator
+#endif
+#include W4K_INC
+// DEEP (round 6): the K-loop text with the vendor library's skeleton (W4K_TEXT_*_DEEP: third barrier, first operand's region released after ITS reads, pieces from MFMA 23
+// on) - the same MFMA order, bit-identical results; +1.5-2.2 % on the products of >= 128 K-tiles, which is where the launcher picks it
+template <bool ORDER_B, bool BA = false, bool DEEP = false>      // BA: the instantiation for bias / activation problems (a separate code object: the hot kernel's epilogue stays two modes small)
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -771,8 +776,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
       w4k_pcy[q] = __builtin_amdgcn_readfirstlane((wave * 8 + q) * 1024);
       w4k_pcx[q] = __builtin_amdgcn_readfirstlane(P_TILE + (wave * 8 + q) * 1024);
     }
-    if constexpr (ORDER_B) W4K_RUN(W4K_TEXT_BFIRST);
-    else W4K_RUN(W4K_TEXT_AFIRST);
+    if constexpr (DEEP) {
+      if constexpr (ORDER_B) W4K_RUN(W4K_TEXT_BFIRST_DEEP);
+      else W4K_RUN(W4K_TEXT_AFIRST_DEEP);
+    } else {
+      if constexpr (ORDER_B) W4K_RUN(W4K_TEXT_BFIRST);
+      else W4K_RUN(W4K_TEXT_AFIRST);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);                                             // no accumulator read may be scheduled above the block
   // Accumulator layout (B tile rows interleaved, see above): acc[i][j][r] of lane (frow, fchk) is row i*16 + 4*fchk + r, column 8*frow + j
@@ -1070,7 +1080,7 @@ extern "C" int opadpo_debug_w4s_read(unsigned long long* out4, int reset) {
   return (int)e;
 }
 #endif
-template <bool ORDER_B, int EPI = 0>      // EPI 0: plain / fp32 residual / SwiGLU backward epilogues (the hot instantiation, at its register limit); 2: SwiGLU pair only; 3: table-free rotary embedding (own code objects)
+template <bool ORDER_B, int EPI = 0, bool DEEP = false>      // DEEP: the K-loop's DEEP text (products of >= 128 K-tiles; see gemm_nt_w4_kernel).  EPI 0: plain / fp32 residual / SwiGLU backward epilogues (the hot instantiation, at its register limit); 2: SwiGLU pair only; 3: table-free rotary embedding (own code objects)
 __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1175,8 +1185,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
 #if OPADPO_W4S_DIAG
     { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); dg_glue += t_ - dg_t; dg_t = t_; __builtin_amdgcn_sched_barrier(0); }
 #endif
-    if constexpr (ORDER_B) W4S_RUN(W4S_TEXT_BFIRST);
-    else W4S_RUN(W4S_TEXT_AFIRST);
+    if constexpr (DEEP) {
+      if constexpr (ORDER_B) W4S_RUN(W4S_TEXT_BFIRST_DEEP);
+      else W4S_RUN(W4S_TEXT_AFIRST_DEEP);
+    } else {
+      if constexpr (ORDER_B) W4S_RUN(W4S_TEXT_BFIRST);
+      else W4S_RUN(W4S_TEXT_AFIRST);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #if OPADPO_W4S_DIAG
     { const unsigned long long t_ = __builtin_readcyclecounter(); dg_asm += t_ - dg_t; dg_t = t_; ++dg_n; __builtin_amdgcn_sched_barrier(0); }
@@ -2250,6 +2265,7 @@ static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
 static bool g_w4s_few = false;      // opadpo_set_flags use_tr bit 10 (tests): 8 workgroups walk the tile list, so small problems exercise long walks
+static bool g_w4_nodeep = false;    // opadpo_set_flags use_tr bit 11 (tests, A/B): the products of >= 128 K-tiles keep the default K-loop text (round 6: they run the DEEP text)
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
   g_use_tr = (use_tr & 1) != 0;
@@ -2259,6 +2275,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   if ((use_tr >> 5) & 3) g_dec64_variant = (use_tr >> 5) & 3; else if (!getenv("OPADPO_DEC64_V")) g_dec64_variant = 0;
   opadpo_set_sample_compact((use_tr & 512) ? 0 : -1);      // bit 9 forces the diagnostic sampler; otherwise OPADPO_SAMPLE_COMPACT decides
   g_w4s_few = (use_tr & 1024) != 0;
+  g_w4_nodeep = (use_tr & 2048) != 0;
   g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
 bool opadpo_flag_tr() { return g_use_tr; }
@@ -2269,6 +2286,7 @@ static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B fir
 // the tile list and keeps its K-tile pipeline full across output tiles.  OPADPO_W4S=0 / variant 31: one tile per workgroup (A/B, cross-check).
 static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
 static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("OPADPO_ROPE_DIRECT")) : 1;      // 0: table-free rotary embedding through the staged epilogue (rounds 3-4; A/B)
+static const int env_w4_deep_ = getenv("OPADPO_W4_DEEP") ? atoi(getenv("OPADPO_W4_DEEP")) : 2;      // 2 (default): >= 128 K-tiles run the DEEP text, streaming where eligible; 1: DEEP text, one tile per workgroup; 0: default text (A/B)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
     const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
@@ -2276,6 +2294,9 @@ static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("
     const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos && a.b1_fold_n == 0 &&                               \
                          ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || ((w4_direct_swiglu_bwd_ok(a) || w4_direct_swiglu_pair_ok(a)) && !a.swiglu_bwd_staged)) && \
                          a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_;                              \
+    const bool deep_stream_ = env_w4_deep_ >= 2 && !g_w4_nodeep && g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos && a.b1_fold_n == 0 && \
+                              a.act == 0 && (!a.R || w4_direct_resid_ok(a)) && a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK >= 128 && (a.K1 + a.K2) / P_BK > g_w4s_maxnt && \
+                              grid_ >= 2 * cus_;                                                                                \
     if (g_w4s > 0 && g_gemm_variant != 31 && env_rope_direct_ && w4_direct_rope_pos_ok(a) && a.K1 / P_BK >= 3 && (a.K1 + a.K2) / P_BK <= g_w4s_maxnt && grid_ >= 2 * cus_) { \
       if (ob_) hipLaunchKernelGGL((gemm_nt_w4s_kernel<true, 3>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);           \
       else hipLaunchKernelGGL((gemm_nt_w4s_kernel<false, 3>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);              \
@@ -2285,6 +2306,13 @@ static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("
     } else if (stream_) {                                                                                                    \
       if (ob_) hipLaunchKernelGGL(gemm_nt_w4s_kernel<true>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                \
       else hipLaunchKernelGGL(gemm_nt_w4s_kernel<false>, dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);                   \
+    } else if (deep_stream_) {      /* >= 128 K-tiles: streaming pays with the DEEP text only (default text: -4.7 %) */      \
+      if (ob_) hipLaunchKernelGGL((gemm_nt_w4s_kernel<true, 0, true>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);     \
+      else hipLaunchKernelGGL((gemm_nt_w4s_kernel<false, 0, true>), dim3(cus_), dim3(256), 2 * P_STAGE, st, a, grid_);        \
+    }                                                                                                                        \
+    else if (env_w4_deep_ && !g_w4_nodeep && (a.K1 + a.K2) / P_BK >= 128) {      /* the deep-K products (down, the dgrads): the DEEP text */         \
+      if (ob_) hipLaunchKernelGGL((gemm_nt_w4_kernel<true, false, true>), dim3(grid_), dim3(256), 2 * P_STAGE, st, a);       \
+      else hipLaunchKernelGGL((gemm_nt_w4_kernel<false, false, true>), dim3(grid_), dim3(256), 2 * P_STAGE, st, a);          \
     }                                                                                                                        \
     else if (ob_) hipLaunchKernelGGL(gemm_nt_w4_kernel<true>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                   \
     else hipLaunchKernelGGL(gemm_nt_w4_kernel<false>, dim3(grid_), dim3(256), 2 * P_STAGE, st, a);                            \
@@ -2371,8 +2399,12 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_x<64, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     (void)hipFuncSetAttribute((const void*)gemm_nt_w4s_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);

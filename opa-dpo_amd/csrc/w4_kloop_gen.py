@@ -23,6 +23,11 @@ The block expects the pieces of tiles 0 and 1 issued (C++ prologue; tile 1 only 
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# experiment variants (tools/build_kloop_exp.sh: W4K_EXP=<names> W4K_OUT=<file>; never the committed file).  noadv: the K offset never advances - every K-tile
+# re-reads the first one (all L2 hits at the same operand randomness, results wrong: what memory stalls cost); early: the vendor kernel's skeleton for EVERY text
+# (shipped for the deep-K products only, below); p3 / p2: the 13 pieces behind the stage release at a period of 3 / 2 MFMAs
+EXP = [e for e in os.environ.get("W4K_EXP", "").split(",") if e]
+EXP_KW = dict(early_release="early" in EXP, period=3 if "p3" in EXP else 2 if "p2" in EXP else 4)
 XOFF = [0, 1024, 256, 1280, 512, 1536, 768, 1792]      # LDS byte offset of B fragment j (B rows interleaved so that a lane owns 8 consecutive columns)
 
 
@@ -178,7 +183,7 @@ def tile_text(slots, piece_ops, mode):
                     out.append("s_xor_b32 s48, s48, 1")
             elif it[0] == "salu":
                 if mode == "loop":
-                    out.append("s_add_u32 s49, s49, 0x80")
+                    out.append("s_add_u32 s49, s49, 0" if "noadv" in EXP else "s_add_u32 s49, s49, 0x80")
             else:
                 raise ValueError(it)
         if k < 128:
@@ -192,8 +197,8 @@ def tile_text(slots, piece_ops, mode):
     return out
 
 
-def block_text(first):
-    slots = slots_r5(first=first)
+def block_text(first, early=False):
+    slots = slots_r5(first=first, **dict(EXP_KW, early_release=early or EXP_KW["early_release"]))
     po = piece_order(first)
     check_slots(slots, po)
     t = []
@@ -212,7 +217,7 @@ def block_text(first):
         t.append(f"s_mov_b32 s{40 + q}, %[dx2_{q}]")
     for q in range(4):
         t.append(f"s_mov_b32 s{44 + q}, %[dy2_{q}]")
-    t += ["s_mov_b32 s49, %[koff2]", "s_mov_b32 s39, s38", "s_mov_b32 s38, 0", "s_branch 1b", "4:", "s_cmp_eq_u32 s37, 0", "s_cbranch_scc1 5f"]
+    t += ["s_mov_b32 s49, 0" if "noadv" in EXP else "s_mov_b32 s49, %[koff2]", "s_mov_b32 s39, s38", "s_mov_b32 s38, 0", "s_branch 1b", "4:", "s_cmp_eq_u32 s37, 0", "s_cbranch_scc1 5f"]
     t += tile_text(slots, po, "tail_a")
     t += ["5:"]
     t += tile_text(slots, po, "tail_b")
@@ -224,17 +229,17 @@ def switch_text(tag):
     """addresses, descriptors and K origin of the operand pair fetched next (generic operands vo<tag>_p, dx<tag>_q, dy<tag>_q)"""
     t = [f"v_mov_b32_e32 v{140 + p}, %[vo{tag}_{p}]" for p in range(16)]
     t += [f"s_mov_b32 s{40 + q}, %[dx{tag}_{q}]" for q in range(4)] + [f"s_mov_b32 s{44 + q}, %[dy{tag}_{q}]" for q in range(4)]
-    t += ["s_mov_b32 s49, -128"]                          # the loop adds 128 before its first piece: K-tile 0 of the new pair
+    t += ["s_mov_b32 s49, 0" if "noadv" in EXP else "s_mov_b32 s49, -128"]                          # the loop adds 128 before its first piece: K-tile 0 of the new pair
     return t
 
 
-def stream_text(first):
+def stream_text(first, early=False):
     """One OUTPUT tile of the streaming (persistent) kernel gemm_nt_w4s_kernel: the K-tile stream never drains at an output-tile boundary - the last two
     K-tiles of a tile fetch K-tiles 0 and 1 of the workgroup's NEXT output tile, its last K-tile reads the next tile's first fragments, then the (C++)
     epilogue stores this tile while those pieces are in flight.  K-tiles: FIRST (t = 0, accumulators start from 0) | s39 x LOOP from the first pair |
     switch, s38 x LOOP from the second pair (K-concatenated LoRA tail) | switch to the next tile's first pair, 2 x LOOP - or, on the workgroup's last tile
     (s37 = 0), the two draining tails.  s36 = 1 on the workgroup's first tile (wait for K-tile 0, read its fragments).  Needs K1 >= 3 K-tiles."""
-    slots = slots_r5(first=first)
+    slots = slots_r5(first=first, **dict(EXP_KW, early_release=early or EXP_KW["early_release"]))
     po = piece_order(first)
     check_slots(slots, po)
     t = ["s_cmp_eq_u32 s36, 0", "s_cbranch_scc1 8f", "s_waitcnt vmcnt(16)", "s_barrier"]
@@ -267,8 +272,21 @@ def main():
         L.append(f"#define {name} \\")
         L += ['  "' + l + '\\n" \\' for l in txt]
         L.append('  ""')
+    # the vendor library's skeleton (a third barrier releases the first operand's region after ITS reads, bursts of five pieces at a period of three MFMAs): ahead by
+    # 1.5 - 2.2 % on the products of >= 128 K-tiles, level / behind on the shallow ones (profiles/r06v_ab_kloop_sched.txt) - the one-tile-per-workgroup kernel's text there
+    for first, name in (("X", "W4K_TEXT_BFIRST_DEEP"), ("Y", "W4K_TEXT_AFIRST_DEEP")):
+        txt = block_text(first, early=True)
+        L.append(f"#define {name} \\")
+        L += ['  "' + l + '\\n" \\' for l in txt]
+        L.append('  ""')
     for first, name in (("X", "W4S_TEXT_BFIRST"), ("Y", "W4S_TEXT_AFIRST")):
         txt = stream_text(first)
+        L.append(f"#define {name} \\")
+        L += ['  "' + l + '\\n" \\' for l in txt]
+        L.append('  ""')
+    # ... and the streaming kernel's: with the default text streaming LOSES 4.7 % at >= 128 K-tiles, with this one it is 0.6 - 1 % ahead of one tile per workgroup
+    for first, name in (("X", "W4S_TEXT_BFIRST_DEEP"), ("Y", "W4S_TEXT_AFIRST_DEEP")):
+        txt = stream_text(first, early=True)
         L.append(f"#define {name} \\")
         L += ['  "' + l + '\\n" \\' for l in txt]
         L.append('  ""')
@@ -305,7 +323,8 @@ def main():
     wrap("W4S_INS", s_ins)
     wrap("W4S_CLOBBERS", s_clob)
     L.append("#define W4S_RUN(TEXT) asm volatile(TEXT : W4S_OUTS : W4S_INS : W4S_CLOBBERS)")
-    out = os.path.join(HERE, "w4_kloop.inc")
+    out = os.environ.get("W4K_OUT") or os.path.join(HERE, "w4_kloop.inc")
+    assert not EXP or os.environ.get("W4K_OUT"), "experiment variants go to W4K_OUT, not to the committed file"
     text = "\n".join(L) + "\n"
     if "--check" in os.sys.argv:
         assert open(out).read() == text, "w4_kloop.inc is stale: run python opa-dpo_amd/csrc/w4_kloop_gen.py"

@@ -142,6 +142,32 @@ def test_gemm_nt_r_wide_products_k_folded(L, K):
     assert torch.equal(o300, outs[10][:300]) and torch.equal(o1, outs[10][699:]) and torch.equal(again, outs[10])
 
 
+@pytest.mark.parametrize("N,K1,K2", [(4096, 11008, 256), (4096, 8192, 0), (512, 22016, 0), (8192, 8448, 64)])
+def test_gemm_nt_deep_k_text_is_bit_identical(L, N, K1, K2):
+    """Round 6: products of >= 128 K-tiles (down projection K = 11008 + r, the dgrads K = 12288 / 22016; LlamaMLP / LlamaAttention backward under peft,
+    rl_models.py:120) run the DEEP text of the generated K-loop (csrc/w4_kloop_gen.py: the same loads, barriers and MFMAs placed differently).  The MFMA order
+    is the same, so the result must be BIT-equal to the default text (flag bit 11) - on both piece orders (N <= 4096: B first, beyond: A first), with and
+    without the K-concatenated LoRA tail, ragged M, fp32 output with a residual - and equal to torch fp32 within bf16 rounding."""
+    M = 1500 + 37
+    a1, b1 = rnd(M, K1, scale=0.5, seed=1), rnd(N, K1, scale=0.03, seed=2)
+    kw = dict(a2=rnd(M, K2, scale=0.5, seed=3), b2=rnd(N, K2, scale=0.03, seed=4)) if K2 else {}
+    want = a1.float() @ b1.float().t() + (kw["a2"].float() @ kw["b2"].float().t() if K2 else 0.0)
+    res = torch.randn(M, N, device=dev())
+    got = {}
+    # variant 31: one tile per workgroup; variant 10 with bit 10: the STREAMING kernel on 8 workgroups (its DEEP text when bit 11 is clear)
+    for variant, bits in ((31, 0), (31, 2048), (10, 1024), (10, 1024 | 2048)):
+        L.set_flags(variant, 1 | bits)
+        ob = torch.empty(M, N, dtype=BF, device=dev()); of = torch.empty(M, N, device=dev())
+        L.gemm_nt(a1, b1, ob, **kw)
+        L.gemm_nt(a1, b1, of, residual=res, **kw)
+        torch.cuda.synchronize()
+        got[(variant, bits)] = (ob, of)
+        assert relerr(ob, want) < 6e-3 and relerr(of, want + res) < 2e-5
+    L.set_flags(True, True)
+    for key, (ob, of) in got.items():
+        assert torch.equal(ob, got[(31, 2048)][0]) and torch.equal(of, got[(31, 2048)][1]), key
+
+
 @pytest.mark.parametrize("M", [2, 8, 13, 24, 31, 50])
 def test_gemm_nt_decode_strided_operands(L, M):
     """Decode-schedule kernels with every operand a column slice of a wider buffer (lda / ldb / ldc / ldr != logical width),
