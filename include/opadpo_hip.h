@@ -57,7 +57,10 @@ const char* opadpo_last_error(void);
  * workgroups instead of one per CU (tests: long tile walks per workgroup on small problems; results are bit-identical for any workgroup count),
  * bit 11 = the gemm_nt products of >= 128 K-tiles (down projection, the dgrads) keep the default K-loop text of the 256x256 kernel; clear (default since round 6):
  * they run its DEEP text - another placement of the same loads, barriers and MFMAs, bit-identical results, +2-3 % there (OPADPO_W4_DEEP=0: process default off).
- * (Round 5 used bit 11 for an experimental 64-rows-per-wave attention forward, measured slower and removed.) */
+ * (Round 5 used bit 11 for an experimental 64-rows-per-wave attention forward, measured slower and removed.)
+ * bit 12 = the 256x256 gemm_nt kernels deal their tile order to the XCDs in contiguous chunks (rounds 1-5); clear (default since round 6): 32-tile blocks dealt
+ * block-cyclically, so that the eight XCDs of a round share one row group's A panels through the Infinity Cache - bit-identical results, -1.0 % per training step
+ * (OPADPO_XCD_CYCLIC=0: process default off). */
 void opadpo_set_flags(int use_glds, int use_tr);
 
 /* ---- Linear layers: base GEMM with the LoRA branch fused by K-concatenation ----------------

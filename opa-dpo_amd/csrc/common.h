@@ -80,6 +80,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// The same blocks of 32 consecutive logical tiles per XCD and round (one XCD's 32 workgroups keep their 8 x 4 footprint in its L2), but dealt to the XCDs
+// block-CYCLICALLY: in round k XCD x takes block 8 k + x, so at any time the eight XCDs work on neighbouring column blocks of the SAME row group - its A panels
+// are fetched from HBM once for the chip (Infinity-Cache hits for seven XCDs) and the B matrix stays within the cache's reach between two passes, where the
+// contiguous-chunk deal above has eight row groups' A panels plus B in flight.  Assumes 256 resident workgroups per round (block b on XCD b % 8); the last,
+// partial round falls back to the contiguous deal.
+__device__ __forceinline__ int xcd_remap_cyclic(int bid, int nwg) {
+  const int full = nwg & ~255;
+  if (bid >= full) return full + xcd_remap(bid - full, nwg - full);
+  return (bid & ~255) + ((bid & 7) << 5) + ((bid >> 3) & 31);
+}
+
 // Read one MFMA 16x16x32 operand fragment whose contraction index runs along the ROWS of a
 // row-major LDS tile (row stride `ld_bytes`): lane (c = lane&15, g = lane>>4) receives
 // tile[k0 + g*8 + j][c0 + c], j = 0..7.  TR=true uses the gfx950 transpose read

@@ -654,6 +654,17 @@ __device__ __forceinline__ void w4_direct_epilogue_swiglu_bwd(const GemmNTArgs& 
   }
 }
 
+// Logical tile index -> (row tile, column tile) of the 256x256 4-wave kernels: row tiles in groups of group_m, a group walked column by column - 32 consecutive
+// indices are group_m rows x 32 / group_m columns, one XCD's footprint of a round.  (Bundling groups into super-groups so that a round of the chip covers 16 or 32
+// rows x 16 or 8 columns instead of 8 x 32 measured 0.5 - 2 % slower: profiles/r06z_ab_superh.txt.)
+__device__ __forceinline__ void w4_tile_map(const GemmNTArgs& p, int swz, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int width = p.group_m * tiles_n;
+  const int first_m = (swz / width) * p.group_m;
+  const int gsz = min(tiles_m - first_m, p.group_m);
+  tm = first_m + (swz % width) % gsz;
+  tn = (swz % width) / gsz;
+}
+
 #ifndef W4K_INC
 #define W4K_INC "w4_kloop.inc"      // experiment builds (tools/build_kloop_exp.sh) name another file emitted by the same generator
 #endif
@@ -668,13 +679,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmNTArgs p) {
   const int wr = wave >> 1, wc = wave & 1;
 
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int width = p.group_m * tiles_n;
-  const int group_id = swz / width;
-  const int first_m = group_id * p.group_m;
-  const int gsz = min(tiles_m - first_m, p.group_m);
-  const int tm = first_m + (swz % width) % gsz;
-  const int tn = (swz % width) / gsz;
+  const int swz = p.xcd_cyclic ? xcd_remap_cyclic(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
+  int tm, tn;
+  w4_tile_map(p, swz, tiles_m, tiles_n, tm, tn);
   const int m0 = __builtin_amdgcn_readfirstlane(tm * P_BM), n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
 
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK, nt = nt1 + nt2;
@@ -1087,14 +1094,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4s_kernel(GemmNTArgs p, int n_ti
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_m = (p.M + P_BM - 1) / P_BM, tiles_n = p.N / P_BN;
-  const int width = p.group_m * tiles_n;
   auto tile_of = [&](int b, int& m0, int& n0) {
-    const int swz = xcd_remap(b, n_tiles);
-    const int group_id = swz / width;
-    const int first_m = group_id * p.group_m;
-    const int gsz = min(tiles_m - first_m, p.group_m);
-    m0 = __builtin_amdgcn_readfirstlane((first_m + (swz % width) % gsz) * P_BM);
-    n0 = __builtin_amdgcn_readfirstlane(((swz % width) / gsz) * P_BN);
+    const int swz = p.xcd_cyclic ? xcd_remap_cyclic(b, n_tiles) : xcd_remap(b, n_tiles);
+    int tm, tn;
+    w4_tile_map(p, swz, tiles_m, tiles_n, tm, tn);
+    m0 = __builtin_amdgcn_readfirstlane(tm * P_BM);
+    n0 = __builtin_amdgcn_readfirstlane(tn * P_BN);
   };
   const int nt1 = p.K1 / P_BK, nt2 = p.K2 / P_BK;
   const int srow = lane >> 3, spos = lane & 7;
@@ -2265,6 +2270,7 @@ static int g_gemm_variant = 10;   // 10 (default): auto; 4: 128x128 kernel; 17: 
 static bool g_use_tr = true;
 static int g_tn_w4 = 1;        // use_tr bit 3 CLEARS it: 256x256 gemm_tn_w4_kernel (default) vs the 128x128 kernel
 static bool g_w4s_few = false;      // opadpo_set_flags use_tr bit 10 (tests): 8 workgroups walk the tile list, so small problems exercise long walks
+static bool g_w4_chunk_deal = false; // opadpo_set_flags use_tr bit 12 (tests, A/B): every XCD walks a contiguous chunk of the tile order (rounds 1-5) instead of the block-cyclic deal
 static bool g_w4_nodeep = false;    // opadpo_set_flags use_tr bit 11 (tests, A/B): the products of >= 128 K-tiles keep the default K-loop text (round 6: they run the DEEP text)
 void opadpo_set_flags_impl(int use_glds, int use_tr) {
   g_gemm_variant = use_glds;
@@ -2276,6 +2282,7 @@ void opadpo_set_flags_impl(int use_glds, int use_tr) {
   opadpo_set_sample_compact((use_tr & 512) ? 0 : -1);      // bit 9 forces the diagnostic sampler; otherwise OPADPO_SAMPLE_COMPACT decides
   g_w4s_few = (use_tr & 1024) != 0;
   g_w4_nodeep = (use_tr & 2048) != 0;
+  g_w4_chunk_deal = (use_tr & 4096) != 0;
   g_dec64x_nw = (use_tr >> 7) & 3;      // bits 7-8: rows per workgroup of the dec64x kernel (0 = by shape, 1 / 2 / 3 = 48 / 64 / 128; tests)
 }
 bool opadpo_flag_tr() { return g_use_tr; }
@@ -2390,6 +2397,11 @@ hipError_t launch_gemm_nt(const GemmNTArgs& a_in, hipStream_t st) {
   // the wide projections lose 0.4-2 % with 4 or 6 and 6 % with 12.  OPADPO_W4_GM overrides (diagnostics).
   static const int env_gm = getenv("OPADPO_W4_GM") ? atoi(getenv("OPADPO_W4_GM")) : 0;
   a.group_m = env_gm > 0 ? env_gm : (a.N / P_BN <= 16 ? 4 : 8);
+  // 32-tile blocks dealt to the XCDs block-cyclically (round 6; common.h xcd_remap_cyclic): the eight XCDs of a round share one row group's A panels through the
+  // Infinity Cache and B stays within its reach between passes - down +2.0-5.3 %, gate|up +2.2-2.5 %, dgrad_gu +0.6-2.5 %, q|k|v +0.8-1.3 %, o +-0.2 %, step -1.0 %
+  // (profiles/r06z_ab_cyclic.txt).  OPADPO_XCD_CYCLIC=0 / opadpo_set_flags use_tr bit 12: the contiguous-chunk deal of rounds 1-5 (same results, bit for bit).
+  static const int env_cyc = getenv("OPADPO_XCD_CYCLIC") ? atoi(getenv("OPADPO_XCD_CYCLIC")) : 1;
+  a.xcd_cyclic = env_cyc && !g_w4_chunk_deal;
   const bool stream_hint = (a.act & OPADPO_GEMM_STREAM) != 0;
   a.act &= 0xff;
   const int g_gemm_variant = a.variant >= 0 ? a.variant : ::g_gemm_variant;      // per-call override (opadpo_ctx_set_flags)

@@ -43,6 +43,7 @@ struct GemmNTArgs {
   // output columns [g * b1_fold_n, (g + 1) * b1_fold_n) are the partial product of slice g: A1 columns from g * a1_group_stride (the grouped-A1 rule),
   // B1 = rows 0 .. b1_fold_n - 1 of the caller's matrix read from column g * b1_fold_koff on.  gemm_nt_w4_kernel only.
   int b1_fold_n = 0, b1_fold_koff = 0;
+  int xcd_cyclic = 0;                   // 256x256 4-wave kernels: 32-tile blocks dealt to the XCDs block-cyclically (xcd_remap_cyclic; set by launch_gemm_nt)
 };
 
 struct GemmTNArgs {

@@ -165,7 +165,7 @@ def set_flags(use_glds=10, use_tr: bool = True) -> None:
     bits 7-8 = weight rows per workgroup of the streaming kernel (0 by shape, 1 / 2 / 3 = 48 / 64 / 128), bit 9 = opadpo_sample runs its full
     vocabulary sweeps (the exactness yardstick; clear: OPADPO_SAMPLE_COMPACT decides, default compact), bit 10 = the streaming 256x256 GEMM walks
     its tile list on 8 workgroups (tests), bit 11 = the products of >= 128 K-tiles keep the default K-loop text (default since round 6: the DEEP text,
-    bit-identical results).
+    bit-identical results), bit 12 = contiguous-chunk deal of the tile order to the XCDs (rounds 1-5; default since round 6: block-cyclic, bit-identical).
     NOTE: a context's use_tr (CtxEngine / opadpo_ctx_set_flags) is a different bit space above bit 4 - see include/opadpo_hip.h."""
     v = 10 if use_glds is True else int(use_glds)
     load().opadpo_set_flags(v, int(use_tr))

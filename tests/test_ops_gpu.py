@@ -148,14 +148,15 @@ def test_gemm_nt_deep_k_text_is_bit_identical(L, N, K1, K2):
     rl_models.py:120) run the DEEP text of the generated K-loop (csrc/w4_kloop_gen.py: the same loads, barriers and MFMAs placed differently).  The MFMA order
     is the same, so the result must be BIT-equal to the default text (flag bit 11) - on both piece orders (N <= 4096: B first, beyond: A first), with and
     without the K-concatenated LoRA tail, ragged M, fp32 output with a residual - and equal to torch fp32 within bf16 rounding."""
-    M = 1500 + 37
+    M = 4300 + 37                                    # 17 row tiles: more than one full round of 256 tiles on every N but 512 (where the deals coincide)
     a1, b1 = rnd(M, K1, scale=0.5, seed=1), rnd(N, K1, scale=0.03, seed=2)
     kw = dict(a2=rnd(M, K2, scale=0.5, seed=3), b2=rnd(N, K2, scale=0.03, seed=4)) if K2 else {}
     want = a1.float() @ b1.float().t() + (kw["a2"].float() @ kw["b2"].float().t() if K2 else 0.0)
     res = torch.randn(M, N, device=dev())
     got = {}
     # variant 31: one tile per workgroup; variant 10 with bit 10: the STREAMING kernel on 8 workgroups (its DEEP text when bit 11 is clear)
-    for variant, bits in ((31, 0), (31, 2048), (10, 1024), (10, 1024 | 2048)):
+    # bit 12: the tile order dealt to the XCDs in contiguous chunks (rounds 1-5) instead of block-cyclically - the same tiles in another order
+    for variant, bits in ((31, 0), (31, 2048), (10, 1024), (10, 1024 | 2048), (31, 4096), (10, 1024 | 4096)):
         L.set_flags(variant, 1 | bits)
         ob = torch.empty(M, N, dtype=BF, device=dev()); of = torch.empty(M, N, device=dev())
         L.gemm_nt(a1, b1, ob, **kw)

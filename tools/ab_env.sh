@@ -1,11 +1,19 @@
 #!/bin/bash
-# same-box, sustained A/B of environment-switched kernel variants on the training GEMM shapes, interleaved processes:
-#   AB_CONFIGS="OPADPO_W4_NT=0 OPADPO_W4_NT=1" tools/ab_env.sh          (each config: comma-separated VAR=value pairs)
-for i in 1 2 3; do
-  for C in ${AB_CONFIGS:-"X=0"}; do
-    env $(echo $C | tr ',' ' ') GB_ONLY=gemm GB_VARIANTS=10 GB_ITERS=${GB_ITERS:-200} GB_M=${GB_M:-24576} python tools/gemm_bench.py 2>/dev/null | grep -E "'glds': 10" | python -c "
-import sys,ast
-r=[ast.literal_eval(l) for l in sys.stdin]
-print('%-40s' % '$C', ' '.join('%s %.0f' % (x['name'], x['tflops']) for x in r))"
+# tools/ab_env.sh VAR v0 v1 ...: tools/ab_stream.py (isolated GEMM shapes, default dispatch and one tile per workgroup) under VAR=v for each value, whole processes alternated twice;
+# AB_BENCH=1 adds the bench step the same way
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+VAR=$1; shift
+for rep in 1 2; do
+  for v in "$@"; do
+    echo "== $VAR=$v (rep $rep)"
+    env $VAR=$v AB_VENDOR=0 AB_VARIANTS=10,31 AB_M=${AB_M:-24576,32362} AB_SHAPES=${AB_SHAPES:-qkv,o,gate_up,down,lm_head,dgrad_gu} timeout 400 python tools/ab_stream.py 2>&1 | grep -v amdgpu.ids | cut -c1-230
   done
 done
+if [ "${AB_BENCH:-0}" = "1" ]; then
+for rep in 1 2; do
+  for v in "$@"; do
+    echo "== bench $VAR=$v (rep $rep)"
+    env $VAR=$v timeout 900 python bench.py --steps 6 --warmup 2 --no-extra-configs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"
+  done
+done
+fi
