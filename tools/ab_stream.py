@@ -17,6 +17,9 @@ L.load()
 dev = torch.device("cuda:0")
 shapes = [("qkv", 12288, 4096, 256, 4096), ("o", 4096, 4096, 256, 0), ("gate_up", 22016, 4096, 256, 11008), ("down", 4096, 11008, 256, 0),
           ("lm_head", 32000, 4096, 0, 0), ("dgrad_gu", 4096, 22016, 0, 0), ("dgrad_qkv", 4096, 12288, 0, 0)]
+if os.environ.get("AB_MODEL") == "13b":      # LLaVA-1.5-13B widths (hidden 5120, ffn 13824), LoRA r = 256
+    shapes = [("qkv", 15360, 5120, 256, 5120), ("o", 5120, 5120, 256, 0), ("gate_up", 27648, 5120, 256, 13824), ("down", 5120, 13824, 256, 0),
+              ("dgrad_gu", 5120, 27648, 0, 0), ("dgrad_qkv", 5120, 15360, 0, 0)]
 if os.environ.get("AB_SHAPES"):
     shapes = [sh for sh in shapes if sh[0] in os.environ["AB_SHAPES"].split(",")]
 rounds, iters = int(os.environ.get("AB_ROUNDS", 6)), int(os.environ.get("AB_ITERS", 20))
