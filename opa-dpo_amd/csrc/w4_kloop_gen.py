@@ -44,8 +44,23 @@ def frag_reg(op, kk, f):
     return f"v[{base + 4 * f}:{base + 4 * f + 3}]"
 
 
-def mfma(k, zero_c=False):
+def mfma_ij(k):
+    """(k-half, A fragment i, B fragment j) of the k-th MFMA of a tile.  Rows of 8 MFMAs share their A fragment; the B fragments are walked BACK AND FORTH (round 6), so
+    the MFMA at a row change keeps its B operand too: +1.1 % on a bare power-limited MFMA loop (tools/micro/mfma_power.hip modes 0 / 2), +0.3-0.6 % on every GEMM shape
+    (profiles/r06zz_ab_serp.txt).  Every accumulator still sees k-half 0 before k-half 1: bit-identical to the straight walk ("straight" experiment build)."""
     kk, i, j = k // 64, (k % 64) // 8, k % 8
+    if (i & 1) and "straight" not in EXP:
+        j = 7 - j
+    return kk, i, j
+
+
+def last_use_khalf0(op, f):
+    """index of the last MFMA of a tile that reads k-half-0 fragment f of operand op"""
+    return max(k for k in range(64) if (mfma_ij(k)[2] if op == "X" else mfma_ij(k)[1]) == f)
+
+
+def mfma(k, zero_c=False):
+    kk, i, j = mfma_ij(k)
     a = 4 * (8 * i + j)
     c = "0" if zero_c else f"a[{a}:{a + 3}]"
     return f"v_mfma_f32_16x16x32_bf16 a[{a}:{a + 3}], {frag_reg('Y', kk, i)}, {frag_reg('X', kk, j)}, {c}"
@@ -60,7 +75,8 @@ def slots_r5(first="X", spread_end=True, early_release=False, period=4, e_b2=(5,
     F, G = (first, "Y" if first == "X" else "X")
     s = [[] for _ in range(129)]
     for n in range(8):
-        s[1 + 2 * n].append(("rd", F, 1, n))
+        # (B fragments in the order the previous tile's last row of MFMAs released their registers: that row walks j = 7 .. 0, see mfma_ij)
+        s[1 + 2 * n].append(("rd", F, 1, 7 - n if F == "X" and "straight" not in EXP else n))
     s[2].append(("salu",))
     if early_release:
         s[16].append(("m0", 0))
@@ -158,7 +174,7 @@ def check_slots(slots, piece_ops):
     for op in ("X", "Y"):
         for f in range(8):
             k, idx = pos[("rd", op, 0, f)][0]
-            last_use = 56 + f if op == "X" else 8 * f + 7           # MFMA index of the last k-half-0 use of that register
+            last_use = last_use_khalf0(op, f)                      # MFMA index of the last k-half-0 use of that register
             assert idx > ibar and idx > itog and k > last_use, (op, f, k)
     assert flat[-1][1] == ("lgkm", 0) or any(it == ("lgkm", 0) for (k, it) in flat[-3:])
     # tog_rd after every k-half-1 read

@@ -16,11 +16,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ bf16x8_t frag(const uint4* src, int idx) { const uint4 v = src[idx]; return *(const bf16x8_t*)&v; }
 
-template <int MODE>      // 0: 16x16x32, 8 x 8 tiles of 4 registers; 1: 32x32x16, 4 x 4 tiles of 16 registers
+template <int MODE>      // 0: 16x16x32, 8 x 8 tiles of 4 registers; 1: 32x32x16, 4 x 4 tiles of 16 registers; 2: 16x16x32 with the B fragments walked back and forth (the MFMA at a row change keeps its B operand); 3: 16x16x32 column-major (B fragment fixed over 8 MFMAs, A changes)
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, float* __restrict__ out, int iters) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float sink = 0.f;
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 2 || MODE == 3) {
     f32x4_t acc[8][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -37,7 +37,12 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][i], b[k][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 8; ++j) {
+            if (MODE == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][i], b[k][j], acc[i][j], 0, 0, 0);
+            else if (MODE == 2) { const int jj = (i & 1) ? 7 - j : j; acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][i], b[k][jj], acc[i][jj], 0, 0, 0); }
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][j], b[k][i], acc[j][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -83,7 +88,7 @@ int main(int argc, char** argv) {
   hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
   const int cus = pr.multiProcessorCount;
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 4; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       const int iters = 20000;                                        // 128 (64) MFMAs = 2 * 128 * 128 * 64 FLOP per wave and iteration
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -93,7 +98,9 @@ int main(int argc, char** argv) {
       while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
         for (int q = 0; q < 4; ++q) {
           if (mode == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(cus), dim3(256), 0, 0, d, o, iters);
-          else hipLaunchKernelGGL(mfma_loop<1>, dim3(cus), dim3(256), 0, 0, d, o, iters);
+          else if (mode == 1) hipLaunchKernelGGL(mfma_loop<1>, dim3(cus), dim3(256), 0, 0, d, o, iters);
+          else if (mode == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(cus), dim3(256), 0, 0, d, o, iters);
+          else hipLaunchKernelGGL(mfma_loop<3>, dim3(cus), dim3(256), 0, 0, d, o, iters);
           ++launches;
         }
         hipDeviceSynchronize();
@@ -101,7 +108,7 @@ int main(int argc, char** argv) {
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double fl = (double)launches * cus * 4 * iters * 2.0 * 128 * 128 * 64;
-      printf("mode %d (%s) %s operands rep %d: %.1f TF/s over %.2f s (%d launches)\n", mode, mode ? "32x32x16" : "16x16x32", zero ? "zero" : "random", rep, fl / (ms * 1e-3) / 1e12, ms * 1e-3, launches);
+      printf("mode %d (%s) %s operands rep %d: %.1f TF/s over %.2f s (%d launches)\n", mode, mode == 1 ? "32x32x16" : mode == 2 ? "16x16x32 serpentine" : mode == 3 ? "16x16x32 column-major" : "16x16x32", zero ? "zero" : "random", rep, fl / (ms * 1e-3) / 1e12, ms * 1e-3, launches);
       fflush(stdout);
     }
   }
