@@ -2065,7 +2065,7 @@ __global__ __launch_bounds__(256) void gemm_tn_w4_kernel(GemmTNGroup G) {
     auto mfma_run = [&](int kk, int idx0, int n) {      // idx = i*8 + j
 #pragma unroll
       for (int e = 0; e < n; ++e) {
-        const int idx = idx0 + e, i = idx >> 3, j = idx & 7;
+        const int idx = idx0 + e, i = idx >> 3, j = (i & 1) ? 7 - (idx & 7) : (idx & 7);      // the second operand's fragments walked back and forth: the MFMA at a row change keeps it (as in the gemm_nt K-loop; same sums per accumulator)
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[kk][i]), "v"(fb[kk][j]));
       }
     };
