@@ -2293,10 +2293,17 @@ static int g_w4_order = -1;      // OPADPO_W4_ORDER=0 / 1 forces A first / B fir
 // the tile list and keeps its K-tile pipeline full across output tiles.  OPADPO_W4S=0 / variant 31: one tile per workgroup (A/B, cross-check).
 static int g_w4s = -1, g_w4s_cus = 0, g_w4s_maxnt = 128;
 static const int env_rope_direct_ = getenv("OPADPO_ROPE_DIRECT") ? atoi(getenv("OPADPO_ROPE_DIRECT")) : 1;      // 0: table-free rotary embedding through the staged epilogue (rounds 3-4; A/B)
+// piece order of the 256x256 kernels: the B pieces of a K-tile first for <= 16 column tiles (o / down / the dgrads) and - under the block-cyclic deal, where the A panels
+// of a round are shared chip-wide - for the shallow products of up to 64 column tiles as well (q|k|v: +0.8-1.8 % at 7B, +0.9 % at 13B; the widest shapes lose 5-7 % with it:
+// profiles/r06zz_ab_order_cyclic.txt, r06zz_ab_order_other_shapes.txt); otherwise the A pieces first.  A placement choice: the results do not depend on it.
+static bool w4_b_first(const GemmNTArgs& a) {
+  const int tiles_n = a.N / P_BN, nt = (a.K1 + a.K2) / P_BK;
+  return tiles_n <= 16 || (tiles_n <= 64 && nt < 128);
+}
 static const int env_w4_deep_ = getenv("OPADPO_W4_DEEP") ? atoi(getenv("OPADPO_W4_DEEP")) : 2;      // 2 (default): >= 128 K-tiles run the DEEP text, streaming where eligible; 1: DEEP text, one tile per workgroup; 0: default text (A/B)
 #define W4_LAUNCH(GRID_)                                                                                                     \
   do {                                                                                                                       \
-    const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : a.N / P_BN <= 16;                                                    \
+    const bool ob_ = g_w4_order >= 0 ? g_w4_order != 0 : w4_b_first(a);                                                       \
     const int grid_ = (GRID_), cus_ = g_w4s_few ? 8 : g_w4s_cus;                                                             \
     const bool stream_ = g_w4s > 0 && g_gemm_variant != 31 && !a.bias && !a.rope_cos && !a.rope_pos && a.b1_fold_n == 0 &&                               \
                          ((a.act == 0 && (!a.R || w4_direct_resid_ok(a))) || ((w4_direct_swiglu_bwd_ok(a) || w4_direct_swiglu_pair_ok(a)) && !a.swiglu_bwd_staged)) && \
