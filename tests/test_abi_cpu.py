@@ -139,3 +139,34 @@ def test_generated_kloop_is_current():
     gen = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opa-dpo_amd", "csrc", "w4_kloop_gen.py")
     r = subprocess.run([sys.executable, gen, "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_kloop_generator_experiment_variants(tmp_path):
+    """The generator's experiment variants (tools/build_kloop_exp.sh: W4K_EXP / W4K_OUT) pass its hazard checks too, never write the committed file, and the DEEP
+    texts the library ships (W4K_/W4S_TEXT_*_DEEP) are in the committed file; the MFMA walk visits every accumulator exactly once per k-half in both directions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(root, "opa-dpo_amd", "csrc", "w4_kloop_gen.py")
+    inc = open(os.path.join(root, "opa-dpo_amd", "csrc", "w4_kloop.inc")).read()
+    for name in ("W4K_TEXT_BFIRST", "W4K_TEXT_AFIRST", "W4K_TEXT_BFIRST_DEEP", "W4K_TEXT_AFIRST_DEEP", "W4S_TEXT_BFIRST", "W4S_TEXT_AFIRST", "W4S_TEXT_BFIRST_DEEP",
+                 "W4S_TEXT_AFIRST_DEEP"):
+        assert "#define " + name + " " in inc, name
+    for exp in ("noadv", "early", "p3", "eb8p3l0w92", "eb5p3l3w96", "w96", "straight"):
+        out = tmp_path / (exp + ".inc")
+        r = subprocess.run([sys.executable, gen], capture_output=True, text=True, env=dict(os.environ, W4K_EXP=exp, W4K_OUT=str(out)))
+        assert r.returncode == 0 and out.exists() and "v_mfma_f32_16x16x32_bf16" in out.read_text(), (exp, r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, gen], capture_output=True, text=True, env=dict(os.environ, W4K_EXP="noadv"))      # no W4K_OUT: refused
+    assert r.returncode != 0
+    sys.path.insert(0, os.path.dirname(gen))
+    try:
+        import w4_kloop_gen as g
+        seen = {}
+        for k in range(128):
+            kk, i, j = g.mfma_ij(k)
+            seen.setdefault(kk, []).append((i, j))
+        assert sorted(seen[0]) == sorted(seen[1]) == [(i, j) for i in range(8) for j in range(8)]
+        assert all(k < 64 for k in range(128) if g.mfma_ij(k)[0] == 0)                      # every k-half-0 MFMA before every k-half-1 one
+        assert [g.mfma_ij(k)[2] for k in range(8, 16)] == list(range(7, -1, -1))            # odd rows walk the B fragments backwards
+    finally:
+        sys.path.pop(0)
